@@ -1,0 +1,919 @@
+/*
+ * oracle/pp_oracle.c -- see pp_oracle.h.  TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+ *
+ * Plain C restatement (fp64 displacement field, as the reference: sitkVectorFloat64,
+ * platipy/imaging/registration/deformable.py:97-98,139,159) of the ITK 5.3 filters the
+ * reference calls through SimpleITK 2.3.1 (poetry.lock:4523).  Build with
+ * -ffp-contract=off so the arithmetic order written here is the one executed.
+ */
+#include "pp_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* geometry (itk::ImageBase::TransformIndexToPhysicalPoint / PhysicalPointToContinuousIndex) */
+
+typedef struct {
+  double i2p[9]; /* Direction * diag(spacing) */
+  double p2i[9]; /* inverse */
+  double origin[3];
+  int n[3];
+} geom_x;
+
+static void mat3_inv(const double* m, double* r) {
+  double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7],
+         i = m[8];
+  double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  double det = a * A + b * B + c * C;
+  double id = 1.0 / det;
+  r[0] = A * id;
+  r[1] = -(b * i - c * h) * id;
+  r[2] = (b * f - c * e) * id;
+  r[3] = B * id;
+  r[4] = (a * i - c * g) * id;
+  r[5] = -(a * f - c * d) * id;
+  r[6] = C * id;
+  r[7] = -(a * h - b * g) * id;
+  r[8] = (a * e - b * d) * id;
+}
+
+static int is_identity_dir(const double* d) {
+  static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int k = 0; k < 9; ++k)
+    if (d[k] != I[k]) return 0;
+  return 1;
+}
+
+static void geom_expand(const orc_geom* g, geom_x* x) {
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) x->i2p[r * 3 + c] = g->direction[r * 3 + c] * g->spacing[c];
+  if (is_identity_dir(g->direction)) {
+    /* diag(1/s): what vnl's inverse yields for a diagonal matrix */
+    memset(x->p2i, 0, sizeof(x->p2i));
+    for (int k = 0; k < 3; ++k) x->p2i[k * 3 + k] = 1.0 / g->spacing[k];
+  } else {
+    mat3_inv(x->i2p, x->p2i);
+  }
+  for (int k = 0; k < 3; ++k) {
+    x->origin[k] = g->origin[k];
+    x->n[k] = g->size[k];
+  }
+}
+
+static inline void idx_to_phys(const geom_x* g, double ix, double iy, double iz, double* p) {
+  for (int r = 0; r < 3; ++r)
+    p[r] = g->origin[r] + (g->i2p[r * 3 + 0] * ix + g->i2p[r * 3 + 1] * iy + g->i2p[r * 3 + 2] * iz);
+}
+
+static inline void phys_to_cidx(const geom_x* g, const double* p, double* c) {
+  double v[3] = {p[0] - g->origin[0], p[1] - g->origin[1], p[2] - g->origin[2]};
+  for (int r = 0; r < 3; ++r)
+    c[r] = g->p2i[r * 3 + 0] * v[0] + g->p2i[r * 3 + 1] * v[1] + g->p2i[r * 3 + 2] * v[2];
+}
+
+/* itk::ImageFunction::IsInsideBuffer(ContinuousIndex): [start-0.5, end+0.5) per axis,
+ * written as a negated conjunction so NaN is outside. */
+static inline int inside_buffer(const int* n, const double* c) {
+  for (int k = 0; k < 3; ++k)
+    if (!(c[k] >= -0.5 && c[k] < (double)n[k] - 0.5)) return 0;
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* interpolators */
+
+/* itk::LinearInterpolateImageFunction::EvaluateOptimized(Dispatch<3>): base index = floor,
+ * clamped up to the start index; an axis is interpolated only when its distance is > 0 and
+ * base+1 is still inside; lerps nest x, then y, then z, as a + (b - a) * d in double.
+ * GET(i) must yield a double. */
+#define LERP_BODY(GET)                                                                    \
+  long bx = (long)floor(c[0]), by = (long)floor(c[1]), bz = (long)floor(c[2]);            \
+  if (bx < 0) bx = 0;                                                                     \
+  if (by < 0) by = 0;                                                                     \
+  if (bz < 0) bz = 0;                                                                     \
+  const double dx = c[0] - (double)bx, dy = c[1] - (double)by, dz = c[2] - (double)bz;    \
+  const int ax = (dx > 0.0) && (bx + 1 <= n[0] - 1);                                      \
+  const int ay = (dy > 0.0) && (by + 1 <= n[1] - 1);                                      \
+  const int az = (dz > 0.0) && (bz + 1 <= n[2] - 1);                                      \
+  const size_t sx = 1, sy = (size_t)n[0], sz = (size_t)n[0] * n[1];                       \
+  const size_t b = (size_t)bz * sz + (size_t)by * sy + (size_t)bx;                        \
+  double v0 = GET(b);                                                                     \
+  if (ax) v0 = v0 + (GET(b + sx) - v0) * dx;                                              \
+  if (ay) {                                                                               \
+    double v1 = GET(b + sy);                                                              \
+    if (ax) v1 = v1 + (GET(b + sy + sx) - v1) * dx;                                       \
+    v0 = v0 + (v1 - v0) * dy;                                                             \
+  }                                                                                       \
+  if (az) {                                                                               \
+    double w0 = GET(b + sz);                                                              \
+    if (ax) w0 = w0 + (GET(b + sz + sx) - w0) * dx;                                       \
+    if (ay) {                                                                             \
+      double w1 = GET(b + sz + sy);                                                       \
+      if (ax) w1 = w1 + (GET(b + sz + sy + sx) - w1) * dx;                                \
+      w0 = w0 + (w1 - w0) * dy;                                                           \
+    }                                                                                     \
+    v0 = v0 + (w0 - v0) * dz;                                                             \
+  }                                                                                       \
+  return v0;
+
+static inline double lerp_f32(const float* im, const int* n, const double* c) {
+#define GETF(i) ((double)im[(i)])
+  LERP_BODY(GETF)
+#undef GETF
+}
+static inline double lerp_u8(const uint8_t* im, const int* n, const double* c) {
+#define GETB(i) ((double)im[(i)])
+  LERP_BODY(GETB)
+#undef GETB
+}
+static inline double lerp_f64(const double* im, const int* n, const double* c) {
+#define GETD(i) (im[(i)])
+  LERP_BODY(GETD)
+#undef GETD
+}
+
+/* itk::VectorLinearInterpolateImageFunction::EvaluateAtContinuousIndex, the default
+ * interpolator of itk::DisplacementFieldTransform: weighted sum over the 2^3 neighbours,
+ * neighbour indices clamped into the buffer, early exit once the overlap sums to 1. */
+static inline void veclerp_f64(const double* f, const int* n, const double* c, double* out) {
+  const size_t N = (size_t)n[0] * n[1] * n[2];
+  long base[3];
+  double dist[3];
+  for (int k = 0; k < 3; ++k) {
+    base[k] = (long)floor(c[k]);
+    dist[k] = c[k] - (double)base[k];
+  }
+  out[0] = out[1] = out[2] = 0.0;
+  double total = 0.0;
+  for (unsigned counter = 0; counter < 8; ++counter) {
+    double overlap = 1.0;
+    unsigned upper = counter;
+    long ni[3];
+    for (int k = 0; k < 3; ++k) {
+      if (upper & 1) {
+        ni[k] = base[k] + 1;
+        if (ni[k] > n[k] - 1) ni[k] = n[k] - 1;
+        overlap *= dist[k];
+      } else {
+        ni[k] = base[k];
+        if (ni[k] < 0) ni[k] = 0;
+        overlap *= 1.0 - dist[k];
+      }
+      upper >>= 1;
+    }
+    if (overlap) {
+      const size_t i = ((size_t)ni[2] * n[1] + (size_t)ni[1]) * n[0] + (size_t)ni[0];
+      out[0] += overlap * f[i];
+      out[1] += overlap * f[N + i];
+      out[2] += overlap * f[2 * N + i];
+      total += overlap;
+    }
+    if (total == 1.0) break;
+  }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* itkGaussianOperator.hxx: GenerateCoefficients + the Numerical-Recipes style Bessel
+ * polynomials it uses. */
+
+static double bessel_i0(double y) {
+  double d = fabs(y), acc, m;
+  if (d < 3.75) {
+    m = y / 3.75;
+    m *= m;
+    acc = 1.0 + m * (3.5156229 +
+                     m * (3.0899424 +
+                          m * (1.2067492 + m * (0.2659732 + m * (0.360768e-1 + m * 0.45813e-2)))));
+  } else {
+    m = 3.75 / d;
+    acc = (exp(d) / sqrt(d)) *
+          (0.39894228 +
+           m * (0.1328592e-1 +
+                m * (0.225319e-2 +
+                     m * (-0.157565e-2 +
+                          m * (0.916281e-2 +
+                               m * (-0.2057706e-1 +
+                                    m * (0.2635537e-1 + m * (-0.1647633e-1 + m * 0.392377e-2))))))));
+  }
+  return acc;
+}
+
+static double bessel_i1(double y) {
+  double d = fabs(y), acc, m;
+  if (d < 3.75) {
+    m = y / 3.75;
+    m *= m;
+    acc = d * (0.5 + m * (0.87890594 +
+                          m * (0.51498869 +
+                               m * (0.15084934 +
+                                    m * (0.2658733e-1 + m * (0.301532e-2 + m * 0.32411e-3))))));
+  } else {
+    m = 3.75 / d;
+    acc = 0.2282967e-1 + m * (-0.2895312e-1 + m * (0.1787654e-1 - m * 0.420059e-2));
+    acc = 0.39894228 +
+          m * (-0.3988024e-1 +
+               m * (-0.362018e-2 + m * (0.163801e-2 + m * (-0.1031555e-1 + m * acc))));
+    acc *= (exp(d) / sqrt(d));
+  }
+  return (y < 0.0) ? -acc : acc;
+}
+
+static double bessel_in(int n, double y) {
+  const double DIGITS = 10.0;
+  if (y == 0.0) return 0.0;
+  double toy = 2.0 / fabs(y);
+  double qip = 0.0, acc = 0.0, qi = 1.0, qim;
+  for (int j = 2 * (n + (int)(DIGITS * sqrt((double)n))); j > 0; j--) {
+    qim = qip + j * toy * qi;
+    qip = qi;
+    qi = qim;
+    if (fabs(qi) > 1.0e10) {
+      acc *= 1.0e-10;
+      qi *= 1.0e-10;
+      qip *= 1.0e-10;
+    }
+    if (j == n) acc = qip;
+  }
+  acc *= bessel_i0(y) / qi;
+  return (y < 0.0 && (n & 1)) ? -acc : acc;
+}
+
+int orc_gaussian_operator(double variance, double max_error, int max_kernel_width,
+                          double* coeffs, int cap) {
+  /* half kernel, centre first */
+  int alloc = 64, len = 0;
+  double* h = (double*)malloc(sizeof(double) * alloc);
+  const double et = exp(-variance);
+  const double capv = 1.0 - max_error;
+  double sum = 0.0;
+  h[len++] = et * bessel_i0(variance);
+  sum += h[0];
+  h[len++] = et * bessel_i1(variance);
+  sum += h[1] * 2.0;
+  for (int i = 2; sum < capv; ++i) {
+    if (len == alloc) {
+      alloc *= 2;
+      h = (double*)realloc(h, sizeof(double) * alloc);
+    }
+    h[len++] = et * bessel_in(i, variance);
+    sum += h[i] * 2.0;
+    if (h[i] < sum * DBL_EPSILON) break;         /* cannot accumulate further */
+    if (len > max_kernel_width) break;           /* "coeff.size() > m_MaximumKernelWidth" */
+  }
+  for (int i = 0; i < len; ++i) h[i] /= sum;
+  const int radius = len - 1;
+  if (2 * radius + 1 > cap) {
+    free(h);
+    return -1;
+  }
+  for (int i = 0; i <= radius; ++i) {
+    coeffs[radius + i] = h[i];
+    coeffs[radius - i] = h[i];
+  }
+  free(h);
+  return radius;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* directional FIR with ZeroFluxNeumann (clamped index) boundary; sum runs from the
+ * neighbourhood's first element to its last (itk::NeighborhoodInnerProduct). */
+
+static void conv_axis_f32(const float* in, float* out, const int* n, int axis,
+                          const double* c, int r) {
+  const long nx = n[0], ny = n[1], nz = n[2];
+  const long stride = axis == 0 ? 1 : (axis == 1 ? nx : nx * ny);
+  const long len = n[axis];
+#pragma omp parallel for schedule(static)
+  for (long z = 0; z < nz; ++z)
+    for (long y = 0; y < ny; ++y)
+      for (long x = 0; x < nx; ++x) {
+        const long pos = axis == 0 ? x : (axis == 1 ? y : z);
+        const size_t base = (size_t)z * ny * nx + (size_t)y * nx + x;
+        double s = 0.0;
+        for (int k = -r; k <= r; ++k) {
+          long q = pos + k;
+          if (q < 0) q = 0;
+          if (q > len - 1) q = len - 1;
+          s += c[k + r] * (double)in[(long)base + (q - pos) * stride];
+        }
+        out[base] = (float)s;
+      }
+}
+
+static void conv_axis_f64(const double* in, double* out, const int* n, int axis,
+                          const double* c, int r) {
+  const long nx = n[0], ny = n[1], nz = n[2];
+  const long stride = axis == 0 ? 1 : (axis == 1 ? nx : nx * ny);
+  const long len = n[axis];
+#pragma omp parallel for schedule(static)
+  for (long z = 0; z < nz; ++z)
+    for (long y = 0; y < ny; ++y)
+      for (long x = 0; x < nx; ++x) {
+        const long pos = axis == 0 ? x : (axis == 1 ? y : z);
+        const size_t base = (size_t)z * ny * nx + (size_t)y * nx + x;
+        double s = 0.0;
+        for (int k = -r; k <= r; ++k) {
+          long q = pos + k;
+          if (q < 0) q = 0;
+          if (q > len - 1) q = len - 1;
+          s += c[k + r] * in[(long)base + (q - pos) * stride];
+        }
+        out[base] = s;
+      }
+}
+
+#define MAX_TAPS 4096
+
+int orc_discrete_gaussian_f32(const float* in, float* out, const int size[3],
+                              const double spacing[3], const double variance[3],
+                              double max_error, int max_kernel_width, int use_spacing) {
+  const size_t N = (size_t)size[0] * size[1] * size[2];
+  float* a = (float*)malloc(N * sizeof(float));
+  float* b = (float*)malloc(N * sizeof(float));
+  double* c = (double*)malloc(sizeof(double) * MAX_TAPS);
+  if (!a || !b || !c) return -2;
+  memcpy(a, in, N * sizeof(float));
+  /* itkDiscreteGaussianImageFilter::GenerateData: oper[D-1-i] has direction i and the
+   * mini-pipeline runs oper[0], oper[1], ... => z, then y, then x. */
+  for (int pass = 0; pass < 3; ++pass) {
+    const int axis = 2 - pass;
+    double var = variance[axis];
+    if (use_spacing) var = var / (spacing[axis] * spacing[axis]);
+    int r = orc_gaussian_operator(var, max_error, max_kernel_width, c, MAX_TAPS);
+    if (r < 0) return -1;
+    conv_axis_f32(a, b, size, axis, c, r);
+    float* t = a;
+    a = b;
+    b = t;
+  }
+  memcpy(out, a, N * sizeof(float));
+  free(a);
+  free(b);
+  free(c);
+  return 0;
+}
+
+int orc_smooth_field_f64(double* field, const int size[3], const double sigma_vox[3],
+                         double max_error, int max_kernel_width) {
+  const size_t N = (size_t)size[0] * size[1] * size[2];
+  double* tmp = (double*)malloc(N * sizeof(double));
+  double* c = (double*)malloc(sizeof(double) * MAX_TAPS);
+  if (!tmp || !c) return -2;
+  /* itkPDEDeformableRegistrationFilter::SmoothDisplacementField: for j = 0..D-1 (x, y, z),
+   * GaussianOperator(variance = sigma_j^2, MaximumError, MaximumKernelWidth), each pass over
+   * the whole field before the next. */
+  for (int comp = 0; comp < 3; ++comp) {
+    double* f = field + comp * N;
+    double* src = f;
+    double* dst = tmp;
+    for (int axis = 0; axis < 3; ++axis) {
+      int r = orc_gaussian_operator(sigma_vox[axis] * sigma_vox[axis], max_error,
+                                    max_kernel_width, c, MAX_TAPS);
+      if (r < 0) return -1;
+      conv_axis_f64(src, dst, size, axis, c, r);
+      double* t = src;
+      src = dst;
+      dst = t;
+    }
+    if (src != f) memcpy(f, src, N * sizeof(double));
+  }
+  free(tmp);
+  free(c);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* itkWarpImageFilter::DynamicThreadedGenerateData, field on the output grid
+ * (m_DefFieldSameInformation): point = IndexToPhysical(index) + D[index]; inside the moving
+ * buffer -> linear interpolation cast to the pixel type, else EdgePaddingValue. */
+int orc_warp_image_f32(const float* moving, const orc_geom* gm, const double* field,
+                       const orc_geom* gout, float edge_value, float* out) {
+  geom_x xm, xo;
+  geom_expand(gm, &xm);
+  geom_expand(gout, &xo);
+  const long nx = gout->size[0], ny = gout->size[1], nz = gout->size[2];
+  const size_t N = (size_t)nx * ny * nz;
+#pragma omp parallel for schedule(static)
+  for (long z = 0; z < nz; ++z)
+    for (long y = 0; y < ny; ++y)
+      for (long x = 0; x < nx; ++x) {
+        const size_t i = ((size_t)z * ny + y) * nx + x;
+        double p[3], c[3];
+        idx_to_phys(&xo, (double)x, (double)y, (double)z, p);
+        p[0] += field[i];
+        p[1] += field[N + i];
+        p[2] += field[2 * N + i];
+        phys_to_cidx(&xm, p, c);
+        if (inside_buffer(xm.n, c))
+          out[i] = (float)lerp_f32(moving, xm.n, c);
+        else
+          out[i] = edge_value;
+      }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* itkESMDemonsRegistrationFunction::ComputeUpdate, UseGradientType = Symmetric (the
+ * FastSymmetricForcesDemons default), evaluated at every voxel of the fixed grid.  Identity
+ * direction only (TransformLocalVectorToPhysicalVector is then the identity). */
+int orc_esm_update(const float* fixed, const float* warped, const orc_geom* g,
+                   double max_step_length, double intensity_threshold,
+                   double denominator_threshold, double* update, orc_demons_stats* stats) {
+  if (!is_identity_dir(g->direction)) return -3;
+  const long n[3] = {g->size[0], g->size[1], g->size[2]};
+  const long st[3] = {1, n[0], n[0] * n[1]};
+  const size_t N = (size_t)n[0] * n[1] * n[2];
+  const double* sp = g->spacing;
+  /* InitializeIteration: m_Normalizer = mean(spacing^2) * MaximumUpdateStepLength^2 */
+  double normalizer;
+  if (max_step_length > 0.0) {
+    normalizer = 0.0;
+    for (int k = 0; k < 3; ++k) normalizer += sp[k] * sp[k];
+    normalizer *= max_step_length * max_step_length / 3.0;
+  } else {
+    normalizer = -1.0;
+  }
+  const float SENT = FLT_MAX; /* NumericTraits<MovingPixelType>::max() */
+  double ssd = 0.0, ssc = 0.0;
+  long long npx = 0;
+#pragma omp parallel for schedule(static) reduction(+ : ssd, ssc, npx)
+  for (long z = 0; z < n[2]; ++z)
+    for (long y = 0; y < n[1]; ++y)
+      for (long x = 0; x < n[0]; ++x) {
+        const long idx[3] = {x, y, z};
+        const size_t i = ((size_t)z * n[1] + y) * n[0] + x;
+        double u[3] = {0.0, 0.0, 0.0};
+        const float mpix = warped[i];
+        if (mpix == SENT) {
+          update[i] = update[N + i] = update[2 * N + i] = 0.0;
+          continue; /* returns before the global-data accumulation */
+        }
+        const double fixedValue = (double)fixed[i];
+        const double movingValue = (double)mpix;
+        double grad2[3];
+        for (int d = 0; d < 3; ++d) {
+          /* warped-moving gradient "more or less by hand", sentinel-aware */
+          double wg;
+          if (n[d] == 0) {
+            wg = 0.0;
+          } else if (n[d] == 1) {
+            /* index == FirstIndex and index == LastIndex-1: the first branch wins and
+             * reads index+1, out of bounds in ITK; treat as a crunched border */
+            wg = 0.0;
+          } else if (idx[d] == 0) {
+            const float mv = warped[i + st[d]];
+            if (mv == SENT)
+              wg = 0.0;
+            else {
+              wg = (double)mv - movingValue;
+              wg /= sp[d];
+            }
+          } else if (idx[d] == n[d] - 1) {
+            const float mv = warped[i - st[d]];
+            if (mv == SENT)
+              wg = 0.0;
+            else {
+              wg = movingValue - (double)mv;
+              wg /= sp[d];
+            }
+          } else {
+            const float mp = warped[i + st[d]];
+            const float mm = warped[i - st[d]];
+            if (mp == SENT) {
+              wg = movingValue;
+              if (mm == SENT)
+                wg = 0.0;
+              else {
+                wg -= (double)mm;
+                wg /= sp[d];
+              }
+            } else {
+              wg = (double)mp;
+              if (mm == SENT) {
+                wg -= movingValue;
+                wg /= sp[d];
+              } else {
+                wg -= (double)mm;
+                wg *= 0.5 / sp[d];
+              }
+            }
+          }
+          /* itk::CentralDifferenceImageFunction::EvaluateAtIndex on the fixed image:
+           * zero on the first/last index of an axis */
+          double fg;
+          if (idx[d] < 1 || idx[d] > n[d] - 2) {
+            fg = 0.0;
+          } else {
+            fg = (double)fixed[i + st[d]];
+            fg -= (double)fixed[i - st[d]];
+            fg *= 0.5 / sp[d];
+          }
+          grad2[d] = fg + wg;
+        }
+        const double g2 = grad2[0] * grad2[0] + grad2[1] * grad2[1] + grad2[2] * grad2[2];
+        const double speed = fixedValue - movingValue;
+        if (fabs(speed) < intensity_threshold) {
+          /* update stays 0 */
+        } else {
+          double denom;
+          if (normalizer > 0.0)
+            denom = g2 + (speed * speed) / normalizer;
+          else
+            denom = g2;
+          if (denom < denominator_threshold) {
+            /* 0 */
+          } else {
+            const double factor = 2.0 * speed / denom;
+            for (int d = 0; d < 3; ++d) u[d] = factor * grad2[d];
+          }
+        }
+        update[i] = u[0];
+        update[N + i] = u[1];
+        update[2 * N + i] = u[2];
+        ssd += speed * speed;
+        npx += 1;
+        ssc += u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+      }
+  if (stats) {
+    stats->sum_sq_diff = ssd;
+    stats->sum_sq_change = ssc;
+    stats->n_pixels = npx;
+    if (npx) {
+      stats->metric = ssd / (double)npx;
+      stats->rms_change = sqrt(ssc / (double)npx);
+    }
+  }
+  return 0;
+}
+
+/* itkFiniteDifferenceImageFilter::GenerateData driving
+ * itkFastSymmetricForcesDemonsRegistrationFilter::{InitializeIteration, ApplyUpdate}. */
+int orc_demons_execute(const float* fixed, const float* moving, const orc_geom* g,
+                       int n_iterations, const double sigma_d_vox[3], const double sigma_u_vox[3],
+                       int smooth_displacement, int smooth_update, double max_rms_error,
+                       double max_step_length, double intensity_threshold, double max_error,
+                       int max_kernel_width, double* field, orc_demons_stats* stats) {
+  const size_t N = (size_t)g->size[0] * g->size[1] * g->size[2];
+  float* warped = (float*)malloc(N * sizeof(float));
+  double* update = (double*)malloc(3 * N * sizeof(double));
+  if (!warped || !update) return -2;
+  memset(field, 0, 3 * N * sizeof(double)); /* CopyInputToOutput with no initial field */
+  orc_demons_stats st;
+  memset(&st, 0, sizeof(st));
+  st.metric = DBL_MAX;
+  st.rms_change = DBL_MAX;
+  double rms_change = 0.0; /* FiniteDifferenceImageFilter::m_RMSChange */
+  int elapsed = 0;
+  int rc = 0;
+  for (;;) {
+    /* Halt() */
+    if (elapsed >= n_iterations) break;
+    if (elapsed != 0 && max_rms_error > rms_change) break;
+    /* InitializeIteration: warp moving through the current field, sentinel padding */
+    rc = orc_warp_image_f32(moving, g, field, g, FLT_MAX, warped);
+    if (rc) break;
+    /* CalculateChange */
+    rc = orc_esm_update(fixed, warped, g, max_step_length, intensity_threshold, 1e-9, update,
+                        &st);
+    if (rc) break;
+    /* ApplyUpdate(dt = 1) */
+    if (smooth_update) {
+      rc = orc_smooth_field_f64(update, g->size, sigma_u_vox, max_error, max_kernel_width);
+      if (rc) break;
+    }
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)(3 * N); ++i) field[i] = field[i] + update[i];
+    rms_change = st.rms_change;
+    if (smooth_displacement) {
+      rc = orc_smooth_field_f64(field, g->size, sigma_d_vox, max_error, max_kernel_width);
+      if (rc) break;
+    }
+    ++elapsed;
+  }
+  st.elapsed_iterations = elapsed;
+  if (stats) *stats = st;
+  free(warped);
+  free(update);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* itkResampleImageFilter (non-linear-transform path: every output voxel is mapped through
+ * index -> physical -> transform -> input continuous index). */
+
+typedef struct {
+  const double* A;
+  const double* t;
+  const double* field;
+  geom_x gd;
+} xform;
+
+static inline void xform_point(const xform* T, const double* p, double* q) {
+  if (T->A) {
+    for (int r = 0; r < 3; ++r)
+      q[r] = T->A[r * 3 + 0] * p[0] + T->A[r * 3 + 1] * p[1] + T->A[r * 3 + 2] * p[2] + T->t[r];
+  } else {
+    q[0] = p[0];
+    q[1] = p[1];
+    q[2] = p[2];
+  }
+  if (T->field) {
+    /* itkDisplacementFieldTransform::TransformPoint */
+    double c[3], d[3];
+    phys_to_cidx(&T->gd, q, c);
+    if (inside_buffer(T->gd.n, c)) {
+      veclerp_f64(T->field, T->gd.n, c, d);
+      q[0] += d[0];
+      q[1] += d[1];
+      q[2] += d[2];
+    }
+  }
+}
+
+#define RESAMPLE_LOOP(STORE_INSIDE, STORE_DEFAULT)                                 \
+  geom_x xi, xo;                                                                   \
+  geom_expand(gin, &xi);                                                           \
+  geom_expand(gout, &xo);                                                          \
+  xform T;                                                                         \
+  T.A = affine_A;                                                                  \
+  T.t = affine_t;                                                                  \
+  T.field = field;                                                                 \
+  if (field) geom_expand(gd, &T.gd);                                               \
+  const long nx = gout->size[0], ny = gout->size[1], nz = gout->size[2];           \
+  _Pragma("omp parallel for schedule(static)") for (long z = 0; z < nz; ++z)      \
+      for (long y = 0; y < ny; ++y) for (long x = 0; x < nx; ++x) {                \
+    const size_t i = ((size_t)z * ny + y) * nx + x;                                \
+    double p[3], q[3], c[3];                                                       \
+    idx_to_phys(&xo, (double)x, (double)y, (double)z, p);                          \
+    xform_point(&T, p, q);                                                         \
+    phys_to_cidx(&xi, q, c);                                                       \
+    if (inside_buffer(xi.n, c)) {                                                  \
+      STORE_INSIDE                                                                 \
+    } else {                                                                       \
+      STORE_DEFAULT                                                                \
+    }                                                                              \
+  }
+
+static inline size_t nn_index(const int* n, const double* c) {
+  /* itk::Math::RoundHalfIntegerUp per axis */
+  long ix = (long)floor(c[0] + 0.5), iy = (long)floor(c[1] + 0.5), iz = (long)floor(c[2] + 0.5);
+  return ((size_t)iz * n[1] + (size_t)iy) * n[0] + (size_t)ix;
+}
+
+int orc_resample_f32(const float* in, const orc_geom* gin, const orc_geom* gout,
+                     const double* affine_A, const double* affine_t, const double* field,
+                     const orc_geom* gd, int interp, double default_value, float* out) {
+  if (interp == ORC_INTERP_LINEAR) {
+    RESAMPLE_LOOP(out[i] = (float)lerp_f32(in, xi.n, c);, out[i] = (float)default_value;)
+  } else if (interp == ORC_INTERP_NEAREST) {
+    RESAMPLE_LOOP(out[i] = in[nn_index(xi.n, c)];, out[i] = (float)default_value;)
+  } else {
+    return -4;
+  }
+  return 0;
+}
+
+static inline uint8_t cast_u8(double v) {
+  /* ResampleImageFilter::CastPixelWithBoundsChecking */
+  if (v < 0.0) return 0;
+  if (v > 255.0) return 255;
+  return (uint8_t)v;
+}
+
+int orc_resample_u8(const uint8_t* in, const orc_geom* gin, const orc_geom* gout,
+                    const double* affine_A, const double* affine_t, const double* field,
+                    const orc_geom* gd, int interp, double default_value, uint8_t* out) {
+  if (interp == ORC_INTERP_LINEAR) {
+    RESAMPLE_LOOP(out[i] = cast_u8(lerp_u8(in, xi.n, c));, out[i] = cast_u8(default_value);)
+  } else if (interp == ORC_INTERP_NEAREST) {
+    RESAMPLE_LOOP(out[i] = in[nn_index(xi.n, c)];, out[i] = cast_u8(default_value);)
+  } else {
+    return -4;
+  }
+  return 0;
+}
+
+int orc_resample_vec_f64(const double* in, const orc_geom* gin, const orc_geom* gout,
+                         const double* field, const orc_geom* gd, double* out) {
+  const double* affine_A = NULL;
+  const double* affine_t = NULL;
+  const size_t Ni = (size_t)gin->size[0] * gin->size[1] * gin->size[2];
+  const size_t No = (size_t)gout->size[0] * gout->size[1] * gout->size[2];
+  /* default pixel 0 -> zero vector; LinearInterpolateImageFunction per component */
+  RESAMPLE_LOOP(out[i] = lerp_f64(in, xi.n, c); out[No + i] = lerp_f64(in + Ni, xi.n, c);
+                out[2 * No + i] = lerp_f64(in + 2 * Ni, xi.n, c);
+                , out[i] = 0.0; out[No + i] = 0.0; out[2 * No + i] = 0.0;)
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* itkRecursiveGaussianImageFilter (Deriche 4th order, zero order) +
+ * itkRecursiveSeparableImageFilter::FilterDataArray. */
+
+typedef struct {
+  double N0, N1, N2, N3, D1, D2, D3, D4, M1, M2, M3, M4, BN1, BN2, BN3, BN4, BM1, BM2, BM3, BM4;
+} rg_coef;
+
+static void rg_setup(double sigma, double spacing, rg_coef* k) {
+  if (spacing < 0.0) spacing = -spacing;
+  const double sigmad = sigma / spacing;
+  const double W1 = 0.6681, L1 = -1.3932, W2 = 2.0787, L2 = -1.3732;
+  const double A1 = 1.3530, B1 = 1.8151, A2 = -0.3531, B2 = 0.0902; /* zero order */
+  /* ComputeDCoefficients */
+  {
+    const double Cos1 = cos(W1 / sigmad), Cos2 = cos(W2 / sigmad);
+    const double Exp1 = exp(L1 / sigmad), Exp2 = exp(L2 / sigmad);
+    k->D4 = Exp1 * Exp1 * Exp2 * Exp2;
+    k->D3 = -2 * Cos1 * Exp1 * Exp2 * Exp2;
+    k->D3 += -2 * Cos2 * Exp2 * Exp1 * Exp1;
+    k->D2 = 4 * Cos2 * Cos1 * Exp1 * Exp2;
+    k->D2 += Exp1 * Exp1 + Exp2 * Exp2;
+    k->D1 = -2 * (Exp2 * Cos2 + Exp1 * Cos1);
+  }
+  const double SD = 1.0 + k->D1 + k->D2 + k->D3 + k->D4;
+  /* ComputeNCoefficients */
+  double SN;
+  {
+    const double Sin1 = sin(W1 / sigmad), Sin2 = sin(W2 / sigmad);
+    const double Cos1 = cos(W1 / sigmad), Cos2 = cos(W2 / sigmad);
+    const double Exp1 = exp(L1 / sigmad), Exp2 = exp(L2 / sigmad);
+    k->N0 = A1 + A2;
+    k->N1 = Exp2 * (B2 * Sin2 - (A2 + 2 * A1) * Cos2);
+    k->N1 += Exp1 * (B1 * Sin1 - (A1 + 2 * A2) * Cos1);
+    k->N2 = (A1 + A2) * Cos2 * Cos1;
+    k->N2 -= B1 * Cos2 * Sin1 + B2 * Cos1 * Sin2;
+    k->N2 *= 2 * Exp1 * Exp2;
+    k->N2 += A2 * Exp1 * Exp1 + A1 * Exp2 * Exp2;
+    k->N3 = Exp2 * Exp1 * Exp1 * (B2 * Sin2 - A2 * Cos2);
+    k->N3 += Exp1 * Exp2 * Exp2 * (B1 * Sin1 - A1 * Cos1);
+    SN = k->N0 + k->N1 + k->N2 + k->N3;
+  }
+  const double alpha0 = 2 * SN / SD - k->N0;
+  k->N0 *= 1.0 / alpha0; /* across_scale_normalization = 1 (NormalizeAcrossScale off) */
+  k->N1 *= 1.0 / alpha0;
+  k->N2 *= 1.0 / alpha0;
+  k->N3 *= 1.0 / alpha0;
+  /* ComputeRemainingCoefficients(symmetric = true) */
+  k->M1 = k->N1 - k->D1 * k->N0;
+  k->M2 = k->N2 - k->D2 * k->N0;
+  k->M3 = k->N3 - k->D3 * k->N0;
+  k->M4 = -k->D4 * k->N0;
+  const double SN2 = k->N0 + k->N1 + k->N2 + k->N3;
+  const double SM = k->M1 + k->M2 + k->M3 + k->M4;
+  const double SD2 = 1.0 + k->D1 + k->D2 + k->D3 + k->D4;
+  k->BN1 = k->D1 * SN2 / SD2;
+  k->BN2 = k->D2 * SN2 / SD2;
+  k->BN3 = k->D3 * SN2 / SD2;
+  k->BN4 = k->D4 * SN2 / SD2;
+  k->BM1 = k->D1 * SM / SD2;
+  k->BM2 = k->D2 * SM / SD2;
+  k->BM3 = k->D3 * SM / SD2;
+  k->BM4 = k->D4 * SM / SD2;
+}
+
+#define EMA(a1, b1, a2, b2, a3, b3, a4, b4) ((a1) * (b1) + (a2) * (b2) + (a3) * (b3) + (a4) * (b4))
+
+static void rg_filter_line(double* outs, const double* data, double* scratch, long ln,
+                           const rg_coef* k) {
+  double* s1 = outs;
+  double* s2 = scratch;
+  const double v1 = data[0];
+  s1[0] = EMA(v1, k->N0, v1, k->N1, v1, k->N2, v1, k->N3);
+  s1[1] = EMA(data[1], k->N0, v1, k->N1, v1, k->N2, v1, k->N3);
+  s1[2] = EMA(data[2], k->N0, data[1], k->N1, v1, k->N2, v1, k->N3);
+  s1[3] = EMA(data[3], k->N0, data[2], k->N1, data[1], k->N2, v1, k->N3);
+  s1[0] -= EMA(v1, k->BN1, v1, k->BN2, v1, k->BN3, v1, k->BN4);
+  s1[1] -= EMA(s1[0], k->D1, v1, k->BN2, v1, k->BN3, v1, k->BN4);
+  s1[2] -= EMA(s1[1], k->D1, s1[0], k->D2, v1, k->BN3, v1, k->BN4);
+  s1[3] -= EMA(s1[2], k->D1, s1[1], k->D2, s1[0], k->D3, v1, k->BN4);
+  for (long i = 4; i < ln; ++i) {
+    s1[i] = EMA(data[i], k->N0, data[i - 1], k->N1, data[i - 2], k->N2, data[i - 3], k->N3);
+    s1[i] -= EMA(s1[i - 1], k->D1, s1[i - 2], k->D2, s1[i - 3], k->D3, s1[i - 4], k->D4);
+  }
+  const double v2 = data[ln - 1];
+  s2[ln - 1] = EMA(v2, k->M1, v2, k->M2, v2, k->M3, v2, k->M4);
+  s2[ln - 2] = EMA(data[ln - 1], k->M1, v2, k->M2, v2, k->M3, v2, k->M4);
+  s2[ln - 3] = EMA(data[ln - 2], k->M1, data[ln - 1], k->M2, v2, k->M3, v2, k->M4);
+  s2[ln - 4] = EMA(data[ln - 3], k->M1, data[ln - 2], k->M2, data[ln - 1], k->M3, v2, k->M4);
+  s2[ln - 1] -= EMA(v2, k->BM1, v2, k->BM2, v2, k->BM3, v2, k->BM4);
+  s2[ln - 2] -= EMA(s2[ln - 1], k->D1, v2, k->BM2, v2, k->BM3, v2, k->BM4);
+  s2[ln - 3] -= EMA(s2[ln - 2], k->D1, s2[ln - 1], k->D2, v2, k->BM3, v2, k->BM4);
+  s2[ln - 4] -= EMA(s2[ln - 3], k->D1, s2[ln - 2], k->D2, s2[ln - 1], k->D3, v2, k->BM4);
+  for (long i = ln - 4; i > 0; i--) {
+    s2[i - 1] = EMA(data[i], k->M1, data[i + 1], k->M2, data[i + 2], k->M3, data[i + 3], k->M4);
+    s2[i - 1] -= EMA(s2[i], k->D1, s2[i + 1], k->D2, s2[i + 2], k->D3, s2[i + 3], k->D4);
+  }
+  for (long i = 0; i < ln; ++i) outs[i] = s1[i] + s2[i];
+}
+
+/* one directional pass: read (double or float) -> filter in double -> store float */
+static int rg_pass(const double* in_d, const float* in_f, float* out, const int* n, int axis,
+                   double sigma, double spacing) {
+  const long nx = n[0], ny = n[1], nz = n[2];
+  const long len = n[axis];
+  if (len < 4) return -5; /* ITK: "The number of pixels along direction is less than 4" */
+  rg_coef k;
+  rg_setup(sigma, spacing, &k);
+  const long stride = axis == 0 ? 1 : (axis == 1 ? nx : nx * ny);
+  const long na = axis == 0 ? ny : nx;               /* inner line-origin count */
+  const long nb = axis == 2 ? ny : nz;               /* outer */
+#pragma omp parallel
+  {
+    double* data = (double*)malloc(sizeof(double) * len * 3);
+    double* outs = data + len;
+    double* scr = data + 2 * len;
+#pragma omp for schedule(static)
+    for (long bb = 0; bb < nb; ++bb)
+      for (long aa = 0; aa < na; ++aa) {
+        size_t o;
+        if (axis == 0)
+          o = ((size_t)bb * ny + aa) * nx; /* bb = z, aa = y */
+        else if (axis == 1)
+          o = (size_t)bb * ny * nx + aa;   /* bb = z, aa = x */
+        else
+          o = (size_t)bb * nx + aa;        /* bb = y, aa = x */
+        if (in_d)
+          for (long i = 0; i < len; ++i) data[i] = in_d[o + i * stride];
+        else
+          for (long i = 0; i < len; ++i) data[i] = (double)in_f[o + i * stride];
+        rg_filter_line(outs, data, scr, len, &k);
+        for (long i = 0; i < len; ++i) out[o + i * stride] = (float)outs[i];
+      }
+    free(data);
+  }
+  return 0;
+}
+
+/* itkSmoothingRecursiveGaussianImageFilter: first filter along the LAST axis, then axes
+ * 0..D-2; internal images are NumericTraits<PixelType>::FloatType (float), lines are
+ * filtered in RealType (double); final cast to the output pixel type. */
+int orc_recursive_gaussian_vec_f64(double* field, const orc_geom* g, const double sigma[3]) {
+  const size_t N = (size_t)g->size[0] * g->size[1] * g->size[2];
+  float* a = (float*)malloc(N * sizeof(float));
+  float* b = (float*)malloc(N * sizeof(float));
+  if (!a || !b) return -2;
+  int rc = 0;
+  for (int comp = 0; comp < 3 && !rc; ++comp) {
+    double* f = field + comp * N;
+    rc = rg_pass(f, NULL, a, g->size, 2, sigma[2], g->spacing[2]);
+    if (!rc) rc = rg_pass(NULL, a, b, g->size, 0, sigma[0], g->spacing[0]);
+    if (!rc) rc = rg_pass(NULL, b, a, g->size, 1, sigma[1], g->spacing[1]);
+    if (!rc)
+      for (size_t i = 0; i < N; ++i) f[i] = (double)a[i];
+  }
+  free(a);
+  free(b);
+  return rc;
+}
+
+int orc_recursive_gaussian_f32(const float* in, float* out, const orc_geom* g,
+                               const double sigma[3]) {
+  const size_t N = (size_t)g->size[0] * g->size[1] * g->size[2];
+  float* a = (float*)malloc(N * sizeof(float));
+  if (!a) return -2;
+  int rc = rg_pass(NULL, in, out, g->size, 2, sigma[2], g->spacing[2]);
+  if (!rc) rc = rg_pass(NULL, out, a, g->size, 0, sigma[0], g->spacing[0]);
+  if (!rc) rc = rg_pass(NULL, a, out, g->size, 1, sigma[1], g->spacing[1]);
+  free(a);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* fusion.py:148-169, vote_type "local": sitk.SquaredDifference -> DiscreteGaussian(var =
+ * sigma^2, defaults maximumKernelWidth 32, maximumError 0.01, useImageSpacing True) ->
+ * Pow(raw + epsilon, -1) -> Cast float32. */
+int orc_weight_map_local(const float* target, const float* moving, const int size[3],
+                         const double spacing[3], double sigma, double epsilon, float* weight) {
+  const size_t N = (size_t)size[0] * size[1] * size[2];
+  float* sq = (float*)malloc(N * sizeof(float));
+  if (!sq) return -2;
+  for (size_t i = 0; i < N; ++i) {
+    /* itk::Functor::SquaredDifference2: (A - B) in double, squared, cast to output */
+    const double d = (double)target[i] - (double)moving[i];
+    sq[i] = (float)(d * d);
+  }
+  const double var[3] = {sigma * sigma, sigma * sigma, sigma * sigma};
+  int rc = orc_discrete_gaussian_f32(sq, weight, size, spacing, var, 0.01, 32, 1);
+  if (!rc)
+    for (size_t i = 0; i < N; ++i) {
+      /* (raw + eps) on a float image adds in float-typed pixels; Pow computes in double */
+      const float s = (float)((double)weight[i] + epsilon);
+      weight[i] = (float)pow((double)s, -1.0);
+    }
+  free(sq);
+  return rc;
+}
