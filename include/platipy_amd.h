@@ -1,0 +1,191 @@
+/*
+ * include/platipy_amd.h -- C ABI of libplatipy_hip.so (gfx950 / MI355X).
+ *
+ * The reference (pyplati/platipy) has no C/FFI boundary on this path: its L2 Python functions
+ * call SimpleITK (SWIG -> ITK C++) directly.  This header is therefore the boundary a
+ * maintainer would bind *instead of* those SimpleITK calls; every entry point names the
+ * reference call site (file:line under the reference tree) whose SimpleITK call it replaces.
+ * platipy_amd/_lib.py is the ctypes binding; INTEGRATION.md shows the reference-side stub.
+ *
+ * Rules of the ABI
+ *  - extern "C", plain pointers and sizes, no C++/torch types.
+ *  - All volume pointers are caller-owned DEVICE pointers (e.g. torch tensor data_ptr());
+ *    the library never frees or retains them past the call.  Scratch memory belongs to the
+ *    ctx and grows on demand (hipMalloc only when a call needs more than any earlier one).
+ *  - Every call enqueues on the ctx's stream and returns; pp_sync() waits.  The one
+ *    exception is a call given a non-NULL host `stats` pointer, which synchronises the
+ *    stream before returning so the statistics are valid.
+ *  - Return value: PP_OK (0) or a negative pp_status; pp_last_error(ctx) describes the last
+ *    failure.  Nothing throws across the ABI and nothing calls exit().
+ *  - One ctx per (device, stream); no global state, so N ctxs can drive N GPUs/streams.
+ *
+ * Layout: scalar volumes are [Z][Y][X] (x fastest), size = {nx, ny, nz}.  Displacement
+ * fields are planar fp32, [3][Z][Y][X]; plane c holds the c-th physical (mm) component.
+ */
+#ifndef PLATIPY_AMD_H
+#define PLATIPY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_ABI_VERSION 1
+
+typedef enum {
+  PP_OK = 0,
+  PP_ERR_ARG = -1,         /* NULL / inconsistent argument                       */
+  PP_ERR_HIP = -2,         /* a HIP runtime call or kernel launch failed          */
+  PP_ERR_ALLOC = -3,       /* workspace allocation failed                         */
+  PP_ERR_UNSUPPORTED = -4, /* valid request this build does not implement         */
+  PP_ERR_SIZE = -5         /* volume too small / too large for the operation      */
+} pp_status;
+
+enum { PP_INTERP_NEAREST = 1, PP_INTERP_LINEAR = 2 }; /* = sitk.sitkNearestNeighbor / sitkLinear */
+
+enum { PP_DEMONS_AUTO = 0, PP_DEMONS_STAGED = 1, PP_DEMONS_FUSED = 2 };
+
+typedef struct pp_ctx pp_ctx;
+
+typedef struct {
+  int size[3];         /* nx, ny, nz */
+  double spacing[3];   /* mm         */
+  double origin[3];    /* mm         */
+  double direction[9]; /* row-major  */
+} pp_geom;
+
+/* Parameters of sitk.FastSymmetricForcesDemonsRegistrationFilter as the reference
+ * configures it (registration/deformable.py:244-257); pp_demons_default_params() fills
+ * SimpleITK 2.3.1's defaults. */
+typedef struct {
+  int iterations;               /* SetNumberOfIterations (deformable.py:144)              */
+  double sigma_d_vox[3];        /* SetStandardDeviations, voxels (deformable.py:253-257)  */
+  double sigma_u_vox[3];        /* UpdateFieldStandardDeviations, voxels (default 1.0)    */
+  int smooth_displacement;      /* SetSmoothDisplacementField (deformable.py:249)         */
+  int smooth_update;            /* SetSmoothUpdateField (deformable.py:248)               */
+  double max_rms_error;         /* MaximumRMSError, 0.02; <= 0 disables the early halt    */
+  double max_step_length;       /* MaximumUpdateStepLength, 0.5                           */
+  double intensity_threshold;   /* IntensityDifferenceThreshold, 0.001                    */
+  double denominator_threshold; /* ESM m_DenominatorThreshold, 1e-9                       */
+  double max_error;             /* GaussianOperator MaximumError, 0.1                     */
+  int max_kernel_width;         /* GaussianOperator MaximumKernelWidth, 30                */
+  int variant;                  /* PP_DEMONS_AUTO | _STAGED | _FUSED                      */
+} pp_demons_params;
+
+typedef struct {
+  double metric;         /* GetMetric(): mean squared intensity difference            */
+  double rms_change;     /* GetRMSChange(): sqrt(mean |update|^2), raw update         */
+  double sum_sq_diff;
+  double sum_sq_change;
+  int64_t n_pixels;
+  int elapsed_iterations; /* GetElapsedIterations()                                   */
+  int halted;             /* 1 if the RMS rule stopped the loop early                 */
+} pp_demons_stats;
+
+/* ---- context --------------------------------------------------------------------- */
+int pp_abi_version(void);
+int pp_create(int device, void* hip_stream, pp_ctx** out);
+void pp_destroy(pp_ctx* ctx);
+const char* pp_last_error(const pp_ctx* ctx);
+int pp_set_stream(pp_ctx* ctx, void* hip_stream);
+int pp_sync(pp_ctx* ctx);
+size_t pp_workspace_bytes(const pp_ctx* ctx);
+
+/* ---- host helpers ---------------------------------------------------------------- */
+/* itk::GaussianOperator coefficients (every FIR below uses them).  taps gets 2r+1 values,
+ * returns r or a negative pp_status. */
+int pp_gauss_taps(double variance, double max_error, int max_kernel_width, double* taps, int cap);
+void pp_demons_default_params(pp_demons_params* p);
+
+/* ---- Gaussian FIR ------------------------------------------------------------------ */
+/* sitk.DiscreteGaussian(image, variance, maximumKernelWidth, maximumError=0.01,
+ * useImageSpacing=True): registration/utils.py:226, label/fusion.py:168,279. */
+int pp_discrete_gaussian_f32(pp_ctx* ctx, const float* in, float* out, const int size[3],
+                             const double spacing[3], const double variance[3], double max_error,
+                             int max_kernel_width, int use_image_spacing);
+/* PDEDeformableRegistrationFilter::SmoothDisplacementField / SmoothUpdateField, in place on
+ * a planar 3-vector field; sigma in voxels (deformable.py:248-257). */
+int pp_smooth_field_f32(pp_ctx* ctx, float* field, const int size[3], const double sigma_vox[3],
+                        double max_error, int max_kernel_width);
+
+/* ---- recursive (IIR) Gaussian ------------------------------------------------------ */
+/* sitk.SmoothingRecursiveGaussian(dvf_total, sigma) (deformable.py:157-158), in place on a
+ * planar field; sigma in the units ITK reads them in (mm). */
+int pp_recursive_gaussian_field_f32(pp_ctx* ctx, float* field, const pp_geom* g,
+                                    const double sigma[3]);
+int pp_recursive_gaussian_f32(pp_ctx* ctx, const float* in, float* out, const pp_geom* g,
+                              const double sigma[3]);
+
+/* ---- warp / resample --------------------------------------------------------------- */
+/* out(x) = moving(x + D(x)), moving/field/out on one grid: itk::WarpImageFilter inside the
+ * demons loop (edge = FLT_MAX sentinel) and sitk.Resample(m_image, tfm_total, interp)
+ * (deformable.py:140, edge 0) / the final warp (deformable.py:281-301). */
+int pp_warp_f32(pp_ctx* ctx, const float* moving, const float* field, const pp_geom* g,
+                float edge_value, float* out);
+/* sitk.ResampleImageFilter (registration/utils.py:176-190, :257-267): out grid gout, input
+ * grid gin, transform q = A p + t (NULL = identity) followed by q += D(p) for a field D
+ * sampled on gout (NULL = none).  Coordinates are computed in fp64. */
+int pp_resample_f32(pp_ctx* ctx, const float* in, const pp_geom* gin, const pp_geom* gout,
+                    const double* affine_A, const double* affine_t, const float* field,
+                    int interp, double default_value, float* out);
+int pp_resample_u8(pp_ctx* ctx, const uint8_t* in, const pp_geom* gin, const pp_geom* gout,
+                   const double* affine_A, const double* affine_t, const float* field,
+                   int interp, double default_value, uint8_t* out);
+/* sitk.Resample on the vector field itself (deformable.py:130,137,185): linear, default 0. */
+int pp_resample_field_f32(pp_ctx* ctx, const float* in, const pp_geom* gin, const pp_geom* gout,
+                          float* out);
+/* dvf_total + sitk.Resample(dvf_iter, DisplacementFieldTransform(dvf_total))
+ * (deformable.py:154): total(x) += iter(x + total(x)), 0 outside; both on grid g. */
+int pp_compose_field_f32(pp_ctx* ctx, float* total, const float* iter, const pp_geom* g);
+
+/* ---- demons ------------------------------------------------------------------------ */
+/* One itk::ESMDemonsRegistrationFunction::ComputeUpdate sweep (symmetric gradient) over
+ * the grid: update = planar field.  stats may be NULL. */
+int pp_demons_force_f32(pp_ctx* ctx, const float* fixed, const float* warped, const pp_geom* g,
+                        const pp_demons_params* p, float* update, pp_demons_stats* stats);
+/* registration_algorithm.Execute(f_image, m_image) (deformable.py:149): the whole inner
+ * loop on device, field starting from zero.  stats may be NULL (then fully asynchronous). */
+int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, const pp_geom* g,
+                          const pp_demons_params* p, float* field, pp_demons_stats* stats);
+
+/* ---- label fusion ------------------------------------------------------------------ */
+/* compute_weight_map(vote_type="local") (label/fusion.py:148-169):
+ * w = 1 / (DiscreteGaussian((T - M)^2, sigma^2) + epsilon). */
+int pp_weight_map_local_f32(pp_ctx* ctx, const float* target, const float* moving,
+                            const int size[3], const double spacing[3], double sigma,
+                            double epsilon, float* weight);
+/* sum of squared differences (vote_type="global", label/fusion.py:154-161), fp64 on host. */
+int pp_sum_sq_diff_f32(pp_ctx* ctx, const float* a, const float* b, size_t n, double* result);
+/* combine_labels accumulation (label/fusion.py:263,269-276), one atlas at a time:
+ * wsum += w (if wsum != NULL);  wlsum += w * label. */
+int pp_fuse_accumulate_u8(pp_ctx* ctx, const float* weight, const uint8_t* label, float* wsum,
+                          float* wlsum, size_t n);
+/* P = wlsum / (wsum == 0 ? 1 : wsum)  (label/fusion.py:264-276) */
+int pp_fuse_divide_f32(pp_ctx* ctx, const float* wlsum, const float* wsum, float* out, size_t n);
+/* global min / max (RescaleIntensity, label/fusion.py:282; process_probability_image :305) */
+int pp_minmax_f32(pp_ctx* ctx, const float* in, size_t n, float* min_out, float* max_out);
+/* RescaleIntensity(0,1) given (min,max) then Threshold(lower, upper=1, outside=0)
+ * (label/fusion.py:282-288), in place. */
+int pp_rescale_threshold_f32(pp_ctx* ctx, float* data, size_t n, float in_min, float in_max,
+                             float lower);
+/* BinaryThreshold(prob / max >= threshold) -> uint8 (label/fusion.py:305-308) */
+int pp_binary_threshold_f32(pp_ctx* ctx, const float* prob, size_t n, float inv_max,
+                            float threshold, uint8_t* out);
+
+/* ---- linear registration ----------------------------------------------------------- */
+/* One evaluation of itk::MeanSquaresImageToImageMetricv4 + its derivative with respect to
+ * the 12 parameters of an affine map in *index* space (registration/linear.py:141-148,238):
+ * for fixed voxels on the lattice {start + k*step}, m = moving(A x + b) trilinear;
+ * value = sum (f - m)^2, grad[12] = d value / d(A,b), count = valid samples.
+ * result (host, 14 doubles): value, count, grad[12].  Synchronises. */
+int pp_meansq_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], const float* moving,
+                         const int msize[3], const double A[9], const double b[3],
+                         const int start[3], const int step[3], const uint8_t* fixed_mask,
+                         double* result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLATIPY_AMD_H */

@@ -1,0 +1,297 @@
+"""ctypes binding of the C ABI in include/platipy_amd.h (libplatipy_hip.so, gfx950).
+
+The product path has no CPU fallback: if the shared library is missing or fails to load, every
+operation raises.  `Context` methods take raw device addresses (ints); `ptr()` extracts one from
+a torch tensor.  The same binding class is pointed at the CPU-emulated build of the identical
+kernel sources by the test-suite only (tests/emu), never by the package itself.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "csrc", "libplatipy_hip.so")
+
+PP_OK = 0
+INTERP_NEAREST = 1
+INTERP_LINEAR = 2
+DEMONS_AUTO, DEMONS_STAGED, DEMONS_FUSED = 0, 1, 2
+ABI_VERSION = 1
+
+
+class Geom(C.Structure):
+    _fields_ = [("size", C.c_int * 3), ("spacing", C.c_double * 3), ("origin", C.c_double * 3),
+                ("direction", C.c_double * 9)]
+
+
+class DemonsParams(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int),
+        ("sigma_d_vox", C.c_double * 3),
+        ("sigma_u_vox", C.c_double * 3),
+        ("smooth_displacement", C.c_int),
+        ("smooth_update", C.c_int),
+        ("max_rms_error", C.c_double),
+        ("max_step_length", C.c_double),
+        ("intensity_threshold", C.c_double),
+        ("denominator_threshold", C.c_double),
+        ("max_error", C.c_double),
+        ("max_kernel_width", C.c_int),
+        ("variant", C.c_int),
+    ]
+
+
+class DemonsStats(C.Structure):
+    _fields_ = [
+        ("metric", C.c_double),
+        ("rms_change", C.c_double),
+        ("sum_sq_diff", C.c_double),
+        ("sum_sq_change", C.c_double),
+        ("n_pixels", C.c_int64),
+        ("elapsed_iterations", C.c_int),
+        ("halted", C.c_int),
+    ]
+
+
+class PlatipyAmdError(RuntimeError):
+    pass
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "pp_abi_version": (C.c_int, []),
+    "pp_create": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    "pp_destroy": (None, [_P]),
+    "pp_last_error": (C.c_char_p, [_P]),
+    "pp_set_stream": (C.c_int, [_P, _P]),
+    "pp_sync": (C.c_int, [_P]),
+    "pp_workspace_bytes": (C.c_size_t, [_P]),
+    "pp_gauss_taps": (C.c_int, [C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double), C.c_int]),
+    "pp_demons_default_params": (None, [C.POINTER(DemonsParams)]),
+    "pp_discrete_gaussian_f32": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                           C.c_double, C.c_int, C.c_int]),
+    "pp_smooth_field_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_double, C.c_int]),
+    "pp_recursive_gaussian_field_f32": (C.c_int, [_P, _P, C.POINTER(Geom), C.POINTER(C.c_double)]),
+    "pp_recursive_gaussian_f32": (C.c_int, [_P, _P, _P, C.POINTER(Geom), C.POINTER(C.c_double)]),
+    "pp_warp_f32": (C.c_int, [_P, _P, _P, C.POINTER(Geom), C.c_float, _P]),
+    "pp_resample_f32": (C.c_int, [_P, _P, C.POINTER(Geom), C.POINTER(Geom), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                  _P, C.c_int, C.c_double, _P]),
+    "pp_resample_u8": (C.c_int, [_P, _P, C.POINTER(Geom), C.POINTER(Geom), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                 _P, C.c_int, C.c_double, _P]),
+    "pp_resample_field_f32": (C.c_int, [_P, _P, C.POINTER(Geom), C.POINTER(Geom), _P]),
+    "pp_compose_field_f32": (C.c_int, [_P, _P, _P, C.POINTER(Geom)]),
+    "pp_demons_force_f32": (C.c_int, [_P, _P, _P, C.POINTER(Geom), C.POINTER(DemonsParams), _P, C.POINTER(DemonsStats)]),
+    "pp_demons_execute_f32": (C.c_int, [_P, _P, _P, C.POINTER(Geom), C.POINTER(DemonsParams), _P, C.POINTER(DemonsStats)]),
+    "pp_weight_map_local_f32": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_double, C.c_double, _P]),
+    "pp_sum_sq_diff_f32": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_double)]),
+    "pp_fuse_accumulate_u8": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t]),
+    "pp_fuse_divide_f32": (C.c_int, [_P, _P, _P, _P, C.c_size_t]),
+    "pp_minmax_f32": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "pp_rescale_threshold_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, C.c_float]),
+    "pp_binary_threshold_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P]),
+    "pp_meansq_affine_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int), _P,
+                                       C.POINTER(C.c_double)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load(path=None):
+    """dlopen the C-ABI library and declare every entry point.  Raises if it is absent."""
+    path = path or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise PlatipyAmdError(
+            f"{path} not found: build it with `python -m platipy_amd._build` (needs hipcc). "
+            "platipy_amd has no CPU fallback.")
+    try:
+        dll = C.CDLL(path)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise PlatipyAmdError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(dll, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if dll.pp_abi_version() != ABI_VERSION:
+        raise PlatipyAmdError(f"{path}: ABI version {dll.pp_abi_version()} != {ABI_VERSION}")
+    return dll
+
+
+_DLL = None
+
+
+def dll():
+    global _DLL
+    if _DLL is None:
+        _DLL = load()
+    return _DLL
+
+
+def ptr(x):
+    """Device (or, in the emulated test build, host) address of a tensor/array, or None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return x.ctypes.data  # numpy (test builds only)
+
+
+def make_geom(size, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=(1, 0, 0, 0, 1, 0, 0, 0, 1)):
+    g = Geom()
+    g.size[:] = [int(s) for s in size]
+    g.spacing[:] = [float(s) for s in spacing]
+    g.origin[:] = [float(s) for s in origin]
+    g.direction[:] = [float(s) for s in direction]
+    return g
+
+
+def _i3(v):
+    return (C.c_int * 3)(*[int(x) for x in v])
+
+
+def _d3(v):
+    return (C.c_double * 3)(*[float(x) for x in v])
+
+
+def _dn(v, n):
+    if v is None:
+        return None
+    return (C.c_double * n)(*[float(x) for x in v])
+
+
+def gauss_taps(variance, max_error, max_kernel_width, lib=None):
+    lib = lib or dll()
+    buf = (C.c_double * 1024)()
+    r = lib.pp_gauss_taps(float(variance), float(max_error), int(max_kernel_width), buf, 1024)
+    if r < 0:
+        raise PlatipyAmdError(f"pp_gauss_taps failed ({r})")
+    return [buf[i] for i in range(2 * r + 1)]
+
+
+class Context:
+    """One pp_ctx: a (device, stream) pair plus its scratch memory."""
+
+    def __init__(self, device=0, stream=0, lib=None):
+        self.lib = lib or dll()
+        h = _P()
+        rc = self.lib.pp_create(int(device), _P(stream or None), C.byref(h))
+        if rc != PP_OK:
+            raise PlatipyAmdError(f"pp_create(device={device}) failed ({rc})")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.lib.pp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != PP_OK:
+            msg = self.lib.pp_last_error(self.h)
+            raise PlatipyAmdError(f"{what} failed ({rc}): {msg.decode(errors='replace') if msg else ''}")
+
+    def set_stream(self, stream):
+        self._chk(self.lib.pp_set_stream(self.h, _P(stream or None)), "pp_set_stream")
+
+    def sync(self):
+        self._chk(self.lib.pp_sync(self.h), "pp_sync")
+
+    def workspace_bytes(self):
+        return self.lib.pp_workspace_bytes(self.h)
+
+    def default_demons_params(self):
+        p = DemonsParams()
+        self.lib.pp_demons_default_params(C.byref(p))
+        return p
+
+    # -- FIR / IIR ------------------------------------------------------------------
+    def discrete_gaussian(self, src, dst, size, spacing, variance, max_error=0.01, max_kernel_width=32, use_spacing=True):
+        self._chk(self.lib.pp_discrete_gaussian_f32(self.h, ptr(src), ptr(dst), _i3(size), _d3(spacing), _d3(variance),
+                                                    float(max_error), int(max_kernel_width), int(bool(use_spacing))),
+                  "pp_discrete_gaussian_f32")
+
+    def smooth_field(self, field, size, sigma_vox, max_error=0.1, max_kernel_width=30):
+        self._chk(self.lib.pp_smooth_field_f32(self.h, ptr(field), _i3(size), _d3(sigma_vox), float(max_error),
+                                               int(max_kernel_width)), "pp_smooth_field_f32")
+
+    def recursive_gaussian_field(self, field, geom, sigma):
+        self._chk(self.lib.pp_recursive_gaussian_field_f32(self.h, ptr(field), C.byref(geom), _d3(sigma)),
+                  "pp_recursive_gaussian_field_f32")
+
+    def recursive_gaussian(self, src, dst, geom, sigma):
+        self._chk(self.lib.pp_recursive_gaussian_f32(self.h, ptr(src), ptr(dst), C.byref(geom), _d3(sigma)),
+                  "pp_recursive_gaussian_f32")
+
+    # -- warp / resample ------------------------------------------------------------
+    def warp(self, moving, field, geom, edge_value, out):
+        self._chk(self.lib.pp_warp_f32(self.h, ptr(moving), ptr(field), C.byref(geom), float(edge_value), ptr(out)),
+                  "pp_warp_f32")
+
+    def resample(self, src, gin, gout, out, affine_A=None, affine_t=None, field=None, interp=INTERP_LINEAR,
+                 default_value=0.0, u8=False):
+        fn = self.lib.pp_resample_u8 if u8 else self.lib.pp_resample_f32
+        self._chk(fn(self.h, ptr(src), C.byref(gin), C.byref(gout), _dn(affine_A, 9), _dn(affine_t, 3), ptr(field),
+                     int(interp), float(default_value), ptr(out)), "pp_resample")
+
+    def resample_field(self, src, gin, gout, out):
+        self._chk(self.lib.pp_resample_field_f32(self.h, ptr(src), C.byref(gin), C.byref(gout), ptr(out)),
+                  "pp_resample_field_f32")
+
+    def compose_field(self, total, it, geom):
+        self._chk(self.lib.pp_compose_field_f32(self.h, ptr(total), ptr(it), C.byref(geom)), "pp_compose_field_f32")
+
+    # -- demons ---------------------------------------------------------------------
+    def demons_force(self, fixed, warped, geom, params, update, want_stats=True):
+        st = DemonsStats()
+        self._chk(self.lib.pp_demons_force_f32(self.h, ptr(fixed), ptr(warped), C.byref(geom), C.byref(params), ptr(update),
+                                               C.byref(st) if want_stats else None), "pp_demons_force_f32")
+        return st if want_stats else None
+
+    def demons_execute(self, fixed, moving, geom, params, field, want_stats=True):
+        st = DemonsStats()
+        self._chk(self.lib.pp_demons_execute_f32(self.h, ptr(fixed), ptr(moving), C.byref(geom), C.byref(params), ptr(field),
+                                                 C.byref(st) if want_stats else None), "pp_demons_execute_f32")
+        return st if want_stats else None
+
+    # -- fusion ---------------------------------------------------------------------
+    def weight_map_local(self, target, moving, size, spacing, sigma, epsilon, out):
+        self._chk(self.lib.pp_weight_map_local_f32(self.h, ptr(target), ptr(moving), _i3(size), _d3(spacing), float(sigma),
+                                                   float(epsilon), ptr(out)), "pp_weight_map_local_f32")
+
+    def sum_sq_diff(self, a, b, n):
+        r = C.c_double()
+        self._chk(self.lib.pp_sum_sq_diff_f32(self.h, ptr(a), ptr(b), int(n), C.byref(r)), "pp_sum_sq_diff_f32")
+        return r.value
+
+    def fuse_accumulate(self, weight, label, wsum, wlsum, n):
+        self._chk(self.lib.pp_fuse_accumulate_u8(self.h, ptr(weight), ptr(label), ptr(wsum), ptr(wlsum), int(n)),
+                  "pp_fuse_accumulate_u8")
+
+    def fuse_divide(self, wlsum, wsum, out, n):
+        self._chk(self.lib.pp_fuse_divide_f32(self.h, ptr(wlsum), ptr(wsum), ptr(out), int(n)), "pp_fuse_divide_f32")
+
+    def minmax(self, src, n):
+        lo, hi = C.c_float(), C.c_float()
+        self._chk(self.lib.pp_minmax_f32(self.h, ptr(src), int(n), C.byref(lo), C.byref(hi)), "pp_minmax_f32")
+        return lo.value, hi.value
+
+    def rescale_threshold(self, data, n, in_min, in_max, lower):
+        self._chk(self.lib.pp_rescale_threshold_f32(self.h, ptr(data), int(n), float(in_min), float(in_max), float(lower)),
+                  "pp_rescale_threshold_f32")
+
+    def binary_threshold(self, prob, n, inv_max, threshold, out):
+        self._chk(self.lib.pp_binary_threshold_f32(self.h, ptr(prob), int(n), float(inv_max), float(threshold), ptr(out)),
+                  "pp_binary_threshold_f32")
+
+    def meansq_affine(self, fixed, fsize, moving, msize, A, b, start, step, mask=None):
+        res = (C.c_double * 14)()
+        self._chk(self.lib.pp_meansq_affine_f32(self.h, ptr(fixed), _i3(fsize), ptr(moving), _i3(msize), _dn(A, 9), _dn(b, 3),
+                                                _i3(start), _i3(step), ptr(mask), res), "pp_meansq_affine_f32")
+        return [res[i] for i in range(14)]

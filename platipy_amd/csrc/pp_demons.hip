@@ -1,0 +1,790 @@
+// platipy_amd/csrc/pp_demons.hip -- the demons inner loop.
+//
+// Replaces sitk.FastSymmetricForcesDemonsRegistrationFilter.Execute (reference:
+// platipy/imaging/registration/deformable.py:149, configured at :244-257).  Per iteration ITK
+// runs five whole-volume stages (warp, ESM update, smooth update, add, smooth field).  All
+// are memory-bound stencils/gathers -- no MFMA.  Two schedules are built here:
+//
+//  STAGED  one launch per stage and per smoothing axis, the schedule the algorithmic byte
+//          model (196 B/voxel/iteration) describes.  Any kernel radius.
+//  FUSED   two launches per iteration.  Both march a 64x16 (x,y) tile through a z-chunk,
+//          keeping the current plane (+halo) in LDS and the z-window in registers, so every
+//          separable 3-D Gaussian costs one read and one write of the field:
+//            A  force+smooth:  F, M.D  -> G_u * U            (+ metric / RMS partial sums)
+//            B  add+smooth+warp:  D, U, M -> D' = G_d * (D+U),  M.D'
+//          Real traffic ~64 B/voxel/iteration plus halo re-reads (served by L2/MALL).
+//          Kernel radii <= 3 (the reference's sigma_u = 1 and sigma_d = 1.5 mm give 1..3).
+//
+// The early-halt rule (MaximumRMSError) is evaluated on device: the per-iteration finalize
+// kernel raises a flag that turns every later launch into a no-op, so a whole Execute is
+// enqueued without a host round trip.
+#include "pp_internal.h"
+#include "pp_kernels.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+struct pp_dev_stats {
+  double ssd, ssc;
+  long long npx;
+  double metric, rms;
+  int elapsed;
+  int halt;
+};
+
+struct pp_esm_consts {
+  float hx, hy, hz;   // 0.5 / spacing
+  float ix, iy, iz;   // 1 / spacing
+  float inv_norm;     // 1 / normalizer (unused when !has_norm)
+  float denom_thr;
+  double intensity_thr;
+  int has_norm;
+};
+
+// One axis of the symmetric ESM gradient: itk::CentralDifferenceImageFunction on the fixed
+// image (zero on the first/last index) plus the sentinel-aware difference of the warped moving
+// image that ESMDemonsRegistrationFunction::ComputeUpdate builds "more or less by hand".
+__device__ __forceinline__ float pp_esm_axis(float fm, float fp, float mc, float mm, float mp, int idx, int n, float h,
+                                             float inv_sp) {
+  const float SENT = FLT_MAX;
+  float wg;
+  if (n == 1) wg = 0.0f;
+  else if (idx == 0) wg = (mp == SENT) ? 0.0f : (mp - mc) * inv_sp;
+  else if (idx == n - 1) wg = (mm == SENT) ? 0.0f : (mc - mm) * inv_sp;
+  else if (mp == SENT) wg = (mm == SENT) ? 0.0f : (mc - mm) * inv_sp;
+  else if (mm == SENT) wg = (mp - mc) * inv_sp;
+  else wg = (mp - mm) * h;
+  const float fg = (idx < 1 || idx > n - 2) ? 0.0f : (fp - fm) * h;
+  return fg + wg;
+}
+
+struct pp_esm_out {
+  float ux, uy, uz;
+  float sq_speed, sq_update;
+  int counted;
+};
+
+__device__ __forceinline__ pp_esm_out pp_esm_voxel(const pp_esm_consts& K, float fc, float mc, float gx, float gy, float gz) {
+  pp_esm_out o;
+  o.ux = o.uy = o.uz = 0.0f;
+  o.sq_speed = o.sq_update = 0.0f;
+  o.counted = 0;
+  if (mc == FLT_MAX) return o;  // mapped outside the moving image: no update, not counted
+  const float speed = fc - mc;
+  const float g2 = gx * gx + gy * gy + gz * gz;
+  if (!(fabs((double)speed) < K.intensity_thr)) {
+    const float denom = K.has_norm ? g2 + speed * speed * K.inv_norm : g2;
+    if (!(denom < K.denom_thr)) {
+      const float factor = 2.0f * speed / denom;
+      o.ux = factor * gx;
+      o.uy = factor * gy;
+      o.uz = factor * gz;
+    }
+  }
+  o.sq_speed = speed * speed;
+  o.sq_update = o.ux * o.ux + o.uy * o.uy + o.uz * o.uz;
+  o.counted = 1;
+  return o;
+}
+
+// ---------------------------------------------------------------------------------------
+// STAGED: ESM update, one voxel per thread (neighbour loads are L1/L2 hits).
+
+__global__ void __launch_bounds__(NT) k_demons_force(const float* __restrict__ F, const float* __restrict__ Mw,
+                                                     float* __restrict__ U, pp_dims d, pp_esm_consts K,
+                                                     double* __restrict__ partials, const int* __restrict__ halt) {
+  __shared__ double red[3 * NT];
+  if (halt && *halt) return;
+  const size_t N = (size_t)d.nx * d.ny * d.nz;
+  const size_t sy = d.nx, sz = (size_t)d.nx * d.ny;
+  double a_ssd = 0.0, a_ssc = 0.0, a_n = 0.0;
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < N; i += (size_t)gridDim.x * NT) {
+    const int x = (int)(i % d.nx);
+    const int y = (int)((i / d.nx) % d.ny);
+    const int z = (int)(i / sz);
+    const size_t xm = x > 0 ? i - 1 : i, xp = x < d.nx - 1 ? i + 1 : i;
+    const size_t ym = y > 0 ? i - sy : i, yp = y < d.ny - 1 ? i + sy : i;
+    const size_t zm = z > 0 ? i - sz : i, zp = z < d.nz - 1 ? i + sz : i;
+    const float fc = F[i], mc = Mw[i];
+    const float gx = pp_esm_axis(F[xm], F[xp], mc, Mw[xm], Mw[xp], x, d.nx, K.hx, K.ix);
+    const float gy = pp_esm_axis(F[ym], F[yp], mc, Mw[ym], Mw[yp], y, d.ny, K.hy, K.iy);
+    const float gz = pp_esm_axis(F[zm], F[zp], mc, Mw[zm], Mw[zp], z, d.nz, K.hz, K.iz);
+    const pp_esm_out o = pp_esm_voxel(K, fc, mc, gx, gy, gz);
+    U[i] = o.ux;
+    U[N + i] = o.uy;
+    U[2 * N + i] = o.uz;
+    a_ssd += (double)o.sq_speed;
+    a_ssc += (double)o.sq_update;
+    a_n += (double)o.counted;
+  }
+  pp_block_sum3<NT>(a_ssd, a_ssc, a_n, red);
+  if (threadIdx.x == 0) {
+    partials[3 * (size_t)blockIdx.x + 0] = a_ssd;
+    partials[3 * (size_t)blockIdx.x + 1] = a_ssc;
+    partials[3 * (size_t)blockIdx.x + 2] = a_n;
+  }
+}
+
+// End of an iteration: fold the per-block partial sums (fixed order -> deterministic), publish
+// metric / RMS change, count the iteration and apply FiniteDifferenceImageFilter::Halt().
+__global__ void __launch_bounds__(NT) k_demons_finalize(const double* __restrict__ partials, int nblocks,
+                                                        pp_dev_stats* __restrict__ st, double max_rms) {
+  __shared__ double red[3 * NT];
+  if (st->halt) return;
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += NT) {
+    a += partials[3 * (size_t)i + 0];
+    b += partials[3 * (size_t)i + 1];
+    c += partials[3 * (size_t)i + 2];
+  }
+  pp_block_sum3<NT>(a, b, c, red);
+  if (threadIdx.x == 0) {
+    st->ssd = a;
+    st->ssc = b;
+    st->npx = (long long)c;
+    if (c > 0.0) {
+      st->metric = a / c;
+      st->rms = sqrt(b / c);
+    }
+    st->elapsed += 1;
+    if (max_rms > st->rms) st->halt = 1;  // Halt(): m_MaximumRMSError > m_RMSChange
+  }
+}
+
+__global__ void __launch_bounds__(NT) k_add_inplace(float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                    const int* __restrict__ halt) {
+  if (halt && *halt) return;
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) a[i] += b[i];
+}
+
+// After a fused Execute the newest field sits in `alt` when an odd number of iterations ran.
+__global__ void __launch_bounds__(NT) k_copy_if_odd(float* __restrict__ dst, const float* __restrict__ alt, size_t n,
+                                                    const pp_dev_stats* __restrict__ st) {
+  if ((st->elapsed & 1) == 0) return;
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) dst[i] = alt[i];
+}
+
+unsigned grid_for(size_t work, unsigned cap = 65535u * 4u) {
+  size_t blocks = (work + NT - 1) / NT;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+// ---------------------------------------------------------------------------------------
+// FUSED kernels.  Tile TX x TY outputs per plane, NT = (TX/4) * TY threads; thread (cx, cy) owns
+// the 4 consecutive x outputs x = tx0 + 4 cx .. +3 of row y = ty0 + cy on every plane of its chunk.
+
+constexpr int TX = 64;
+constexpr int TY = 16;
+static_assert((TX / 4) * TY == NT, "thread layout");
+
+template <int R>
+struct fused_geom {
+  static constexpr int UW = TX + 2 * R;           // smoothing-input tile width  (x from tx0 - R)
+  static constexpr int UH = TY + 2 * R;           // smoothing-input tile height (y from ty0 - R)
+  static constexpr int UWP = (UW + 3) / 4 * 4;    // row pitch, keeps rows 16-B aligned
+  static constexpr int NU = UW * UH;              // voxels per smoothing-input plane
+  static constexpr int KU = (NU + NT - 1) / NT;   // of which one thread owns at most KU
+  static constexpr int MW = UW + 2;               // image tile (1 more voxel each side for gradients)
+  static constexpr int MH = UH + 2;
+  static constexpr int MWP = MW;
+  static constexpr int NB = MW * MH - UW * UH;    // border ring elements
+  static constexpr int XI = UH * (TX / 4);        // x-pass work items per component
+};
+
+// x pass: item (row uy, group cx) reads 4 + 2R inputs of `us` and writes 4 outputs to `xs`.
+template <int R>
+__device__ __forceinline__ void fused_xpass(const float* __restrict__ us /*[3][UH][UWP]*/,
+                                            float* __restrict__ xs /*[3][UH][TX]*/, const pp_taps_small& wx) {
+  using G = fused_geom<R>;
+  for (int it = threadIdx.x; it < 3 * G::XI; it += NT) {
+    const int c = it / G::XI;
+    const int rem = it - c * G::XI;
+    const int uy = rem / (TX / 4);
+    const int cx = rem - uy * (TX / 4);
+    const float* src = us + ((size_t)c * G::UH + uy) * G::UWP + 4 * cx;
+    float in[4 + 2 * R];
+#pragma unroll
+    for (int q = 0; q < (4 + 2 * R) / 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+      in[4 * q + 0] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
+    }
+    if ((4 + 2 * R) % 4 == 2) {
+      const float2 v = *reinterpret_cast<const float2*>(src + (4 + 2 * R) / 4 * 4);
+      in[(4 + 2 * R) / 4 * 4 + 0] = v.x;
+      in[(4 + 2 * R) / 4 * 4 + 1] = v.y;
+    }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float s = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 2 * R + 1; ++k) s = fmaf(wx.w[k], in[j + k], s);
+      o[j] = s;
+    }
+    *reinterpret_cast<float4*>(xs + ((size_t)c * G::UH + uy) * TX + 4 * cx) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// y pass for this thread's 4 outputs of component c.
+template <int R>
+__device__ __forceinline__ void fused_ypass(const float* __restrict__ xs, int c, int cx, int cy, const pp_taps_small& wy,
+                                            float v[4]) {
+  using G = fused_geom<R>;
+  v[0] = v[1] = v[2] = v[3] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 2 * R + 1; ++k) {
+    const float4 a = *reinterpret_cast<const float4*>(xs + ((size_t)c * G::UH + cy + k) * TX + 4 * cx);
+    v[0] = fmaf(wy.w[k], a.x, v[0]);
+    v[1] = fmaf(wy.w[k], a.y, v[1]);
+    v[2] = fmaf(wy.w[k], a.z, v[2]);
+    v[3] = fmaf(wy.w[k], a.w, v[3]);
+  }
+}
+
+template <int R>
+struct zring {
+  float r[3][4][2 * R + 1];
+  __device__ __forceinline__ void push(const float v[3][4]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int k = 0; k < 2 * R; ++k) r[c][j][k] = r[c][j][k + 1];
+        r[c][j][2 * R] = v[c][j];
+      }
+  }
+  __device__ __forceinline__ float dot(int c, int j, const pp_taps_small& wz) const {
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2 * R + 1; ++k) s = fmaf(wz.w[k], r[c][j][k], s);
+    return s;
+  }
+};
+
+struct fused_args {
+  pp_dims d;
+  int zchunk;
+  pp_taps_small wx, wy, wz;
+};
+
+// ---- kernel A: ESM update + 3-D Gaussian of the update ---------------------------------
+template <int R>
+__global__ void __launch_bounds__(NT) k_fused_force_smooth(const float* __restrict__ F, const float* __restrict__ Mw,
+                                                           float* __restrict__ Us, fused_args a, pp_esm_consts K,
+                                                           double* __restrict__ partials, const int* __restrict__ halt) {
+  using G = fused_geom<R>;
+  __shared__ __attribute__((aligned(16))) float s_m[G::MH * G::MWP];        // warped moving, current plane
+  __shared__ __attribute__((aligned(16))) float s_f[G::MH * G::MWP];        // fixed, current plane
+  __shared__ __attribute__((aligned(16))) float s_u[3 * G::UH * G::UWP];    // raw update, current plane
+  __shared__ __attribute__((aligned(16))) float s_x[3 * G::UH * TX];        // after the x pass
+  __shared__ double red[3 * NT];
+  if (halt && *halt) return;
+
+  const pp_dims d = a.d;
+  const int t = threadIdx.x;
+  const int cx = t % (TX / 4), cy = t / (TX / 4);
+  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY, z0 = blockIdx.z * a.zchunk;
+  const size_t sy = d.nx, sz = (size_t)d.nx * d.ny;
+  const size_t N = sz * d.nz;
+
+  // Owned smoothing-input voxels (ux, uy); image values are always fetched at the clamped
+  // position so that out-of-volume halo slots replicate the edge update (ZeroFluxNeumann).
+  int own_l[G::KU];   // LDS slot in s_m / s_f of the clamped position
+  int own_w[G::KU];   // LDS slot this thread fills in s_m / s_f (its unclamped position)
+  int own_u[G::KU];   // slot in s_u
+  int own_x[G::KU], own_y[G::KU];
+  size_t own_g[G::KU];
+  bool own_cnt[G::KU];
+  float mprev[G::KU], mcur[G::KU], mnext[G::KU], fprev[G::KU], fcur[G::KU], fnext[G::KU];
+#pragma unroll
+  for (int k = 0; k < G::KU; ++k) {
+    const int e = t + k * NT;
+    const int ee = e < G::NU ? e : 0;
+    const int uy = ee / G::UW, ux = ee - uy * G::UW;
+    const int xg = tx0 - R + ux, yg = ty0 - R + uy;
+    const int xc = pp_clampi(xg, 0, d.nx - 1), yc = pp_clampi(yg, 0, d.ny - 1);
+    own_x[k] = xc;
+    own_y[k] = yc;
+    own_g[k] = (size_t)yc * sy + xc;
+    own_w[k] = (uy + 1) * G::MWP + (ux + 1);
+    own_l[k] = (yc - (ty0 - R - 1)) * G::MWP + (xc - (tx0 - R - 1));
+    own_u[k] = uy * G::UWP + ux;
+    own_cnt[k] = e < G::NU && xg >= tx0 && xg < tx0 + TX && xg < d.nx && yg >= ty0 && yg < ty0 + TY && yg < d.ny;
+  }
+  // Border ring of the image tiles (needed only in-plane): one element per low thread.
+  int brd_w = -1;
+  size_t brd_g = 0;
+  if (t < G::NB) {
+    int my, mx;
+    if (t < G::MW) { my = 0; mx = t; }
+    else if (t < 2 * G::MW) { my = G::MH - 1; mx = t - G::MW; }
+    else { const int q = t - 2 * G::MW; my = 1 + q / 2; mx = (q & 1) ? G::MW - 1 : 0; }
+    const int xc = pp_clampi(tx0 - R - 1 + mx, 0, d.nx - 1), yc = pp_clampi(ty0 - R - 1 + my, 0, d.ny - 1);
+    brd_w = my * G::MWP + mx;
+    brd_g = (size_t)yc * sy + xc;
+  }
+  static_assert(G::NB <= NT, "border ring must fit one pass");
+
+  const int zs = z0 - R;                                            // first smoothing-input plane
+  const int zo_last = (z0 + a.zchunk - 1 < d.nz - 1) ? z0 + a.zchunk - 1 : d.nz - 1;
+  const int ze = zo_last + R;                                       // last smoothing-input plane
+  const int zlo = pp_clampi(zs, 0, d.nz - 1);
+
+  // prime the z window of the image values at plane zlo
+  {
+    const size_t pm = (size_t)pp_clampi(zlo - 1, 0, d.nz - 1) * sz, pc = (size_t)zlo * sz,
+                 pn = (size_t)pp_clampi(zlo + 1, 0, d.nz - 1) * sz;
+#pragma unroll
+    for (int k = 0; k < G::KU; ++k) {
+      mprev[k] = Mw[pm + own_g[k]]; fprev[k] = F[pm + own_g[k]];
+      mcur[k] = Mw[pc + own_g[k]];  fcur[k] = F[pc + own_g[k]];
+      mnext[k] = Mw[pn + own_g[k]]; fnext[k] = F[pn + own_g[k]];
+    }
+  }
+
+  zring<R> ring;
+  float v[3][4];
+  double a_ssd = 0.0, a_ssc = 0.0, a_n = 0.0;
+  int zc_done = -1;
+
+  for (int zi = zs; zi <= ze; ++zi) {
+    const int zc = pp_clampi(zi, 0, d.nz - 1);
+    if (zc != zc_done) {
+      // (1) publish the current image plane to LDS; prefetch plane zc + 2 into registers
+      float min_[G::KU], fin_[G::KU];
+      const size_t p2 = (size_t)pp_clampi(zc + 2, 0, d.nz - 1) * sz;
+#pragma unroll
+      for (int k = 0; k < G::KU; ++k) {
+        min_[k] = Mw[p2 + own_g[k]];
+        fin_[k] = F[p2 + own_g[k]];
+      }
+      __syncthreads();  // previous plane's readers of s_m / s_f / s_x are done
+#pragma unroll
+      for (int k = 0; k < G::KU; ++k)
+        if (t + k * NT < G::NU) {
+          s_m[own_w[k]] = mcur[k];
+          s_f[own_w[k]] = fcur[k];
+        }
+      if (brd_w >= 0) {
+        s_m[brd_w] = Mw[(size_t)zc * sz + brd_g];
+        s_f[brd_w] = F[(size_t)zc * sz + brd_g];
+      }
+      __syncthreads();
+      // (2) ESM update at every smoothing-input voxel of this plane
+      const bool count_plane = (zc >= z0 && zc <= zo_last);
+#pragma unroll
+      for (int k = 0; k < G::KU; ++k)
+        if (t + k * NT < G::NU) {
+          const int l = own_l[k];
+          const float gx = pp_esm_axis(s_f[l - 1], s_f[l + 1], mcur[k], s_m[l - 1], s_m[l + 1], own_x[k], d.nx, K.hx, K.ix);
+          const float gy = pp_esm_axis(s_f[l - G::MWP], s_f[l + G::MWP], mcur[k], s_m[l - G::MWP], s_m[l + G::MWP], own_y[k],
+                                       d.ny, K.hy, K.iy);
+          const float gz = pp_esm_axis(fprev[k], fnext[k], mcur[k], mprev[k], mnext[k], zc, d.nz, K.hz, K.iz);
+          const pp_esm_out o = pp_esm_voxel(K, fcur[k], mcur[k], gx, gy, gz);
+          s_u[own_u[k]] = o.ux;
+          s_u[G::UH * G::UWP + own_u[k]] = o.uy;
+          s_u[2 * G::UH * G::UWP + own_u[k]] = o.uz;
+          if (count_plane && own_cnt[k]) {
+            a_ssd += (double)o.sq_speed;
+            a_ssc += (double)o.sq_update;
+            a_n += (double)o.counted;
+          }
+        }
+      __syncthreads();
+      // (3) x pass, (4) y pass
+      fused_xpass<R>(s_u, s_x, a.wx);
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 3; ++c) fused_ypass<R>(s_x, c, cx, cy, a.wy, v[c]);
+      // rotate the z window of the image values
+#pragma unroll
+      for (int k = 0; k < G::KU; ++k) {
+        mprev[k] = mcur[k]; mcur[k] = mnext[k]; mnext[k] = min_[k];
+        fprev[k] = fcur[k]; fcur[k] = fnext[k]; fnext[k] = fin_[k];
+      }
+      zc_done = zc;
+    }
+    // (5) z pass out of the register window (repeated planes re-enter: clamped edge)
+    ring.push(v);
+    const int zo = zi - R;
+    if (zo >= z0 && zo <= zo_last) {
+      const int x = tx0 + 4 * cx, y = ty0 + cy;
+      if (y < d.ny && x < d.nx) {
+        const size_t o = (size_t)zo * sz + (size_t)y * sy + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float r0 = ring.dot(c, 0, a.wz), r1 = ring.dot(c, 1, a.wz), r2 = ring.dot(c, 2, a.wz),
+                      r3 = ring.dot(c, 3, a.wz);
+          if ((d.nx & 3) == 0) {
+            *reinterpret_cast<float4*>(Us + c * N + o) = make_float4(r0, r1, r2, r3);
+          } else {
+            Us[c * N + o] = r0;
+            if (x + 1 < d.nx) Us[c * N + o + 1] = r1;
+            if (x + 2 < d.nx) Us[c * N + o + 2] = r2;
+            if (x + 3 < d.nx) Us[c * N + o + 3] = r3;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  pp_block_sum3<NT>(a_ssd, a_ssc, a_n, red);
+  if (t == 0) {
+    const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    partials[3 * b + 0] = a_ssd;
+    partials[3 * b + 1] = a_ssc;
+    partials[3 * b + 2] = a_n;
+  }
+}
+
+// ---- kernel B: D' = G_d * (D + U), then the next iteration's warped moving image ------
+template <int R>
+__global__ void __launch_bounds__(NT) k_fused_add_smooth_warp(const float* __restrict__ D, const float* __restrict__ Us,
+                                                              const float* __restrict__ M, float* __restrict__ Dn,
+                                                              float* __restrict__ Mw, fused_args a, pp_warp_scale sc,
+                                                              const int* __restrict__ halt) {
+  using G = fused_geom<R>;
+  __shared__ __attribute__((aligned(16))) float s_u[3 * G::UH * G::UWP];
+  __shared__ __attribute__((aligned(16))) float s_x[3 * G::UH * TX];
+  if (halt && *halt) return;
+
+  const pp_dims d = a.d;
+  const int t = threadIdx.x;
+  const int cx = t % (TX / 4), cy = t / (TX / 4);
+  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY, z0 = blockIdx.z * a.zchunk;
+  const size_t sy = d.nx, sz = (size_t)d.nx * d.ny;
+  const size_t N = sz * d.nz;
+
+  int own_u[G::KU];
+  size_t own_g[G::KU];
+#pragma unroll
+  for (int k = 0; k < G::KU; ++k) {
+    const int e = t + k * NT;
+    const int ee = e < G::NU ? e : 0;
+    const int uy = ee / G::UW, ux = ee - uy * G::UW;
+    const int xc = pp_clampi(tx0 - R + ux, 0, d.nx - 1), yc = pp_clampi(ty0 - R + uy, 0, d.ny - 1);
+    own_g[k] = (size_t)yc * sy + xc;
+    own_u[k] = uy * G::UWP + ux;
+  }
+
+  const int zs = z0 - R;
+  const int zo_last = (z0 + a.zchunk - 1 < d.nz - 1) ? z0 + a.zchunk - 1 : d.nz - 1;
+  const int ze = zo_last + R;
+  const int zlo = pp_clampi(zs, 0, d.nz - 1);
+
+  float cur[3][G::KU];
+  {
+    const size_t pc = (size_t)zlo * sz;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int k = 0; k < G::KU; ++k) cur[c][k] = D[c * N + pc + own_g[k]] + Us[c * N + pc + own_g[k]];
+  }
+
+  zring<R> ring;
+  float v[3][4];
+  int zc_done = -1;
+
+  for (int zi = zs; zi <= ze; ++zi) {
+    const int zc = pp_clampi(zi, 0, d.nz - 1);
+    if (zc != zc_done) {
+      // prefetch the next plane's D + U while this one is smoothed
+      float nxt[3][G::KU];
+      const size_t pn = (size_t)pp_clampi(zc + 1, 0, d.nz - 1) * sz;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < G::KU; ++k) nxt[c][k] = D[c * N + pn + own_g[k]] + Us[c * N + pn + own_g[k]];
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < G::KU; ++k)
+          if (t + k * NT < G::NU) s_u[c * G::UH * G::UWP + own_u[k]] = cur[c][k];
+      __syncthreads();
+      fused_xpass<R>(s_u, s_x, a.wx);
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 3; ++c) fused_ypass<R>(s_x, c, cx, cy, a.wy, v[c]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < G::KU; ++k) cur[c][k] = nxt[c][k];
+      zc_done = zc;
+    }
+    ring.push(v);
+    const int zo = zi - R;
+    if (zo >= z0 && zo <= zo_last) {
+      const int x = tx0 + 4 * cx, y = ty0 + cy;
+      if (y < d.ny && x < d.nx) {
+        const size_t o = (size_t)zo * sz + (size_t)y * sy + x;
+        float dn[3][4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dn[c][j] = ring.dot(c, j, a.wz);
+        float mw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int bx, by, bz;
+          float fx, fy, fz;
+          pp_split(x + j, dn[0][j] * sc.ix, bx, fx);
+          pp_split(y, dn[1][j] * sc.iy, by, fy);
+          pp_split(zo, dn[2][j] * sc.iz, bz, fz);
+          const bool inside = (x + j < d.nx) && pp_inside1(bx, fx, d.nx) && pp_inside1(by, fy, d.ny) && pp_inside1(bz, fz, d.nz);
+          mw[j] = inside ? pp_trilinear(M, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz) : FLT_MAX;
+        }
+        if ((d.nx & 3) == 0) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<float4*>(Dn + c * N + o) = make_float4(dn[c][0], dn[c][1], dn[c][2], dn[c][3]);
+          *reinterpret_cast<float4*>(Mw + o) = make_float4(mw[0], mw[1], mw[2], mw[3]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (x + j < d.nx) {
+              Dn[o + j] = dn[0][j];
+              Dn[N + o + j] = dn[1][j];
+              Dn[2 * N + o + j] = dn[2][j];
+              Mw[o + j] = mw[j];
+            }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+
+void esm_consts(const pp_geom* g, const pp_demons_params* p, pp_esm_consts* K) {
+  K->hx = (float)(0.5 / g->spacing[0]);
+  K->hy = (float)(0.5 / g->spacing[1]);
+  K->hz = (float)(0.5 / g->spacing[2]);
+  K->ix = (float)(1.0 / g->spacing[0]);
+  K->iy = (float)(1.0 / g->spacing[1]);
+  K->iz = (float)(1.0 / g->spacing[2]);
+  if (p->max_step_length > 0.0) {
+    double nrm = 0.0;
+    for (int k = 0; k < 3; ++k) nrm += g->spacing[k] * g->spacing[k];
+    nrm *= p->max_step_length * p->max_step_length / 3.0;
+    K->inv_norm = (float)(1.0 / nrm);
+    K->has_norm = 1;
+  } else {
+    K->inv_norm = 0.0f;
+    K->has_norm = 0;
+  }
+  K->denom_thr = (float)p->denominator_threshold;
+  K->intensity_thr = p->intensity_threshold;
+}
+
+void small_taps(const pp_taps& t, int R, pp_taps_small* s) {
+  for (int k = 0; k < 2 * PP_FUSED_MAX_R + 1; ++k) s->w[k] = 0.0f;
+  for (int k = -t.r; k <= t.r; ++k) s->w[k + R] = t.w[k + t.r];  // centred; outer taps stay 0
+}
+
+int fused_zchunk(const pp_dims& d) {
+  // enough blocks to fill 256 CUs several times over, chunks long enough to amortise the z halo
+  if (const char* e = getenv("PP_FUSED_ZCHUNK")) {
+    const int v = atoi(e);
+    if (v >= 1) return v;
+  }
+  const int tiles = ((d.nx + TX - 1) / TX) * ((d.ny + TY - 1) / TY);
+  int zc = 32;
+  while (zc > 8 && (size_t)tiles * ((d.nz + zc - 1) / zc) < 2048) zc /= 2;
+  if (zc > d.nz) zc = d.nz;
+  return zc;
+}
+
+template <int R>
+int launch_fused_iteration(pp_ctx* ctx, const float* F, const float* M, const float* Mw_in, float* Mw_out, const float* D,
+                           float* Dn, float* Us, const fused_args& fu, const fused_args& fd, const pp_esm_consts& K,
+                           const pp_warp_scale& sc, double* partials, const int* halt) {
+  const pp_dims& d = fu.d;
+  const dim3 grid((d.nx + TX - 1) / TX, (d.ny + TY - 1) / TY, (d.nz + fu.zchunk - 1) / fu.zchunk), block(NT);
+  hipLaunchKernelGGL((k_fused_force_smooth<R>), grid, block, 0, ctx->stream, F, Mw_in, Us, fu, K, partials, halt);
+  PP_LAUNCH_CHECK(ctx, "k_fused_force_smooth");
+  hipLaunchKernelGGL((k_fused_add_smooth_warp<R>), grid, block, 0, ctx->stream, D, (const float*)Us, M, Dn, Mw_out, fd, sc, halt);
+  PP_LAUNCH_CHECK(ctx, "k_fused_add_smooth_warp");
+  return PP_OK;
+}
+
+int check_demons_args(pp_ctx* ctx, const pp_geom* g, const pp_demons_params* p) {
+  int rc = pp_geom_check(ctx, g, "grid");
+  if (rc) return rc;
+  PP_REQUIRE(ctx, p, "demons: NULL parameters");
+  if (!pp_geom_identity_dir(g))
+    return pp_fail(ctx, PP_ERR_UNSUPPORTED, "demons: only identity direction cosines are supported");
+  PP_REQUIRE(ctx, p->iterations >= 0, "demons: negative iteration count");
+  return PP_OK;
+}
+
+int read_stats(pp_ctx* ctx, const pp_dev_stats* dst, pp_demons_stats* out) {
+  pp_dev_stats h;
+  PP_HIP(ctx, hipMemcpyAsync(&h, dst, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  out->metric = h.metric;
+  out->rms_change = h.rms;
+  out->sum_sq_diff = h.ssd;
+  out->sum_sq_change = h.ssc;
+  out->n_pixels = h.npx;
+  out->elapsed_iterations = h.elapsed;
+  out->halted = h.halt;
+  return PP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pp_demons_force_f32(pp_ctx* ctx, const float* fixed, const float* warped, const pp_geom* g, const pp_demons_params* p,
+                        float* update, pp_demons_stats* stats) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, fixed && warped && update, "pp_demons_force_f32: NULL volume");
+  int rc = check_demons_args(ctx, g, p);
+  if (rc) return rc;
+  const pp_dims d{g->size[0], g->size[1], g->size[2]};
+  const size_t N = pp_nvox(g->size);
+  const unsigned nb = grid_for(N, 8192);
+  rc = pp_reserve(ctx, pp_align_up(3 * (size_t)nb * sizeof(double), 256) + 256);
+  if (rc) return rc;
+  pp_carver cv{ctx->ws, 0};
+  double* partials = cv.take<double>(3 * (size_t)nb);
+  pp_dev_stats* dst = cv.take<pp_dev_stats>(1);
+  pp_esm_consts K;
+  esm_consts(g, p, &K);
+  PP_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(pp_dev_stats), ctx->stream));
+  hipLaunchKernelGGL(k_demons_force, dim3(nb), dim3(NT), 0, ctx->stream, fixed, warped, update, d, K, partials, (const int*)nullptr);
+  PP_LAUNCH_CHECK(ctx, "k_demons_force");
+  hipLaunchKernelGGL(k_demons_finalize, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, dst, -1.0);
+  PP_LAUNCH_CHECK(ctx, "k_demons_finalize");
+  if (stats) return read_stats(ctx, dst, stats);
+  return PP_OK;
+}
+
+int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, const pp_geom* g, const pp_demons_params* p,
+                          float* field, pp_demons_stats* stats) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, fixed && moving && field, "pp_demons_execute_f32: NULL volume");
+  int rc = check_demons_args(ctx, g, p);
+  if (rc) return rc;
+  const pp_dims d{g->size[0], g->size[1], g->size[2]};
+  const size_t N = pp_nvox(g->size);
+
+  pp_taps tu[3], td[3];
+  for (int a = 0; a < 3; ++a) {
+    rc = pp_make_taps(ctx, p->sigma_u_vox[a] * p->sigma_u_vox[a], p->max_error, p->max_kernel_width, &tu[a]);
+    if (rc) return rc;
+    rc = pp_make_taps(ctx, p->sigma_d_vox[a] * p->sigma_d_vox[a], p->max_error, p->max_kernel_width, &td[a]);
+    if (rc) return rc;
+  }
+  int rmax = 0;
+  for (int a = 0; a < 3; ++a) {
+    if (tu[a].r > rmax) rmax = tu[a].r;
+    if (td[a].r > rmax) rmax = td[a].r;
+  }
+  const bool fusable = p->smooth_update && p->smooth_displacement && rmax <= PP_FUSED_MAX_R;
+  int variant = p->variant;
+  if (variant == PP_DEMONS_AUTO) variant = fusable ? PP_DEMONS_FUSED : PP_DEMONS_STAGED;
+  if (variant == PP_DEMONS_FUSED && !fusable)
+    return pp_fail(ctx, PP_ERR_UNSUPPORTED,
+                   "fused demons needs both smoothers on and kernel radii <= %d (got %d)", PP_FUSED_MAX_R, rmax);
+  PP_REQUIRE(ctx, variant == PP_DEMONS_FUSED || variant == PP_DEMONS_STAGED, "demons: unknown variant");
+
+  pp_esm_consts K;
+  esm_consts(g, p, &K);
+  const pp_warp_scale sc{(float)(1.0 / g->spacing[0]), (float)(1.0 / g->spacing[1]), (float)(1.0 / g->spacing[2])};
+  const double max_rms = p->max_rms_error > 0.0 ? p->max_rms_error : -1.0;
+
+  if (variant == PP_DEMONS_STAGED) {
+    const unsigned nb = grid_for(N, 8192);
+    const size_t need = pp_align_up(N * 4, 256) + 3 * pp_align_up(3 * N * 4, 256) + pp_align_up(3 * (size_t)nb * 8, 256) + 256;
+    rc = pp_reserve(ctx, need);
+    if (rc) return rc;
+    pp_carver cv{ctx->ws, 0};
+    float* Mw = cv.take<float>(N);
+    float* U = cv.take<float>(3 * N);
+    float* T1 = cv.take<float>(3 * N);
+    float* T2 = cv.take<float>(3 * N);
+    double* partials = cv.take<double>(3 * (size_t)nb);
+    pp_dev_stats* dst = cv.take<pp_dev_stats>(1);
+    const int* halt = &dst->halt;
+    const int order[3] = {0, 1, 2};
+    PP_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(pp_dev_stats), ctx->stream));
+    PP_HIP(ctx, hipMemsetAsync(field, 0, 3 * N * sizeof(float), ctx->stream));
+    for (int it = 0; it < p->iterations; ++it) {
+      rc = pp_warp_same_grid(ctx, moving, field, d, sc, FLT_MAX, Mw, halt);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_demons_force, dim3(nb), dim3(NT), 0, ctx->stream, fixed, (const float*)Mw, U, d, K, partials, halt);
+      PP_LAUNCH_CHECK(ctx, "k_demons_force");
+      if (p->smooth_update) {
+        rc = pp_smooth3_staged(ctx, U, nullptr, U, T1, T2, d, 3, tu, order, halt);
+        if (rc) return rc;
+      }
+      if (p->smooth_displacement) {
+        rc = pp_smooth3_staged(ctx, field, U, field, T1, T2, d, 3, td, order, halt);  // add fused into pass 1
+        if (rc) return rc;
+      } else {
+        hipLaunchKernelGGL(k_add_inplace, dim3(grid_for(3 * N)), dim3(NT), 0, ctx->stream, field, (const float*)U, 3 * N, halt);
+        PP_LAUNCH_CHECK(ctx, "k_add_inplace");
+      }
+      hipLaunchKernelGGL(k_demons_finalize, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, dst, max_rms);
+      PP_LAUNCH_CHECK(ctx, "k_demons_finalize");
+    }
+    if (stats) return read_stats(ctx, dst, stats);
+    return PP_OK;
+  }
+
+  // ---- fused schedule ----
+  const int R = rmax < 1 ? 1 : rmax;
+  fused_args fu, fd;
+  fu.d = d;
+  fu.zchunk = fused_zchunk(d);
+  fd = fu;
+  small_taps(tu[0], R, &fu.wx);
+  small_taps(tu[1], R, &fu.wy);
+  small_taps(tu[2], R, &fu.wz);
+  small_taps(td[0], R, &fd.wx);
+  small_taps(td[1], R, &fd.wy);
+  small_taps(td[2], R, &fd.wz);
+  const size_t nblk = (size_t)((d.nx + TX - 1) / TX) * ((d.ny + TY - 1) / TY) * ((d.nz + fu.zchunk - 1) / fu.zchunk);
+  const size_t need = 2 * pp_align_up(N * 4, 256) + 2 * pp_align_up(3 * N * 4, 256) + pp_align_up(3 * nblk * 8, 256) + 256;
+  rc = pp_reserve(ctx, need);
+  if (rc) return rc;
+  pp_carver cv{ctx->ws, 0};
+  float* MwA = cv.take<float>(N);
+  float* MwB = cv.take<float>(N);
+  float* Us = cv.take<float>(3 * N);
+  float* D2 = cv.take<float>(3 * N);
+  double* partials = cv.take<double>(3 * nblk);
+  pp_dev_stats* dst = cv.take<pp_dev_stats>(1);
+  const int* halt = &dst->halt;
+  PP_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(pp_dev_stats), ctx->stream));
+  PP_HIP(ctx, hipMemsetAsync(field, 0, 3 * N * sizeof(float), ctx->stream));
+  for (int it = 0; it < p->iterations; ++it) {
+    // D = 0 warps the moving image onto itself exactly, so iteration 0 reads it directly.
+    const float* mw_in = it == 0 ? moving : ((it & 1) ? MwA : MwB);
+    float* mw_out = (it & 1) ? MwB : MwA;
+    const float* Dcur = (it & 1) ? D2 : field;
+    float* Dnext = (it & 1) ? field : D2;
+    switch (R) {
+      case 1: rc = launch_fused_iteration<1>(ctx, fixed, moving, mw_in, mw_out, Dcur, Dnext, Us, fu, fd, K, sc, partials, halt); break;
+      case 2: rc = launch_fused_iteration<2>(ctx, fixed, moving, mw_in, mw_out, Dcur, Dnext, Us, fu, fd, K, sc, partials, halt); break;
+      default: rc = launch_fused_iteration<3>(ctx, fixed, moving, mw_in, mw_out, Dcur, Dnext, Us, fu, fd, K, sc, partials, halt); break;
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_demons_finalize, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nblk, dst, max_rms);
+    PP_LAUNCH_CHECK(ctx, "k_demons_finalize");
+  }
+  hipLaunchKernelGGL(k_copy_if_odd, dim3(grid_for(3 * N)), dim3(NT), 0, ctx->stream, field, (const float*)D2, 3 * N,
+                     (const pp_dev_stats*)dst);
+  PP_LAUNCH_CHECK(ctx, "k_copy_if_odd");
+  if (stats) return read_stats(ctx, dst, stats);
+  return PP_OK;
+}
+
+}  // extern "C"

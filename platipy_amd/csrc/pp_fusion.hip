@@ -1,0 +1,340 @@
+// platipy_amd/csrc/pp_fusion.hip -- locality-weighted label fusion and the linear-registration
+// metric.
+//
+// Replaces the SimpleITK arithmetic of platipy/imaging/label/fusion.py: compute_weight_map
+// (:56-202, vote types local/global), combine_labels (:239-292) and the threshold step of
+// process_probability_image (:295-308); plus itk::MeanSquaresImageToImageMetricv4's value and
+// derivative for registration/linear.py:141-148,238.  Everything is a streaming elementwise
+// pass or a reduction (HBM-bound); reductions write per-block partials that a second, single
+// block folds in a fixed order, so results do not depend on scheduling.
+#include "pp_internal.h"
+#include "pp_kernels.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+unsigned grid_for(size_t work, unsigned cap = 4096u) {
+  size_t blocks = (work + NT - 1) / NT;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+__global__ void __launch_bounds__(NT) k_sqdiff(const float* __restrict__ a, const float* __restrict__ b,
+                                               float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+    const float d = a[i] - b[i];
+    out[i] = d * d;
+  }
+}
+
+__global__ void __launch_bounds__(NT) k_inv_eps(float* __restrict__ w, size_t n, float eps) {
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) w[i] = 1.0f / (w[i] + eps);
+}
+
+__global__ void __launch_bounds__(NT) k_ssd_partial(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                    double* __restrict__ partials) {
+  __shared__ double red[3 * NT];
+  double s = 0.0, z0 = 0.0, z1 = 0.0;
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+    const double d = (double)a[i] - (double)b[i];
+    s += d * d;
+  }
+  pp_block_sum3<NT>(s, z0, z1, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(NT) k_sum_final(const double* __restrict__ partials, int count, int stride, int nfields,
+                                                  double* __restrict__ result) {
+  __shared__ double red[3 * NT];
+  for (int f = 0; f < nfields; ++f) {
+    double s = 0.0, z0 = 0.0, z1 = 0.0;
+    for (int i = threadIdx.x; i < count; i += NT) s += partials[(size_t)i * stride + f];
+    pp_block_sum3<NT>(s, z0, z1, red);
+    if (threadIdx.x == 0) result[f] = s;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(NT) k_fuse_accumulate(const float* __restrict__ w, const uint8_t* __restrict__ label,
+                                                        float* __restrict__ wsum, float* __restrict__ wlsum, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+    const float wi = w[i];
+    if (wsum) wsum[i] += wi;
+    wlsum[i] += wi * (float)label[i];
+  }
+}
+
+__global__ void __launch_bounds__(NT) k_fuse_divide(const float* __restrict__ wl, const float* __restrict__ ws,
+                                                    float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+    const float s = ws[i];
+    out[i] = wl[i] / (s == 0.0f ? 1.0f : s);
+  }
+}
+
+__global__ void __launch_bounds__(NT) k_minmax_partial(const float* __restrict__ in, size_t n, float* __restrict__ partials) {
+  __shared__ float smin[NT], smax[NT];
+  float lo = FLT_MAX, hi = -FLT_MAX;
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+    const float v = in[i];
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+  }
+  smin[threadIdx.x] = lo;
+  smax[threadIdx.x] = hi;
+  __syncthreads();
+  for (int s = NT / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + s]);
+      smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x] = smin[0];
+    partials[2 * blockIdx.x + 1] = smax[0];
+  }
+}
+
+__global__ void __launch_bounds__(NT) k_minmax_final(const float* __restrict__ partials, int count, float* __restrict__ result) {
+  __shared__ float smin[NT], smax[NT];
+  float lo = FLT_MAX, hi = -FLT_MAX;
+  for (int i = threadIdx.x; i < count; i += NT) {
+    lo = fminf(lo, partials[2 * i]);
+    hi = fmaxf(hi, partials[2 * i + 1]);
+  }
+  smin[threadIdx.x] = lo;
+  smax[threadIdx.x] = hi;
+  __syncthreads();
+  for (int s = NT / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + s]);
+      smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    result[0] = smin[0];
+    result[1] = smax[0];
+  }
+}
+
+// itk::RescaleIntensityImageFilter (scale/shift in double, clamped to the output range) then
+// itk::ThresholdImageFilter(lower, upper = 1, outside = 0).
+__global__ void __launch_bounds__(NT) k_rescale_threshold(float* __restrict__ data, size_t n, double scale, double shift,
+                                                          float lower) {
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+    double r = (double)data[i] * scale + shift;
+    r = r < 0.0 ? 0.0 : (r > 1.0 ? 1.0 : r);
+    const float v = (float)r;
+    data[i] = (v < lower || v > 1.0f) ? 0.0f : v;
+  }
+}
+
+__global__ void __launch_bounds__(NT) k_binary_threshold(const float* __restrict__ prob, size_t n, float inv_max,
+                                                         float threshold, uint8_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT)
+    out[i] = (prob[i] * inv_max >= threshold) ? (uint8_t)1 : (uint8_t)0;
+}
+
+// ---------------------------------------------------------------------------------------
+// mean-squares metric + gradient w.r.t. an affine index map (12 parameters).
+// sample x = start + k*step (fixed voxel lattice); c = A x + b in moving index space;
+// m = trilinear(moving, c) with the moving gradient taken from the same 8 samples;
+// value = sum (f - m)^2; d value / d A[r][q] = sum -2 (f - m) g_r x_q; d / d b[r] = sum -2 (f - m) g_r.
+struct msq_args {
+  double A[9], b[3];
+  int start[3], step[3], count[3];
+};
+
+__global__ void __launch_bounds__(NT) k_meansq_affine(const float* __restrict__ F, pp_dims df, const float* __restrict__ M,
+                                                      pp_dims dm, const uint8_t* __restrict__ mask, msq_args a,
+                                                      double* __restrict__ partials /* [grid][14] */) {
+  __shared__ double red[3 * NT];
+  double acc[14];
+  for (int k = 0; k < 14; ++k) acc[k] = 0.0;
+  const size_t total = (size_t)a.count[0] * a.count[1] * a.count[2];
+  for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
+    const int kx = (int)(e % a.count[0]);
+    const int ky = (int)((e / a.count[0]) % a.count[1]);
+    const int kz = (int)(e / ((size_t)a.count[0] * a.count[1]));
+    const int x = a.start[0] + kx * a.step[0], y = a.start[1] + ky * a.step[1], z = a.start[2] + kz * a.step[2];
+    const size_t fi = ((size_t)z * df.ny + y) * df.nx + x;
+    if (mask && !mask[fi]) continue;
+    const double xd = x, yd = y, zd = z;
+    const double cx = a.A[0] * xd + a.A[1] * yd + a.A[2] * zd + a.b[0];
+    const double cy = a.A[3] * xd + a.A[4] * yd + a.A[5] * zd + a.b[1];
+    const double cz = a.A[6] * xd + a.A[7] * yd + a.A[8] * zd + a.b[2];
+    if (!(cx >= -0.5 && cx < dm.nx - 0.5 && cy >= -0.5 && cy < dm.ny - 0.5 && cz >= -0.5 && cz < dm.nz - 0.5)) continue;
+    const double flx = floor(cx), fly = floor(cy), flz = floor(cz);
+    int x0, x1, y0, y1, z0, z1;
+    float wx, wy, wz;
+    pp_axis_setup((int)flx, (float)(cx - flx), dm.nx, x0, x1, wx);
+    pp_axis_setup((int)fly, (float)(cy - fly), dm.ny, y0, y1, wy);
+    pp_axis_setup((int)flz, (float)(cz - flz), dm.nz, z0, z1, wz);
+    const size_t sy = dm.nx, sz = (size_t)dm.nx * dm.ny;
+    const float a000 = M[z0 * sz + y0 * sy + x0], a100 = M[z0 * sz + y0 * sy + x1];
+    const float a010 = M[z0 * sz + y1 * sy + x0], a110 = M[z0 * sz + y1 * sy + x1];
+    const float a001 = M[z1 * sz + y0 * sy + x0], a101 = M[z1 * sz + y0 * sy + x1];
+    const float a011 = M[z1 * sz + y1 * sy + x0], a111 = M[z1 * sz + y1 * sy + x1];
+    const float v00 = a000 + (a100 - a000) * wx, v10 = a010 + (a110 - a010) * wx;
+    const float v01 = a001 + (a101 - a001) * wx, v11 = a011 + (a111 - a011) * wx;
+    const float v0 = v00 + (v10 - v00) * wy, v1 = v01 + (v11 - v01) * wy;
+    const float m = v0 + (v1 - v0) * wz;
+    // gradient of the trilinear interpolant (per moving voxel)
+    const float gx0 = (a100 - a000) + ((a110 - a010) - (a100 - a000)) * wy;
+    const float gx1 = (a101 - a001) + ((a111 - a011) - (a101 - a001)) * wy;
+    const float gx = gx0 + (gx1 - gx0) * wz;
+    const float gy = (v10 - v00) + ((v11 - v01) - (v10 - v00)) * wz;
+    const float gz = v1 - v0;
+    const double diff = (double)F[fi] - (double)m;
+    acc[0] += diff * diff;
+    acc[1] += 1.0;
+    const double s = -2.0 * diff;
+    const double g[3] = {s * gx, s * gy, s * gz};
+    for (int r = 0; r < 3; ++r) {
+      acc[2 + r * 3 + 0] += g[r] * xd;
+      acc[2 + r * 3 + 1] += g[r] * yd;
+      acc[2 + r * 3 + 2] += g[r] * zd;
+      acc[11 + r] += g[r];
+    }
+  }
+  for (int k = 0; k < 14; k += 3) {
+    double p = acc[k], q = k + 1 < 14 ? acc[k + 1] : 0.0, r = k + 2 < 14 ? acc[k + 2] : 0.0;
+    pp_block_sum3<NT>(p, q, r, red);
+    if (threadIdx.x == 0) {
+      partials[(size_t)blockIdx.x * 14 + k] = p;
+      if (k + 1 < 14) partials[(size_t)blockIdx.x * 14 + k + 1] = q;
+      if (k + 2 < 14) partials[(size_t)blockIdx.x * 14 + k + 2] = r;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pp_weight_map_local_f32(pp_ctx* ctx, const float* target, const float* moving, const int size[3],
+                            const double spacing[3], double sigma, double epsilon, float* weight) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, target && moving && weight && size && spacing, "pp_weight_map_local_f32: NULL argument");
+  const size_t N = pp_nvox(size);
+  PP_REQUIRE(ctx, N > 0, "pp_weight_map_local_f32: empty volume");
+  hipLaunchKernelGGL(k_sqdiff, dim3(grid_for(N, 65535u)), dim3(NT), 0, ctx->stream, target, moving, weight, N);
+  PP_LAUNCH_CHECK(ctx, "k_sqdiff");
+  const double var[3] = {sigma * sigma, sigma * sigma, sigma * sigma};
+  // sitk.DiscreteGaussian defaults: maximumKernelWidth 32, maximumError 0.01, useImageSpacing True
+  int rc = pp_discrete_gaussian_f32(ctx, weight, weight, size, spacing, var, 0.01, 32, 1);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_inv_eps, dim3(grid_for(N, 65535u)), dim3(NT), 0, ctx->stream, weight, N, (float)epsilon);
+  PP_LAUNCH_CHECK(ctx, "k_inv_eps");
+  return PP_OK;
+}
+
+int pp_sum_sq_diff_f32(pp_ctx* ctx, const float* a, const float* b, size_t n, double* result) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, a && b && result, "pp_sum_sq_diff_f32: NULL argument");
+  const unsigned nb = grid_for(n, 2048u);
+  int rc = pp_reserve(ctx, pp_align_up((nb + 1) * sizeof(double), 256));
+  if (rc) return rc;
+  double* partials = reinterpret_cast<double*>(ctx->ws);
+  hipLaunchKernelGGL(k_ssd_partial, dim3(nb), dim3(NT), 0, ctx->stream, a, b, n, partials);
+  PP_LAUNCH_CHECK(ctx, "k_ssd_partial");
+  hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, 1, 1, partials + nb);
+  PP_LAUNCH_CHECK(ctx, "k_sum_final");
+  PP_HIP(ctx, hipMemcpyAsync(result, partials + nb, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PP_OK;
+}
+
+int pp_fuse_accumulate_u8(pp_ctx* ctx, const float* weight, const uint8_t* label, float* wsum, float* wlsum, size_t n) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, weight && label && wlsum, "pp_fuse_accumulate_u8: NULL argument");
+  hipLaunchKernelGGL(k_fuse_accumulate, dim3(grid_for(n, 65535u)), dim3(NT), 0, ctx->stream, weight, label, wsum, wlsum, n);
+  PP_LAUNCH_CHECK(ctx, "k_fuse_accumulate");
+  return PP_OK;
+}
+
+int pp_fuse_divide_f32(pp_ctx* ctx, const float* wlsum, const float* wsum, float* out, size_t n) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, wlsum && wsum && out, "pp_fuse_divide_f32: NULL argument");
+  hipLaunchKernelGGL(k_fuse_divide, dim3(grid_for(n, 65535u)), dim3(NT), 0, ctx->stream, wlsum, wsum, out, n);
+  PP_LAUNCH_CHECK(ctx, "k_fuse_divide");
+  return PP_OK;
+}
+
+int pp_minmax_f32(pp_ctx* ctx, const float* in, size_t n, float* min_out, float* max_out) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, in && min_out && max_out && n > 0, "pp_minmax_f32: NULL or empty argument");
+  const unsigned nb = grid_for(n, 2048u);
+  int rc = pp_reserve(ctx, pp_align_up((2 * nb + 2) * sizeof(float), 256));
+  if (rc) return rc;
+  float* partials = reinterpret_cast<float*>(ctx->ws);
+  hipLaunchKernelGGL(k_minmax_partial, dim3(nb), dim3(NT), 0, ctx->stream, in, n, partials);
+  PP_LAUNCH_CHECK(ctx, "k_minmax_partial");
+  hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(NT), 0, ctx->stream, (const float*)partials, (int)nb, partials + 2 * nb);
+  PP_LAUNCH_CHECK(ctx, "k_minmax_final");
+  float h[2];
+  PP_HIP(ctx, hipMemcpyAsync(h, partials + 2 * nb, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *min_out = h[0];
+  *max_out = h[1];
+  return PP_OK;
+}
+
+int pp_rescale_threshold_f32(pp_ctx* ctx, float* data, size_t n, float in_min, float in_max, float lower) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, data, "pp_rescale_threshold_f32: NULL argument");
+  // RescaleIntensityImageFilter::BeforeThreadedGenerateData, output range [0, 1]
+  double scale;
+  if (in_min != in_max) scale = 1.0 / ((double)in_max - (double)in_min);
+  else if (in_max != 0.0f) scale = 1.0 / (double)in_max;
+  else scale = 0.0;
+  const double shift = 0.0 - (double)in_min * scale;
+  hipLaunchKernelGGL(k_rescale_threshold, dim3(grid_for(n, 65535u)), dim3(NT), 0, ctx->stream, data, n, scale, shift, lower);
+  PP_LAUNCH_CHECK(ctx, "k_rescale_threshold");
+  return PP_OK;
+}
+
+int pp_binary_threshold_f32(pp_ctx* ctx, const float* prob, size_t n, float inv_max, float threshold, uint8_t* out) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, prob && out, "pp_binary_threshold_f32: NULL argument");
+  hipLaunchKernelGGL(k_binary_threshold, dim3(grid_for(n, 65535u)), dim3(NT), 0, ctx->stream, prob, n, inv_max, threshold, out);
+  PP_LAUNCH_CHECK(ctx, "k_binary_threshold");
+  return PP_OK;
+}
+
+int pp_meansq_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], const float* moving, const int msize[3],
+                         const double A[9], const double b[3], const int start[3], const int step[3],
+                         const uint8_t* fixed_mask, double* result) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, fixed && fsize && moving && msize && A && b && start && step && result, "pp_meansq_affine_f32: NULL argument");
+  msq_args a;
+  memcpy(a.A, A, sizeof(a.A));
+  memcpy(a.b, b, sizeof(a.b));
+  size_t total = 1;
+  for (int k = 0; k < 3; ++k) {
+    PP_REQUIRE(ctx, step[k] >= 1 && start[k] >= 0 && start[k] < fsize[k], "pp_meansq_affine_f32: bad lattice");
+    a.start[k] = start[k];
+    a.step[k] = step[k];
+    a.count[k] = (fsize[k] - 1 - start[k]) / step[k] + 1;
+    total *= (size_t)a.count[k];
+  }
+  const pp_dims df{fsize[0], fsize[1], fsize[2]}, dm{msize[0], msize[1], msize[2]};
+  const unsigned nb = grid_for(total, 1024u);
+  int rc = pp_reserve(ctx, pp_align_up(((size_t)nb * 14 + 14) * sizeof(double), 256));
+  if (rc) return rc;
+  double* partials = reinterpret_cast<double*>(ctx->ws);
+  hipLaunchKernelGGL(k_meansq_affine, dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, a, partials);
+  PP_LAUNCH_CHECK(ctx, "k_meansq_affine");
+  hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, 14, 14, partials + (size_t)nb * 14);
+  PP_LAUNCH_CHECK(ctx, "k_sum_final");
+  PP_HIP(ctx, hipMemcpyAsync(result, partials + (size_t)nb * 14, 14 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PP_OK;
+}
+
+}  // extern "C"

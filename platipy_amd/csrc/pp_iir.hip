@@ -1,0 +1,242 @@
+// platipy_amd/csrc/pp_iir.hip -- recursive (IIR) Gaussian smoothing.
+//
+// Replaces sitk.SmoothingRecursiveGaussian(dvf_total, sigma) (reference:
+// platipy/imaging/registration/deformable.py:157-158), i.e. itk::RecursiveGaussianImageFilter:
+// Deriche's 4th-order recursive approximation of the Gaussian, run as a causal plus an
+// anti-causal pass per line with edge-value extension, along z, then x, then y; results of each
+// directional pass are stored as fp32 (ITK's internal images are float), the recursion itself
+// runs in fp64.  One thread owns one line; lanes always sit on consecutive x so global
+// accesses stay coalesced -- for lines ALONG x the block transposes 256-row x 16-column chunks
+// through LDS.  Runs once per pyramid level, not in the inner loop.
+#include "pp_internal.h"
+#include "pp_kernels.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+struct rg_coef {
+  double n0, n1, n2, n3;
+  double d1, d2, d3, d4;
+  double m1, m2, m3, m4;
+  double kn, km;  // steady-state gains SN/SD and SM/SD (edge extension)
+};
+
+// Deriche zero-order coefficients with ITK's normalisation (unit DC gain, symmetric).
+void rg_setup(double sigma, double spacing, rg_coef* k) {
+  const double sd = sigma / std::fabs(spacing);
+  const double W1 = 0.6681, L1 = -1.3932, W2 = 2.0787, L2 = -1.3732;
+  const double A1 = 1.3530, B1 = 1.8151, A2 = -0.3531, B2 = 0.0902;
+  const double c1 = std::cos(W1 / sd), c2 = std::cos(W2 / sd), s1 = std::sin(W1 / sd), s2 = std::sin(W2 / sd);
+  const double e1 = std::exp(L1 / sd), e2 = std::exp(L2 / sd);
+  k->d4 = e1 * e1 * e2 * e2;
+  k->d3 = -2 * c1 * e1 * e2 * e2 + -2 * c2 * e2 * e1 * e1;
+  k->d2 = 4 * c2 * c1 * e1 * e2 + e1 * e1 + e2 * e2;
+  k->d1 = -2 * (e2 * c2 + e1 * c1);
+  const double SD = 1.0 + k->d1 + k->d2 + k->d3 + k->d4;
+  double n0 = A1 + A2;
+  double n1 = e2 * (B2 * s2 - (A2 + 2 * A1) * c2) + e1 * (B1 * s1 - (A1 + 2 * A2) * c1);
+  double n2 = 2 * e1 * e2 * ((A1 + A2) * c2 * c1 - (B1 * c2 * s1 + B2 * c1 * s2)) + A2 * e1 * e1 + A1 * e2 * e2;
+  double n3 = e2 * e1 * e1 * (B2 * s2 - A2 * c2) + e1 * e2 * e2 * (B1 * s1 - A1 * c1);
+  const double SN = n0 + n1 + n2 + n3;
+  const double alpha0 = 2 * SN / SD - n0;
+  n0 /= alpha0; n1 /= alpha0; n2 /= alpha0; n3 /= alpha0;
+  k->n0 = n0; k->n1 = n1; k->n2 = n2; k->n3 = n3;
+  k->m1 = n1 - k->d1 * n0;
+  k->m2 = n2 - k->d2 * n0;
+  k->m3 = n3 - k->d3 * n0;
+  k->m4 = -k->d4 * n0;
+  k->kn = (n0 + n1 + n2 + n3) / SD;
+  k->km = (k->m1 + k->m2 + k->m3 + k->m4) / SD;
+}
+
+struct rg_state {
+  double x1, x2, x3, x4, y1, y2, y3, y4;
+};
+
+__device__ __forceinline__ void rg_init_causal(rg_state& s, double edge, const rg_coef& k) {
+  s.x1 = s.x2 = s.x3 = s.x4 = edge;
+  s.y1 = s.y2 = s.y3 = s.y4 = edge * k.kn;
+}
+__device__ __forceinline__ void rg_init_anti(rg_state& s, double edge, const rg_coef& k) {
+  s.x1 = s.x2 = s.x3 = s.x4 = edge;
+  s.y1 = s.y2 = s.y3 = s.y4 = edge * k.km;
+}
+// causal: y[i] = n0 x[i] + n1 x[i-1] + n2 x[i-2] + n3 x[i-3] - d1 y[i-1] - ... - d4 y[i-4]
+__device__ __forceinline__ double rg_step_causal(rg_state& s, double x, const rg_coef& k) {
+  const double y = (k.n0 * x + k.n1 * s.x1 + k.n2 * s.x2 + k.n3 * s.x3) - (k.d1 * s.y1 + k.d2 * s.y2 + k.d3 * s.y3 + k.d4 * s.y4);
+  s.x3 = s.x2; s.x2 = s.x1; s.x1 = x;
+  s.y4 = s.y3; s.y3 = s.y2; s.y2 = s.y1; s.y1 = y;
+  return y;
+}
+// anti-causal: y[i] = m1 x[i+1] + m2 x[i+2] + m3 x[i+3] + m4 x[i+4] - d1 y[i+1] - ... - d4 y[i+4]
+__device__ __forceinline__ double rg_step_anti(rg_state& s, double x, const rg_coef& k) {
+  const double y = (k.m1 * s.x1 + k.m2 * s.x2 + k.m3 * s.x3 + k.m4 * s.x4) - (k.d1 * s.y1 + k.d2 * s.y2 + k.d3 * s.y3 + k.d4 * s.y4);
+  s.x4 = s.x3; s.x3 = s.x2; s.x2 = s.x1; s.x1 = x;
+  s.y4 = s.y3; s.y3 = s.y2; s.y2 = s.y1; s.y1 = y;
+  return y;
+}
+
+// Lines along y (AXIS 1) or z (AXIS 2): thread = (x, other axis), strided walk.
+template <int AXIS>
+__global__ void __launch_bounds__(NT) k_rg_strided(const float* __restrict__ in, float* __restrict__ out, pp_dims d,
+                                                   size_t cstride, rg_coef k) {
+  in += (size_t)blockIdx.y * cstride;
+  out += (size_t)blockIdx.y * cstride;
+  const int nother = AXIS == 1 ? d.nz : d.ny;
+  const size_t nlines = (size_t)d.nx * nother;
+  const int len = AXIS == 1 ? d.ny : d.nz;
+  const size_t stride = AXIS == 1 ? (size_t)d.nx : (size_t)d.nx * d.ny;
+  for (size_t l = (size_t)blockIdx.x * NT + threadIdx.x; l < nlines; l += (size_t)gridDim.x * NT) {
+    const int x = (int)(l % d.nx);
+    const int o = (int)(l / d.nx);
+    const size_t base = AXIS == 1 ? (size_t)o * d.nx * d.ny + x : (size_t)o * d.nx + x;
+    rg_state s;
+    rg_init_causal(s, (double)in[base], k);
+    for (int i = 0; i < len; ++i) out[base + i * stride] = (float)rg_step_causal(s, (double)in[base + i * stride], k);
+    rg_init_anti(s, (double)in[base + (size_t)(len - 1) * stride], k);
+    for (int i = len - 1; i >= 0; --i) {
+      const size_t a = base + i * stride;
+      const double xi = (double)in[a];
+      const double y = rg_step_anti(s, xi, k);
+      out[a] = (float)((double)out[a] + y);
+    }
+  }
+}
+
+// Lines along x: a block owns 256 consecutive rows and walks them in 16-column chunks that are
+// transposed through LDS (pitch 17 keeps the per-row accesses conflict-free).
+constexpr int CW = 16;
+__global__ void __launch_bounds__(NT) k_rg_x(const float* __restrict__ in, float* __restrict__ out, pp_dims d,
+                                             size_t cstride, rg_coef k) {
+  __shared__ float tile[NT * (CW + 1)];
+  __shared__ float tcau[NT * (CW + 1)];
+  in += (size_t)blockIdx.y * cstride;
+  out += (size_t)blockIdx.y * cstride;
+  const size_t nrows = (size_t)d.ny * d.nz;
+  const int t = threadIdx.x;
+  const int lc = t % CW, lr = t / CW;  // loader coordinates: column lc, rows lr + 16 j
+  const int nchunks = (d.nx + CW - 1) / CW;
+  for (size_t r0 = (size_t)blockIdx.x * NT; r0 < nrows; r0 += (size_t)gridDim.x * NT) {
+    const size_t myrow = r0 + t;
+    const bool have = myrow < nrows;
+    rg_state s;
+    if (have) rg_init_causal(s, (double)in[myrow * d.nx], k);
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int c0 = ch * CW;
+      __syncthreads();
+      for (int j = 0; j < NT / (NT / CW); ++j) {
+        const int rr = lr + (NT / CW) * j;
+        const size_t row = r0 + rr;
+        if (row < nrows && c0 + lc < d.nx) tile[rr * (CW + 1) + lc] = in[row * d.nx + c0 + lc];
+      }
+      __syncthreads();
+      if (have) {
+        const int w = d.nx - c0 < CW ? d.nx - c0 : CW;
+        for (int c = 0; c < w; ++c) tile[t * (CW + 1) + c] = (float)rg_step_causal(s, (double)tile[t * (CW + 1) + c], k);
+      }
+      __syncthreads();
+      for (int j = 0; j < NT / (NT / CW); ++j) {
+        const int rr = lr + (NT / CW) * j;
+        const size_t row = r0 + rr;
+        if (row < nrows && c0 + lc < d.nx) out[row * d.nx + c0 + lc] = tile[rr * (CW + 1) + lc];
+      }
+    }
+    if (have) rg_init_anti(s, (double)in[myrow * d.nx + d.nx - 1], k);
+    for (int ch = nchunks - 1; ch >= 0; --ch) {
+      const int c0 = ch * CW;
+      __syncthreads();
+      for (int j = 0; j < NT / (NT / CW); ++j) {
+        const int rr = lr + (NT / CW) * j;
+        const size_t row = r0 + rr;
+        if (row < nrows && c0 + lc < d.nx) {
+          tile[rr * (CW + 1) + lc] = in[row * d.nx + c0 + lc];
+          tcau[rr * (CW + 1) + lc] = out[row * d.nx + c0 + lc];
+        }
+      }
+      __syncthreads();
+      if (have) {
+        const int w = d.nx - c0 < CW ? d.nx - c0 : CW;
+        for (int c = w - 1; c >= 0; --c) {
+          const double y = rg_step_anti(s, (double)tile[t * (CW + 1) + c], k);
+          tcau[t * (CW + 1) + c] = (float)((double)tcau[t * (CW + 1) + c] + y);
+        }
+      }
+      __syncthreads();
+      for (int j = 0; j < NT / (NT / CW); ++j) {
+        const int rr = lr + (NT / CW) * j;
+        const size_t row = r0 + rr;
+        if (row < nrows && c0 + lc < d.nx) out[row * d.nx + c0 + lc] = tcau[rr * (CW + 1) + lc];
+      }
+    }
+  }
+}
+
+unsigned grid_for(size_t work) {
+  size_t blocks = (work + NT - 1) / NT;
+  if (blocks > 65535u) blocks = 65535u;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+int rg_pass(pp_ctx* ctx, int axis, const float* in, float* out, const pp_dims& d, int ncomp, double sigma, double spacing) {
+  const int len = axis == 0 ? d.nx : (axis == 1 ? d.ny : d.nz);
+  if (len < 4) return pp_fail(ctx, PP_ERR_SIZE, "recursive Gaussian needs at least 4 voxels along axis %d (got %d)", axis, len);
+  if (!(sigma > 0.0)) return pp_fail(ctx, PP_ERR_ARG, "recursive Gaussian: sigma must be positive");
+  rg_coef k;
+  rg_setup(sigma, spacing, &k);
+  const size_t cstride = (size_t)d.nx * d.ny * d.nz;
+  if (axis == 0) {
+    hipLaunchKernelGGL(k_rg_x, dim3(grid_for((size_t)d.ny * d.nz), ncomp), dim3(NT), 0, ctx->stream, in, out, d, cstride, k);
+  } else if (axis == 1) {
+    hipLaunchKernelGGL((k_rg_strided<1>), dim3(grid_for((size_t)d.nx * d.nz), ncomp), dim3(NT), 0, ctx->stream, in, out, d, cstride, k);
+  } else {
+    hipLaunchKernelGGL((k_rg_strided<2>), dim3(grid_for((size_t)d.nx * d.ny), ncomp), dim3(NT), 0, ctx->stream, in, out, d, cstride, k);
+  }
+  PP_LAUNCH_CHECK(ctx, "k_rg");
+  return PP_OK;
+}
+
+// z -> x -> y, as SmoothingRecursiveGaussianImageFilter chains its directional filters.
+int rg_all(pp_ctx* ctx, const float* in, float* out, float* tmp1, float* tmp2, const pp_geom* g, int ncomp, const double sigma[3]) {
+  const pp_dims d{g->size[0], g->size[1], g->size[2]};
+  int rc = rg_pass(ctx, 2, in, tmp1, d, ncomp, sigma[2], g->spacing[2]);
+  if (rc) return rc;
+  rc = rg_pass(ctx, 0, tmp1, tmp2, d, ncomp, sigma[0], g->spacing[0]);
+  if (rc) return rc;
+  return rg_pass(ctx, 1, tmp2, out, d, ncomp, sigma[1], g->spacing[1]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pp_recursive_gaussian_field_f32(pp_ctx* ctx, float* field, const pp_geom* g, const double sigma[3]) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, field && sigma, "pp_recursive_gaussian_field_f32: NULL argument");
+  int rc = pp_geom_check(ctx, g, "grid");
+  if (rc) return rc;
+  const size_t N = pp_nvox(g->size);
+  rc = pp_reserve(ctx, 2 * pp_align_up(3 * N * sizeof(float), 256));
+  if (rc) return rc;
+  pp_carver cv{ctx->ws, 0};
+  float* t1 = cv.take<float>(3 * N);
+  float* t2 = cv.take<float>(3 * N);
+  return rg_all(ctx, field, field, t1, t2, g, 3, sigma);
+}
+
+int pp_recursive_gaussian_f32(pp_ctx* ctx, const float* in, float* out, const pp_geom* g, const double sigma[3]) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, in && out && sigma, "pp_recursive_gaussian_f32: NULL argument");
+  int rc = pp_geom_check(ctx, g, "grid");
+  if (rc) return rc;
+  const size_t N = pp_nvox(g->size);
+  rc = pp_reserve(ctx, 2 * pp_align_up(N * sizeof(float), 256));
+  if (rc) return rc;
+  pp_carver cv{ctx->ws, 0};
+  float* t1 = cv.take<float>(N);
+  float* t2 = cv.take<float>(N);
+  return rg_all(ctx, in, out, t1, t2, g, 1, sigma);
+}
+
+}  // extern "C"

@@ -1,0 +1,178 @@
+// platipy_amd/csrc/pp_internal.h -- shared host/device helpers of libplatipy_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/platipy_amd.h"
+
+// ---------------------------------------------------------------------------------------
+// context
+
+struct pp_ctx {
+  int device;
+  hipStream_t stream;
+  char* ws;          // device scratch, grown on demand
+  size_t ws_bytes;
+  char err[512];
+};
+
+int pp_fail(pp_ctx* ctx, int code, const char* fmt, ...);
+// Reserve `bytes` of device scratch (256-B aligned slices are carved by the callers).
+int pp_reserve(pp_ctx* ctx, size_t bytes);
+
+#define PP_HIP(ctx, call)                                                              \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return pp_fail((ctx), PP_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+#define PP_LAUNCH_CHECK(ctx, name)                                                        \
+  do {                                                                                    \
+    hipError_t e_ = hipGetLastError();                                                    \
+    if (e_ != hipSuccess)                                                                 \
+      return pp_fail((ctx), PP_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+#define PP_REQUIRE(ctx, cond, msg)                            \
+  do {                                                        \
+    if (!(cond)) return pp_fail((ctx), PP_ERR_ARG, "%s", msg); \
+  } while (0)
+
+static inline size_t pp_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline size_t pp_nvox(const int size[3]) { return (size_t)size[0] * size[1] * size[2]; }
+
+// Scratch carving: a bump pointer over ctx->ws (valid after pp_reserve of the total).
+struct pp_carver {
+  char* base;
+  size_t off;
+  template <typename T>
+  T* take(size_t count) {
+    T* p = reinterpret_cast<T*>(base + off);
+    off = pp_align_up(off + count * sizeof(T), 256);
+    return p;
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// geometry shared with kernels (all index-space; computed on the host in fp64)
+
+struct pp_dims {
+  int nx, ny, nz;
+};
+
+// out index -> input continuous index:  c = A * idx + b  (+ Md * D(idx) when a field is given)
+struct pp_index_map {
+  double A[9];
+  double b[3];
+  double Md[9];  // physical displacement (mm) -> input index units
+};
+
+int pp_geom_check(pp_ctx* ctx, const pp_geom* g, const char* what);
+bool pp_geom_same_grid(const pp_geom* a, const pp_geom* b);
+bool pp_geom_identity_dir(const pp_geom* g);
+// c_in = P2I_in * (X(I2P_out * idx + origin_out) - origin_in) with X(p) = A p + t
+void pp_make_index_map(const pp_geom* gin, const pp_geom* gout, const double* affine_A,
+                       const double* affine_t, pp_index_map* m);
+
+// Gaussian operator taps as floats for a kernel (host side); returns radius or < 0.
+#define PP_MAX_RADIUS 127
+struct pp_taps {
+  int r;
+  float w[2 * PP_MAX_RADIUS + 1];
+};
+int pp_make_taps(pp_ctx* ctx, double variance, double max_error, int max_kernel_width, pp_taps* t);
+
+// Small-radius taps passed by value to the fused kernels.
+#define PP_FUSED_MAX_R 3
+struct pp_taps_small {
+  float w[2 * PP_FUSED_MAX_R + 1];
+};
+
+// ---------------------------------------------------------------------------------------
+// device helpers
+
+__device__ __forceinline__ int pp_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Continuous index = base + frac with integer base and frac in [0,1): the inside-buffer test
+// of itk::ImageFunction::IsInsideBuffer, [-0.5, n-0.5), done exactly on (base, frac).
+__device__ __forceinline__ bool pp_inside1(int b, float f, int n) {
+  return (b >= 0 || (b == -1 && f >= 0.5f)) && (b <= n - 2 || (b == n - 1 && f < 0.5f));
+}
+
+// One axis of itk::LinearInterpolateImageFunction's clamped lerp: given (base, frac) inside
+// the buffer, the two sample indices and the weight (0 where ITK skips the axis).
+__device__ __forceinline__ void pp_axis_setup(int b, float f, int n, int& i0, int& i1, float& w) {
+  i0 = b < 0 ? 0 : b;
+  i1 = i0 + 1 > n - 1 ? n - 1 : i0 + 1;
+  w = b < 0 ? 0.0f : f;
+}
+
+// Trilinear sample of a scalar volume at (bx+fx, by+fy, bz+fz), already known inside.
+// Lerps nest x, y, z in the form a + (b - a) * w, as the reference interpolator does.
+template <typename T>
+__device__ __forceinline__ float pp_trilinear(const T* __restrict__ im, int nx, int ny, int nz, int bx,
+                                              float fx, int by, float fy, int bz, float fz) {
+  int x0, x1, y0, y1, z0, z1;
+  float wx, wy, wz;
+  pp_axis_setup(bx, fx, nx, x0, x1, wx);
+  pp_axis_setup(by, fy, ny, y0, y1, wy);
+  pp_axis_setup(bz, fz, nz, z0, z1, wz);
+  const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+  const T* p00 = im + z0 * sz + y0 * sy;
+  const T* p10 = im + z0 * sz + y1 * sy;
+  const T* p01 = im + z1 * sz + y0 * sy;
+  const T* p11 = im + z1 * sz + y1 * sy;
+  const float a000 = (float)p00[x0], a100 = (float)p00[x1];
+  const float a010 = (float)p10[x0], a110 = (float)p10[x1];
+  const float a001 = (float)p01[x0], a101 = (float)p01[x1];
+  const float a011 = (float)p11[x0], a111 = (float)p11[x1];
+  const float v00 = a000 + (a100 - a000) * wx;
+  const float v10 = a010 + (a110 - a010) * wx;
+  const float v01 = a001 + (a101 - a001) * wx;
+  const float v11 = a011 + (a111 - a011) * wx;
+  const float v0 = v00 + (v10 - v00) * wy;
+  const float v1 = v01 + (v11 - v01) * wy;
+  return v0 + (v1 - v0) * wz;
+}
+
+// Split idx + dv (dv = displacement in voxels) into integer base and fraction without the
+// precision loss of forming the sum in fp32.
+__device__ __forceinline__ void pp_split(int idx, float dv, int& b, float& f) {
+  if (!(fabsf(dv) < 1.0e6f)) {  // absurd or NaN displacement: force "outside the buffer"
+    b = -0x40000000;
+    f = 0.0f;
+    return;
+  }
+  const float fl = floorf(dv);
+  b = idx + (int)fl;
+  f = dv - fl;
+}
+
+// Block-wide sum of three doubles (deterministic tree); result valid on thread 0.
+template <int NT>
+__device__ __forceinline__ void pp_block_sum3(double& a, double& b, double& c, double* sm /* 3*NT */) {
+  const int t = threadIdx.x;
+  sm[t] = a;
+  sm[NT + t] = b;
+  sm[2 * NT + t] = c;
+  __syncthreads();
+  for (int s = NT / 2; s > 0; s >>= 1) {
+    if (t < s) {
+      sm[t] += sm[t + s];
+      sm[NT + t] += sm[NT + t + s];
+      sm[2 * NT + t] += sm[2 * NT + t + s];
+    }
+    __syncthreads();
+  }
+  a = sm[0];
+  b = sm[NT];
+  c = sm[2 * NT];
+}

@@ -1,0 +1,334 @@
+// platipy_amd/csrc/pp_resample.hip -- trilinear / nearest-neighbour gathers.
+//
+// Replaces itk::WarpImageFilter inside the demons loop, sitk.Resample / ResampleImageFilter
+// (reference: registration/utils.py:176-190, :257-267; registration/deformable.py:130,137,140,
+// 154,185,281-301) and itk::DisplacementFieldTransform.  All kernels are HBM/L2-bound gathers:
+// lanes run along x so the displacement planes, the output and -- for smooth fields -- the
+// eight gathered neighbours are row-coalesced; one thread handles 4 consecutive voxels.
+//
+// Two coordinate paths:
+//  * same-grid (hot loop, compose): continuous index = idx + D / spacing, formed as an integer
+//    base plus an fp32 fraction so no precision is lost to the magnitude of idx;
+//  * general (pyramids, linear transforms, propagation of masks): the ITK sequence
+//    index -> physical -> transform -> physical -> continuous index, evaluated in fp64 with
+//    contraction off, so nearest-neighbour decisions match the fp64 restatement bit for bit.
+#include "pp_internal.h"
+#include "pp_kernels.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---------------------------------------------------------------------------------------
+// same-grid warp
+
+template <int VEC>
+__global__ void __launch_bounds__(NT) k_warp_same_grid(const float* __restrict__ moving, const float* __restrict__ field,
+                                                       float* __restrict__ out, pp_dims d, pp_warp_scale sc, float edge,
+                                                       const int* __restrict__ halt) {
+  if (halt && *halt) return;
+  const int nxv = d.nx / VEC;
+  const size_t N = (size_t)d.nx * d.ny * d.nz;
+  const size_t total = N / VEC;
+  for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
+    const int x0 = (int)(e % nxv) * VEC;
+    const int y = (int)((e / nxv) % d.ny);
+    const int z = (int)(e / ((size_t)nxv * d.ny));
+    const size_t i = ((size_t)z * d.ny + y) * d.nx + x0;
+    float dx[VEC], dy[VEC], dz[VEC], res[VEC];
+    if (VEC == 4) {
+      const float4 a = *reinterpret_cast<const float4*>(field + i);
+      const float4 b = *reinterpret_cast<const float4*>(field + N + i);
+      const float4 c = *reinterpret_cast<const float4*>(field + 2 * N + i);
+      dx[0] = a.x; dx[1] = a.y; dx[2] = a.z; dx[3] = a.w;
+      dy[0] = b.x; dy[1] = b.y; dy[2] = b.z; dy[3] = b.w;
+      dz[0] = c.x; dz[1] = c.y; dz[2] = c.z; dz[3] = c.w;
+    } else {
+      dx[0] = field[i];
+      dy[0] = field[N + i];
+      dz[0] = field[2 * N + i];
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      int bx, by, bz;
+      float fx, fy, fz;
+      pp_split(x0 + v, dx[v] * sc.ix, bx, fx);
+      pp_split(y, dy[v] * sc.iy, by, fy);
+      pp_split(z, dz[v] * sc.iz, bz, fz);
+      const bool inside = pp_inside1(bx, fx, d.nx) && pp_inside1(by, fy, d.ny) && pp_inside1(bz, fz, d.nz);
+      res[v] = inside ? pp_trilinear(moving, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz) : edge;
+    }
+    if (VEC == 4)
+      *reinterpret_cast<float4*>(out + i) = make_float4(res[0], res[1], res[2], res[3]);
+    else
+      out[i] = res[0];
+  }
+}
+
+// total(x) += iter(x + total(x)), zero outside (deformable.py:154).  In place on `total`:
+// every thread reads only its own voxel of `total`.
+__global__ void __launch_bounds__(NT) k_compose_same_grid(float* __restrict__ total, const float* __restrict__ iter,
+                                                          pp_dims d, pp_warp_scale sc) {
+  const size_t N = (size_t)d.nx * d.ny * d.nz;
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < N; i += (size_t)gridDim.x * NT) {
+    const int x = (int)(i % d.nx);
+    const int y = (int)((i / d.nx) % d.ny);
+    const int z = (int)(i / ((size_t)d.nx * d.ny));
+    const float tx = total[i], ty = total[N + i], tz = total[2 * N + i];
+    int bx, by, bz;
+    float fx, fy, fz;
+    pp_split(x, tx * sc.ix, bx, fx);
+    pp_split(y, ty * sc.iy, by, fy);
+    pp_split(z, tz * sc.iz, bz, fz);
+    if (pp_inside1(bx, fx, d.nx) && pp_inside1(by, fy, d.ny) && pp_inside1(bz, fz, d.nz)) {
+      total[i] = tx + pp_trilinear(iter, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz);
+      total[N + i] = ty + pp_trilinear(iter + N, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz);
+      total[2 * N + i] = tz + pp_trilinear(iter + 2 * N, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// general resample, fp64 coordinates
+
+struct pp_xform {
+  double i2p_out[9], o_out[3];
+  double A[9], t[3];
+  double p2i_in[9], o_in[3];
+  int has_affine;
+};
+
+// itk::ImageBase::TransformIndexToPhysicalPoint -> MatrixOffsetTransformBase::TransformPoint ->
+// DisplacementFieldTransform::TransformPoint -> TransformPhysicalPointToContinuousIndex, with
+// each sum in the order ITK writes it.
+__device__ __forceinline__ void pp_map_point(const pp_xform& X, int x, int y, int z, double ddx, double ddy, double ddz,
+                                             double c[3]) {
+#pragma clang fp contract(off)
+  const double ix = (double)x, iy = (double)y, iz = (double)z;
+  double p[3], q[3], v[3];
+  for (int r = 0; r < 3; ++r) {
+    double s = 0.0;
+    s += X.i2p_out[r * 3 + 0] * ix;
+    s += X.i2p_out[r * 3 + 1] * iy;
+    s += X.i2p_out[r * 3 + 2] * iz;
+    p[r] = s + X.o_out[r];
+  }
+  if (X.has_affine) {
+    for (int r = 0; r < 3; ++r) {
+      double s = X.A[r * 3 + 0] * p[0] + X.A[r * 3 + 1] * p[1];
+      s = s + X.A[r * 3 + 2] * p[2];
+      q[r] = s + X.t[r];
+    }
+  } else {
+    q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+  }
+  q[0] += ddx;
+  q[1] += ddy;
+  q[2] += ddz;
+  for (int r = 0; r < 3; ++r) v[r] = q[r] - X.o_in[r];
+  for (int r = 0; r < 3; ++r) {
+    double s = X.p2i_in[r * 3 + 0] * v[0] + X.p2i_in[r * 3 + 1] * v[1];
+    c[r] = s + X.p2i_in[r * 3 + 2] * v[2];
+  }
+}
+
+__device__ __forceinline__ bool pp_inside_d(const double c[3], const pp_dims& n) {
+  return (c[0] >= -0.5 && c[0] < (double)n.nx - 0.5) && (c[1] >= -0.5 && c[1] < (double)n.ny - 0.5) &&
+         (c[2] >= -0.5 && c[2] < (double)n.nz - 0.5);
+}
+
+template <typename T>
+__device__ __forceinline__ T pp_cast_out(float v);
+template <>
+__device__ __forceinline__ float pp_cast_out<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ uint8_t pp_cast_out<uint8_t>(float v) {
+  return v < 0.0f ? (uint8_t)0 : (v > 255.0f ? (uint8_t)255 : (uint8_t)v);  // clamp, then truncate
+}
+
+template <typename T, int INTERP, bool HASFIELD>
+__global__ void __launch_bounds__(NT) k_resample(const T* __restrict__ in, pp_dims din, const float* __restrict__ field,
+                                                 T* __restrict__ out, pp_dims dout, pp_xform X, T default_value) {
+  const size_t N = (size_t)dout.nx * dout.ny * dout.nz;
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < N; i += (size_t)gridDim.x * NT) {
+    const int x = (int)(i % dout.nx);
+    const int y = (int)((i / dout.nx) % dout.ny);
+    const int z = (int)(i / ((size_t)dout.nx * dout.ny));
+    double ddx = 0.0, ddy = 0.0, ddz = 0.0;
+    if (HASFIELD) {
+      ddx = (double)field[i];
+      ddy = (double)field[N + i];
+      ddz = (double)field[2 * N + i];
+    }
+    double c[3];
+    pp_map_point(X, x, y, z, ddx, ddy, ddz, c);
+    T res = default_value;
+    if (pp_inside_d(c, din)) {
+      if (INTERP == PP_INTERP_NEAREST) {
+        const int qx = (int)floor(c[0] + 0.5), qy = (int)floor(c[1] + 0.5), qz = (int)floor(c[2] + 0.5);
+        res = in[((size_t)qz * din.ny + qy) * din.nx + qx];
+      } else {
+        const double flx = floor(c[0]), fly = floor(c[1]), flz = floor(c[2]);
+        res = pp_cast_out<T>(pp_trilinear(in, din.nx, din.ny, din.nz, (int)flx, (float)(c[0] - flx), (int)fly,
+                                          (float)(c[1] - fly), (int)flz, (float)(c[2] - flz)));
+      }
+    }
+    out[i] = res;
+  }
+}
+
+// sitk.Resample of the planar vector field onto another grid: identity transform, linear, 0.
+__global__ void __launch_bounds__(NT) k_resample_field(const float* __restrict__ in, pp_dims din, float* __restrict__ out,
+                                                       pp_dims dout, pp_xform X) {
+  const size_t N = (size_t)dout.nx * dout.ny * dout.nz;
+  const size_t Ni = (size_t)din.nx * din.ny * din.nz;
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < N; i += (size_t)gridDim.x * NT) {
+    const int x = (int)(i % dout.nx);
+    const int y = (int)((i / dout.nx) % dout.ny);
+    const int z = (int)(i / ((size_t)dout.nx * dout.ny));
+    double c[3];
+    pp_map_point(X, x, y, z, 0.0, 0.0, 0.0, c);
+    float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+    if (pp_inside_d(c, din)) {
+      const double flx = floor(c[0]), fly = floor(c[1]), flz = floor(c[2]);
+      const int bx = (int)flx, by = (int)fly, bz = (int)flz;
+      const float fx = (float)(c[0] - flx), fy = (float)(c[1] - fly), fz = (float)(c[2] - flz);
+      r0 = pp_trilinear(in, din.nx, din.ny, din.nz, bx, fx, by, fy, bz, fz);
+      r1 = pp_trilinear(in + Ni, din.nx, din.ny, din.nz, bx, fx, by, fy, bz, fz);
+      r2 = pp_trilinear(in + 2 * Ni, din.nx, din.ny, din.nz, bx, fx, by, fy, bz, fz);
+    }
+    out[i] = r0;
+    out[N + i] = r1;
+    out[2 * N + i] = r2;
+  }
+}
+
+unsigned grid_for(size_t work) {
+  size_t blocks = (work + NT - 1) / NT;
+  if (blocks > 65535u * 8u) blocks = 65535u * 8u;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+void fill_xform(const pp_geom* gin, const pp_geom* gout, const double* A, const double* t, pp_xform* X) {
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) X->i2p_out[r * 3 + c] = gout->direction[r * 3 + c] * gout->spacing[c];
+  pp_index_map m;
+  pp_make_index_map(gin, gout, nullptr, nullptr, &m);
+  memcpy(X->p2i_in, m.Md, sizeof(m.Md));
+  for (int k = 0; k < 3; ++k) {
+    X->o_out[k] = gout->origin[k];
+    X->o_in[k] = gin->origin[k];
+  }
+  X->has_affine = (A != nullptr);
+  static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  memcpy(X->A, A ? A : I3, sizeof(X->A));
+  for (int k = 0; k < 3; ++k) X->t[k] = (A && t) ? t[k] : 0.0;
+}
+
+template <typename T>
+int resample_any(pp_ctx* ctx, const T* in, const pp_geom* gin, const pp_geom* gout, const double* A, const double* t,
+                 const float* field, int interp, double default_value, T* out, const char* name) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, in && out, "resample: NULL volume");
+  PP_REQUIRE(ctx, (const void*)in != (const void*)out, "resample: in-place is not supported");
+  int rc = pp_geom_check(ctx, gin, "input");
+  if (rc) return rc;
+  rc = pp_geom_check(ctx, gout, "output");
+  if (rc) return rc;
+  PP_REQUIRE(ctx, interp == PP_INTERP_NEAREST || interp == PP_INTERP_LINEAR, "resample: interpolator must be nearest or linear");
+  pp_xform X;
+  fill_xform(gin, gout, A, t, &X);
+  const pp_dims din{gin->size[0], gin->size[1], gin->size[2]};
+  const pp_dims dout{gout->size[0], gout->size[1], gout->size[2]};
+  const dim3 grid(grid_for(pp_nvox(gout->size))), block(NT);
+  T dv;
+  if (sizeof(T) == 1) {
+    const double c = default_value < 0.0 ? 0.0 : (default_value > 255.0 ? 255.0 : default_value);
+    dv = (T)c;
+  } else {
+    dv = (T)default_value;
+  }
+#define PP_RS(I, F) hipLaunchKernelGGL((k_resample<T, I, F>), grid, block, 0, ctx->stream, in, din, field, out, dout, X, dv)
+  if (interp == PP_INTERP_NEAREST) {
+    if (field) PP_RS(PP_INTERP_NEAREST, true); else PP_RS(PP_INTERP_NEAREST, false);
+  } else {
+    if (field) PP_RS(PP_INTERP_LINEAR, true); else PP_RS(PP_INTERP_LINEAR, false);
+  }
+#undef PP_RS
+  PP_LAUNCH_CHECK(ctx, name);
+  return PP_OK;
+}
+
+}  // namespace
+
+int pp_warp_same_grid(pp_ctx* ctx, const float* moving, const float* field, const pp_dims& d, const pp_warp_scale& sc,
+                      float edge_value, float* out, const int* halt_flag) {
+  const size_t N = (size_t)d.nx * d.ny * d.nz;
+  const bool vec4 = (d.nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(field) | reinterpret_cast<uintptr_t>(out)) % 16 == 0) && (N % 4 == 0);
+  const dim3 block(NT);
+  if (vec4)
+    hipLaunchKernelGGL((k_warp_same_grid<4>), dim3(grid_for(N / 4)), block, 0, ctx->stream, moving, field, out, d, sc,
+                       edge_value, halt_flag);
+  else
+    hipLaunchKernelGGL((k_warp_same_grid<1>), dim3(grid_for(N)), block, 0, ctx->stream, moving, field, out, d, sc,
+                       edge_value, halt_flag);
+  PP_LAUNCH_CHECK(ctx, "k_warp_same_grid");
+  return PP_OK;
+}
+
+extern "C" {
+
+int pp_warp_f32(pp_ctx* ctx, const float* moving, const float* field, const pp_geom* g, float edge_value, float* out) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, moving && field && out, "pp_warp_f32: NULL volume");
+  PP_REQUIRE(ctx, moving != out, "pp_warp_f32: in-place is not supported");
+  int rc = pp_geom_check(ctx, g, "grid");
+  if (rc) return rc;
+  if (!pp_geom_identity_dir(g))
+    return pp_fail(ctx, PP_ERR_UNSUPPORTED, "pp_warp_f32: identity direction only; use pp_resample_f32");
+  const pp_dims d{g->size[0], g->size[1], g->size[2]};
+  const pp_warp_scale sc{(float)(1.0 / g->spacing[0]), (float)(1.0 / g->spacing[1]), (float)(1.0 / g->spacing[2])};
+  return pp_warp_same_grid(ctx, moving, field, d, sc, edge_value, out, nullptr);
+}
+
+int pp_resample_f32(pp_ctx* ctx, const float* in, const pp_geom* gin, const pp_geom* gout, const double* affine_A,
+                    const double* affine_t, const float* field, int interp, double default_value, float* out) {
+  return resample_any<float>(ctx, in, gin, gout, affine_A, affine_t, field, interp, default_value, out, "k_resample<f32>");
+}
+
+int pp_resample_u8(pp_ctx* ctx, const uint8_t* in, const pp_geom* gin, const pp_geom* gout, const double* affine_A,
+                   const double* affine_t, const float* field, int interp, double default_value, uint8_t* out) {
+  return resample_any<uint8_t>(ctx, in, gin, gout, affine_A, affine_t, field, interp, default_value, out, "k_resample<u8>");
+}
+
+int pp_resample_field_f32(pp_ctx* ctx, const float* in, const pp_geom* gin, const pp_geom* gout, float* out) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, in && out && in != out, "pp_resample_field_f32: NULL or aliased field");
+  int rc = pp_geom_check(ctx, gin, "input");
+  if (rc) return rc;
+  rc = pp_geom_check(ctx, gout, "output");
+  if (rc) return rc;
+  pp_xform X;
+  fill_xform(gin, gout, nullptr, nullptr, &X);
+  const pp_dims din{gin->size[0], gin->size[1], gin->size[2]};
+  const pp_dims dout{gout->size[0], gout->size[1], gout->size[2]};
+  hipLaunchKernelGGL(k_resample_field, dim3(grid_for(pp_nvox(gout->size))), dim3(NT), 0, ctx->stream, in, din, out, dout, X);
+  PP_LAUNCH_CHECK(ctx, "k_resample_field");
+  return PP_OK;
+}
+
+int pp_compose_field_f32(pp_ctx* ctx, float* total, const float* iter, const pp_geom* g) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, total && iter && total != iter, "pp_compose_field_f32: NULL or aliased field");
+  int rc = pp_geom_check(ctx, g, "grid");
+  if (rc) return rc;
+  if (!pp_geom_identity_dir(g)) return pp_fail(ctx, PP_ERR_UNSUPPORTED, "pp_compose_field_f32: identity direction only");
+  const pp_dims d{g->size[0], g->size[1], g->size[2]};
+  const pp_warp_scale sc{(float)(1.0 / g->spacing[0]), (float)(1.0 / g->spacing[1]), (float)(1.0 / g->spacing[2])};
+  hipLaunchKernelGGL(k_compose_same_grid, dim3(grid_for(pp_nvox(g->size))), dim3(NT), 0, ctx->stream, total, iter, d, sc);
+  PP_LAUNCH_CHECK(ctx, "k_compose_same_grid");
+  return PP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: longer CPU test")
+
+
+@pytest.fixture(scope="session")
+def emu_backend():
+    from tests.helpers import EmuBackend
+
+    return EmuBackend()
+
+
+@pytest.fixture(scope="session")
+def gpu_backend():
+    from tests.helpers import GpuBackend
+
+    return GpuBackend()
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def backend(request):
+    """The HIP kernels behind the C ABI: on the GPU (real library, -m gpu) or -- CPU suite only --
+    the same sources compiled against the test-only HIP stand-in (tests/emu)."""
+    if request.param == "emu":
+        return request.getfixturevalue("emu_backend")
+    return request.getfixturevalue("gpu_backend")

@@ -1,0 +1,115 @@
+// tests/emu/include/hip/hip_runtime.h
+//
+// TEST INFRASTRUCTURE ONLY.  A CPU stand-in for the small part of the HIP runtime that
+// platipy_amd/csrc uses, so the *unmodified* kernel sources can be compiled with g++ and
+// their indexing / LDS / barrier logic checked against the oracle in the CPU test suite
+// (there is no GPU in the build container).  Each thread block runs as blockDim real
+// threads with a pthread barrier for __syncthreads(); blocks run one after another.
+// It is never on the product's include path and nothing under platipy_amd/ refers to it.
+#pragma once
+
+#include <pthread.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __constant__ static
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+struct float2 { float x, y; };
+struct float3 { float x, y, z; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct uchar4 { unsigned char x, y, z, w; };
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+static inline float2 make_float2(float a, float b) { return float2{a, b}; }
+static inline uchar4 make_uchar4(unsigned char a, unsigned char b, unsigned char c, unsigned char d) {
+  return uchar4{a, b, c, d};
+}
+
+namespace hipemu {
+extern thread_local dim3 t_threadIdx, t_blockIdx;
+extern dim3 g_blockDim, g_gridDim;
+extern pthread_barrier_t* g_barrier;
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+}  // namespace hipemu
+
+#define threadIdx (::hipemu::t_threadIdx)
+#define blockIdx (::hipemu::t_blockIdx)
+#define blockDim (::hipemu::g_blockDim)
+#define gridDim (::hipemu::g_gridDim)
+
+static inline void __syncthreads() { pthread_barrier_wait(::hipemu::g_barrier); }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  ::hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+
+// ---- runtime API subset ------------------------------------------------------------
+typedef int hipError_t;
+typedef void* hipStream_t;
+struct hipemuEvent { std::chrono::steady_clock::time_point t; };
+typedef hipemuEvent* hipEvent_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+static inline hipError_t hipMalloc(void** p, size_t n) {
+  *p = nullptr;
+  if (posix_memalign(p, 256, n ? n : 256)) return hipErrorOutOfMemory;
+  return hipSuccess;
+}
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemuEvent; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+  return hipSuccess;
+}
+
+// ---- device intrinsics subset ------------------------------------------------------
+static inline float atomicAdd(float* p, float v) {
+  float o, n;
+  do { o = *p; n = o + v; } while (!__atomic_compare_exchange(p, &o, &n, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST));
+  return o;
+}
+static inline double atomicAdd(double* p, double v) {
+  double o, n;
+  do { o = *p; n = o + v; } while (!__atomic_compare_exchange(p, &o, &n, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST));
+  return o;
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline int __float2int_rd(float x) { return (int)floorf(x); }
+static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
+static inline float __fdividef(float a, float b) { return a / b; }

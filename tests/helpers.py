@@ -1,0 +1,108 @@
+"""Shared test plumbing: two ways to reach the kernels behind the C ABI, and synthetic volumes."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from platipy_amd import _lib  # noqa: E402
+
+
+class EmuBackend:
+    """TEST ONLY: the kernel sources compiled for the CPU (tests/emu); buffers are numpy arrays."""
+
+    name = "emu"
+
+    def __init__(self):
+        from tests.emu.build_emu import build
+
+        self.lib = _lib.load(build())
+        self.ctx = _lib.Context(0, 0, lib=self.lib)
+
+    def dev(self, a):
+        return np.ascontiguousarray(a).copy()
+
+    def host(self, h):
+        return np.asarray(h)
+
+    def empty(self, shape, dtype=np.float32):
+        return np.zeros(shape, dtype=dtype)
+
+
+class GpuBackend:
+    """The real libplatipy_hip.so on cuda:0; buffers are torch tensors."""
+
+    name = "gpu"
+
+    def __init__(self):
+        import torch
+
+        assert torch.cuda.is_available(), "GPU tests need a GPU"
+        self.torch = torch
+        self.lib = _lib.dll()
+        self.ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream, lib=self.lib)
+
+    def dev(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def host(self, h):
+        self.ctx.sync()
+        return h.cpu().numpy()
+
+    def empty(self, shape, dtype=np.float32):
+        tdt = {np.float32: self.torch.float32, np.uint8: self.torch.uint8}[dtype]
+        return self.torch.zeros(tuple(shape), dtype=tdt, device="cuda")
+
+
+# --------------------------------------------------------------------------------------
+# synthetic data (SURVEY 8d recipe, scaled down)
+
+
+def smooth_noise(shape, seed, cells=6):
+    """Smooth random scalar field: coarse N(0,1) noise, trilinearly up-sampled."""
+    from scipy.ndimage import zoom
+
+    rng = np.random.default_rng(seed)
+    coarse = rng.normal(size=(cells, cells, cells))
+    z = [s / cells for s in shape]
+    out = zoom(coarse, z, order=1, mode="nearest", grid_mode=False)
+    out = out[: shape[0], : shape[1], : shape[2]]
+    pad = [(0, shape[i] - out.shape[i]) for i in range(3)]
+    return np.pad(out, pad, mode="edge")
+
+
+def phantom(shape, seed=1234, n_blobs=8, noise=5.0):
+    """CT-like volume: -1000 background, 0 HU ellipsoid body, ellipsoidal organs, blur, noise."""
+    from scipy.ndimage import gaussian_filter
+
+    rng = np.random.default_rng(seed)
+    nz, ny, nx = shape
+    zz, yy, xx = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    vol = np.full(shape, -1000.0)
+    body = ((xx - nx / 2) / (0.42 * nx)) ** 2 + ((yy - ny / 2) / (0.40 * ny)) ** 2 + ((zz - nz / 2) / (0.46 * nz)) ** 2 < 1
+    vol[body] = 0.0
+    for _ in range(n_blobs):
+        c = [rng.uniform(0.25, 0.75) * s for s in (nx, ny, nz)]
+        r = [rng.uniform(0.06, 0.2) * s for s in (nx, ny, nz)]
+        val = rng.uniform(-200, 400)
+        m = ((xx - c[0]) / r[0]) ** 2 + ((yy - c[1]) / r[1]) ** 2 + ((zz - c[2]) / r[2]) ** 2 < 1
+        vol[m & body] = val
+    vol = gaussian_filter(vol, 1.5)
+    if noise:
+        vol = vol + np.random.default_rng(seed + 1).normal(0, noise, size=shape)
+    return vol.astype(np.float32)
+
+
+def random_dvf(shape, spacing, seed, max_mm=4.0, cells=5):
+    f = np.stack([smooth_noise(shape, seed + c, cells) for c in range(3)])
+    f *= max_mm / np.sqrt((f ** 2).sum(0)).max()
+    return f.astype(np.float32)
+
+
+def dice(a, b):
+    a = a > 0
+    b = b > 0
+    return 2.0 * (a & b).sum() / max(1, a.sum() + b.sum())

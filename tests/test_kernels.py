@@ -1,0 +1,354 @@
+"""Parity of every C-ABI operation against the oracle (CPU restatement of the ITK filters).
+
+Each test runs twice: `emu` (CPU suite: the unmodified kernel sources compiled against the
+test-only HIP stand-in, so indexing / LDS / barrier logic is exercised without a GPU) and `gpu`
+(-m gpu: the real libplatipy_hip.so on cuda:0).  Integer / mask results must be bit-exact;
+fp32 results carry the tolerance written next to the assertion (the oracle keeps the reference's
+fp64 field, the product stores fp32).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from platipy_amd import _lib
+from tests.helpers import phantom, random_dvf, smooth_noise
+
+FLT_MAX = float(np.finfo(np.float32).max)
+
+# (nz, ny, nx), spacing(x,y,z), origin
+GRIDS = [
+    ((13, 22, 45), (0.9, 1.1, 2.5), (320.0, -52.0, 60.0)),   # nx % 4 != 0, one tile in x
+    ((12, 20, 72), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)),        # nx % 4 == 0, two tiles in x and y
+]
+
+
+def geom_of(shape, spacing, origin):
+    return _lib.make_geom((shape[2], shape[1], shape[0]), spacing, origin)
+
+
+def size_of(shape):
+    return (shape[2], shape[1], shape[0])
+
+
+def test_gauss_taps_match_oracle_and_kats():
+    lib = _lib.load(__import__("tests.emu.build_emu", fromlist=["build"]).build())
+    # build-derived known answers: centre -> edge
+    kats = {
+        (1.0, 0.1): [0.4745589, 0.2118383, 0.0508822],
+        (2.25, 0.1): [0.3161258, 0.2323020, 0.1096351],
+        (0.36, 0.1): [0.7383936, 0.1308032],
+        (1.0, 0.01): [0.4668012, 0.2083754, 0.0500505, 0.0081735],
+        (4.0, 0.01): [0.2085927, 0.1801245, 0.1185304, 0.0615941, 0.0261393, 0.0093154],
+    }
+    for (var, err), want in kats.items():
+        got = np.array(_lib.gauss_taps(var, err, 32, lib=lib))
+        r = (len(got) - 1) // 2
+        assert r == len(want) - 1
+        np.testing.assert_allclose(got[r:], want, atol=5e-8)
+        np.testing.assert_array_equal(got, O.gaussian_operator(var, err, 32))  # same recipe -> same doubles
+    # width cap: the half kernel may hold max_width + 1 coefficients
+    got = _lib.gauss_taps(100.0, 0.001, 5, lib=lib)
+    assert len(got) == 2 * 5 + 1
+    np.testing.assert_array_equal(np.array(got), O.gaussian_operator(100.0, 0.001, 5))
+
+
+@pytest.mark.parametrize("grid", GRIDS)
+def test_discrete_gaussian(backend, grid):
+    shape, spacing, origin = grid
+    img = phantom(shape, seed=3)
+    for var, mkw in [((4.0, 4.0, 4.0), 32), ((1.0, 2.0, 9.0), 8)]:
+        want = O.discrete_gaussian(O.Vol(img, spacing, origin), var, mkw).arr
+        src = backend.dev(img)
+        dst = backend.empty(shape)
+        backend.ctx.discrete_gaussian(src, dst, size_of(shape), spacing, var, 0.01, mkw, True)
+        got = backend.host(dst)
+        # fp32 accumulation of <= 65 taps of |v| <= 1000: a few ulp of 1000
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-3)
+
+
+@pytest.mark.parametrize("grid", GRIDS)
+def test_smooth_field(backend, grid):
+    shape, spacing, _ = grid
+    f = random_dvf(shape, spacing, seed=5)
+    sig = [1.5 / s for s in spacing]
+    want = O.smooth_field(f.astype(np.float64), sig)
+    d = backend.dev(f)
+    backend.ctx.smooth_field(d, size_of(shape), sig, 0.1, 30)
+    np.testing.assert_allclose(backend.host(d), want, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("grid", GRIDS)
+def test_warp_same_grid(backend, grid):
+    shape, spacing, origin = grid
+    mov = phantom(shape, seed=7)
+    f = random_dvf(shape, spacing, seed=11, max_mm=6.0)
+    f[:, :2, :, :] *= 8.0  # push some voxels out of the buffer
+    g = geom_of(shape, spacing, origin)
+    want = O.warp_image(O.Vol(mov, spacing, origin), f.astype(np.float64), edge_value=FLT_MAX).arr
+    out = backend.empty(shape)
+    backend.ctx.warp(backend.dev(mov), backend.dev(f), g, FLT_MAX, out)
+    got = backend.host(out)
+    sent_w, sent_g = want == FLT_MAX, got == FLT_MAX
+    # inside/outside decisions may differ only within fp rounding of the buffer edge
+    assert (sent_w != sent_g).mean() < 1e-4
+    both = ~(sent_w | sent_g)
+    # fp32 lerp of |v| <= ~1100 with a fp32 displacement: |dM/dx| * 1e-6 voxel + a few ulp
+    np.testing.assert_allclose(got[both], want[both], rtol=0, atol=5e-3)
+    assert sent_w.sum() > 0
+
+
+def test_warp_identity_and_integer_shift(backend):
+    shape, spacing, origin = (9, 14, 24), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)
+    mov = phantom(shape, seed=8)
+    g = geom_of(shape, spacing, origin)
+    out = backend.empty(shape)
+    zero = np.zeros((3,) + shape, dtype=np.float32)
+    backend.ctx.warp(backend.dev(mov), backend.dev(zero), g, FLT_MAX, out)
+    np.testing.assert_array_equal(backend.host(out), mov)  # warp by zero is the identity, bit for bit
+    sh = zero.copy()
+    sh[0] = 2.0   # +2 voxels in x
+    sh[1] = -1.0  # -1 voxel in y
+    backend.ctx.warp(backend.dev(mov), backend.dev(sh), g, -7.0, out)
+    got = backend.host(out)
+    want = np.full(shape, -7.0, dtype=np.float32)
+    want[:, 1:, :-2] = mov[:, :-1, 2:]
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("interp", [_lib.INTERP_LINEAR, _lib.INTERP_NEAREST])
+def test_resample_between_grids(backend, interp):
+    shape, spacing, origin = GRIDS[0]
+    img = phantom(shape, seed=9)
+    vin = O.Vol(img, spacing, origin)
+    # shrink-by-2 pyramid level grid (registration/utils.py:245-255)
+    new_size = [int(s / 2.0 + 0.5) for s in vin.size]
+    new_spacing = [((so - 1) * sp) / (sn - 1) for so, sp, sn in zip(vin.size, spacing, new_size)]
+    ref = O.Vol(np.zeros(new_size[::-1], dtype=np.float32), new_spacing, origin)
+    want = O.resample(vin, ref, interp=interp, default_value=-3.0).arr
+    out = backend.empty(ref.arr.shape)
+    backend.ctx.resample(backend.dev(img), geom_of(shape, spacing, origin), _lib.make_geom(new_size, new_spacing, origin),
+                         out, interp=interp, default_value=-3.0)
+    got = backend.host(out)
+    if interp == _lib.INTERP_NEAREST:
+        np.testing.assert_array_equal(got, want)
+    else:
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-3)
+
+
+def test_resample_affine(backend):
+    shape, spacing, origin = GRIDS[1]
+    img = phantom(shape, seed=10)
+    vin = O.Vol(img, spacing, origin)
+    ang = 0.1
+    A = np.array([[np.cos(ang), -np.sin(ang), 0.02], [np.sin(ang), np.cos(ang), 0.0], [0.01, 0.0, 1.05]])
+    t = np.array([1.5, -2.25, 0.5])
+    ref_shape, ref_sp, ref_or = (10, 18, 40), (1.3, 1.1, 1.2), (2.0, 1.0, -1.0)
+    ref = O.Vol(np.zeros(ref_shape, dtype=np.float32), ref_sp, ref_or)
+    for interp, tol in [(_lib.INTERP_LINEAR, 2e-3), (_lib.INTERP_NEAREST, 0.0)]:
+        want = O.resample(vin, ref, affine=(A, t), interp=interp, default_value=-1000.0).arr
+        out = backend.empty(ref_shape)
+        backend.ctx.resample(backend.dev(img), geom_of(shape, spacing, origin), geom_of(ref_shape, ref_sp, ref_or), out,
+                             affine_A=A.ravel(), affine_t=t, interp=interp, default_value=-1000.0)
+        got = backend.host(out)
+        if tol == 0.0:
+            np.testing.assert_array_equal(got, want)
+        else:
+            np.testing.assert_allclose(got, want, rtol=0, atol=tol)
+        assert (want == -1000.0).any() and (want != -1000.0).any()
+
+
+@pytest.mark.parametrize("grid", GRIDS)
+def test_mask_propagation_bit_exact(backend, grid):
+    """Propagated binary masks (nearest neighbour through a DVF) are bit-exact given the same DVF."""
+    shape, spacing, origin = grid
+    rng = np.random.default_rng(2)
+    mask = (smooth_noise(shape, 21, cells=4) > 0.2).astype(np.uint8)
+    mask[rng.integers(0, shape[0], 40), rng.integers(0, shape[1], 40), rng.integers(0, shape[2], 40)] ^= 1
+    f = random_dvf(shape, spacing, seed=13, max_mm=7.0)
+    vin = O.Vol(mask, spacing, origin)
+    fvol = O.Vol(f.astype(np.float64), spacing, origin)
+    want = O.resample(vin, vin, field_vol=fvol, interp=_lib.INTERP_NEAREST, default_value=0).arr
+    out = backend.empty(shape, np.uint8)
+    g = geom_of(shape, spacing, origin)
+    backend.ctx.resample(backend.dev(mask), g, g, out, field=backend.dev(f), interp=_lib.INTERP_NEAREST, default_value=0,
+                         u8=True)
+    got = backend.host(out)
+    assert got.dtype == np.uint8
+    np.testing.assert_array_equal(got, want)
+    assert 0 < want.sum() < want.size
+
+
+def test_resample_field_and_compose(backend):
+    shape, spacing, origin = GRIDS[0]
+    f = random_dvf(shape, spacing, seed=17, max_mm=5.0)
+    fin = O.Vol(f.astype(np.float64), spacing, origin)
+    # up-sample onto a finer grid with the same corners (deformable.py:137)
+    fine_shape = (shape[0] * 2 - 1, shape[1] * 2 - 1, shape[2] * 2 - 1)
+    fine_sp = [sp * (n - 1) / (m - 1) for sp, n, m in zip(spacing, size_of(shape), size_of(fine_shape))]
+    ref = O.Vol(np.zeros(fine_shape, dtype=np.float32), fine_sp, origin)
+    want = O.resample_vec(fin, ref).arr
+    out = backend.empty((3,) + fine_shape)
+    backend.ctx.resample_field(backend.dev(f), geom_of(shape, spacing, origin), geom_of(fine_shape, fine_sp, origin), out)
+    np.testing.assert_allclose(backend.host(out), want, rtol=0, atol=2e-5)
+    # composition total += iter o (id + total)  (deformable.py:154)
+    it = random_dvf(shape, spacing, seed=19, max_mm=3.0)
+    tot = O.Vol(f.astype(np.float64), spacing, origin)
+    comp = O.resample_vec(O.Vol(it.astype(np.float64), spacing, origin), tot, through=tot).arr
+    want2 = tot.arr + comp
+    d_tot = backend.dev(f)
+    backend.ctx.compose_field(d_tot, backend.dev(it), geom_of(shape, spacing, origin))
+    np.testing.assert_allclose(backend.host(d_tot), want2, rtol=0, atol=2e-5)
+
+
+def _demons_params(ctx, iterations, spacing, variant, max_rms=0.02):
+    p = ctx.default_demons_params()
+    p.iterations = iterations
+    p.smooth_update = 1
+    p.smooth_displacement = 1
+    p.sigma_d_vox[:] = [1.5 / s for s in spacing]
+    p.max_rms_error = max_rms
+    p.variant = variant
+    return p
+
+
+@pytest.mark.parametrize("grid", GRIDS)
+def test_demons_force_single_sweep(backend, grid):
+    shape, spacing, origin = grid
+    fix = phantom(shape, seed=30)
+    mov = phantom(shape, seed=30, noise=0) + 40.0 * smooth_noise(shape, 31).astype(np.float32)
+    warped = mov.copy()
+    warped[:, :, :3] = FLT_MAX          # crunched border
+    warped[4:6, 5:9, 10:14] = FLT_MAX   # interior hole -> one-sided differences around it
+    warped[2, 3, 20] = fix[2, 3, 20]    # |speed| below the intensity threshold
+    p = _demons_params(backend.ctx, 1, spacing, _lib.DEMONS_STAGED)
+    want, wst = O.esm_update(O.Vol(fix, spacing, origin), O.Vol(warped, spacing, origin))
+    upd = backend.empty((3,) + shape)
+    st = backend.ctx.demons_force(backend.dev(fix), backend.dev(warped), geom_of(shape, spacing, origin), p, upd)
+    got = backend.host(upd)
+    # |U| <= 0.5 * spacing; fp32 evaluation of 2 s J / (|J|^2 + s^2/K)
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+    assert st.n_pixels == wst.n_pixels
+    np.testing.assert_allclose(st.metric, wst.metric, rtol=1e-6)
+    np.testing.assert_allclose(st.rms_change, wst.rms_change, rtol=1e-5)
+    assert (got[:, 4:6, 5:9, 10:14] == 0).all()
+
+
+def _oracle_execute(fix, mov, spacing, origin, iterations, max_rms):
+    f = O.DemonsFilter()
+    f.SetSmoothUpdateField(True)
+    f.SetSmoothDisplacementField(True)
+    f.SetStandardDeviations([1.5 / s for s in spacing])
+    f.SetNumberOfIterations(iterations)
+    f.SetMaximumRMSError(max_rms)
+    d = f.Execute(O.Vol(fix, spacing, origin), O.Vol(mov, spacing, origin))
+    return d.arr, f.stats
+
+
+@pytest.mark.parametrize("variant", [_lib.DEMONS_STAGED, _lib.DEMONS_FUSED])
+@pytest.mark.parametrize("grid", GRIDS)
+def test_demons_execute(backend, grid, variant):
+    """registration_algorithm.Execute (deformable.py:149): 4 iterations, field vs the fp64 oracle.
+
+    Stated fp32 tolerance: max |D - D_oracle| <= 2e-3 mm (spacing ~1 mm) after 4 iterations on a
+    noisy phantom; typical error is ~1e-5 mm."""
+    shape, spacing, origin = grid
+    fix = phantom(shape, seed=40)
+    dv = random_dvf(shape, spacing, seed=41, max_mm=2.5)
+    mov = O.warp_image(O.Vol(fix, spacing, origin), dv.astype(np.float64), edge_value=-1000.0).arr
+    mov = (mov + np.random.default_rng(42).normal(0, 5, size=shape)).astype(np.float32)
+    want, wst = _oracle_execute(fix, mov, spacing, origin, 4, 0.0)
+    p = _demons_params(backend.ctx, 4, spacing, variant, max_rms=0.0)
+    field = backend.empty((3,) + shape)
+    st = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, field)
+    got = backend.host(field)
+    assert st.elapsed_iterations == 4 == wst.elapsed_iterations
+    err = np.abs(got - want)
+    assert err.max() <= 2e-3, f"max field error {err.max()} mm"
+    assert np.sqrt((err ** 2).mean()) <= 5e-5
+    np.testing.assert_allclose(st.metric, wst.metric, rtol=1e-4)
+    np.testing.assert_allclose(st.rms_change, wst.rms_change, rtol=1e-4)
+    assert np.abs(want).max() > 0.2  # the registration did something
+
+
+@pytest.mark.parametrize("variant", [_lib.DEMONS_STAGED, _lib.DEMONS_FUSED])
+def test_demons_early_halt(backend, variant):
+    """MaximumRMSError stops the loop on device exactly where FiniteDifferenceImageFilter::Halt does."""
+    shape, spacing, origin = GRIDS[1]
+    fix = phantom(shape, seed=50, noise=0)
+    mov = fix + np.float32(0.5) * smooth_noise(shape, 51).astype(np.float32)
+    # find an RMS threshold that the oracle crosses mid-run
+    rms = []
+    for n in range(1, 6):
+        _, s = _oracle_execute(fix, mov, spacing, origin, n, 0.0)
+        rms.append(s.rms_change)
+    thr = 0.5 * (rms[1] + rms[2])
+    want, wst = _oracle_execute(fix, mov, spacing, origin, 8, thr)
+    assert 1 < wst.elapsed_iterations < 8
+    p = _demons_params(backend.ctx, 8, spacing, variant, max_rms=thr)
+    field = backend.empty((3,) + shape)
+    st = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, field)
+    assert st.elapsed_iterations == wst.elapsed_iterations
+    assert st.halted == 1
+    np.testing.assert_allclose(backend.host(field), want, rtol=0, atol=1e-3)  # fp32 field vs fp64 oracle
+
+
+@pytest.mark.parametrize("grid", GRIDS)
+def test_recursive_gaussian_field(backend, grid):
+    shape, spacing, origin = grid
+    f = random_dvf(shape, spacing, seed=60, max_mm=5.0)
+    for sigma in ([1.5 / s for s in spacing], [0.4, 2.0, 3.0]):
+        want = O.recursive_gaussian_vec(O.Vol(f.astype(np.float64), spacing, origin), sigma).arr
+        d = backend.dev(f)
+        backend.ctx.recursive_gaussian_field(d, geom_of(shape, spacing, origin), sigma)
+        # each directional pass stores fp32; the causal half is rounded once more than in ITK
+        np.testing.assert_allclose(backend.host(d), want, rtol=0, atol=3e-6)
+
+
+def test_recursive_gaussian_needs_four_voxels(backend):
+    shape = (3, 8, 8)
+    d = backend.dev(np.zeros((3,) + shape, dtype=np.float32))
+    with pytest.raises(_lib.PlatipyAmdError):
+        backend.ctx.recursive_gaussian_field(d, geom_of(shape, (1, 1, 1), (0, 0, 0)), [1.0, 1.0, 1.0])
+
+
+@pytest.mark.parametrize("grid", GRIDS)
+def test_weight_map_and_fusion_ops(backend, grid):
+    shape, spacing, origin = grid
+    n = int(np.prod(shape))
+    tgt = phantom(shape, seed=70)
+    atl = [phantom(shape, seed=70, noise=0) + 30 * smooth_noise(shape, 71 + i).astype(np.float32) for i in range(3)]
+    labels = [(smooth_noise(shape, 80 + i, cells=4) > 0.1).astype(np.uint8) for i in range(3)]
+    ctx = backend.ctx
+    wsum = backend.empty(shape)
+    wlsum = backend.empty(shape)
+    aset = {}
+    for i in range(3):
+        want_w = O.compute_weight_map(O.Vol(tgt, spacing, origin), O.Vol(atl[i], spacing, origin), "local").arr
+        w = backend.empty(shape)
+        ctx.weight_map_local(backend.dev(tgt), backend.dev(atl[i]), size_of(shape), spacing, 2.0, 1e-5, w)
+        got_w = backend.host(w)
+        np.testing.assert_allclose(got_w, want_w, rtol=3e-5, atol=0)
+        # global vote: fp64 sum of squared differences
+        ssd = ctx.sum_sq_diff(backend.dev(tgt), backend.dev(atl[i]), n)
+        np.testing.assert_allclose(ssd, ((tgt.astype(np.float64) - atl[i]) ** 2).sum(), rtol=1e-12)
+        # accumulate with the oracle's weights so the fold itself is compared exactly
+        ctx.fuse_accumulate(backend.dev(want_w), backend.dev(labels[i]), wsum, wlsum, n)
+        aset[str(i)] = {"DIR": {"Weight Map": O.Vol(want_w, spacing, origin), "S": O.Vol(labels[i], spacing, origin)}}
+    ws = [aset[str(i)]["DIR"]["Weight Map"].arr for i in range(3)]
+    np.testing.assert_array_equal(backend.host(wsum), (ws[0] + ws[1]) + ws[2])  # same left fold, same fp32 adds
+    prob = backend.empty(shape)
+    ctx.fuse_divide(wlsum, wsum, prob, n)
+    ctx.discrete_gaussian(prob, prob, size_of(shape), spacing, (1.0, 1.0, 1.0), 0.01, 32, True)
+    lo, hi = ctx.minmax(prob, n)
+    ph = backend.host(prob)
+    assert lo == ph.min() and hi == ph.max()
+    ctx.rescale_threshold(prob, n, lo, hi, 1e-4)
+    want_p = O.combine_labels(aset, "S")["S"].arr
+    # w*L products may be contracted to fma on the GPU: <= 1 ulp of the running sum, then /, blur, rescale
+    np.testing.assert_allclose(backend.host(prob), want_p, rtol=0, atol=3e-6)
+    out = backend.empty(shape, np.uint8)
+    lo2, hi2 = ctx.minmax(prob, n)
+    ctx.binary_threshold(prob, n, 1.0 / hi2, 0.5, out)
+    b = backend.host(out)
+    pr = backend.host(prob)
+    np.testing.assert_array_equal(b, (pr * np.float32(1.0 / hi2) >= np.float32(0.5)).astype(np.uint8))
