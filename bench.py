@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""bench.py -- demons-iteration throughput on MI355X (BASELINE.json metric, config 2).
+
+A "step" is ONE full fast-symmetric-forces demons iteration (warp, ESM update, smooth update,
+add, smooth field, metric/RMS reduction) on a 512x512x256 fp32 volume pair that is already
+resident in HBM -- the finest pyramid level of config 2, where 98 % of the reference's voxel
+iterations are spent.  `value` = voxels x steps x ranks / wall time, in Mvoxels/s.
+
+  python bench.py [--gpus N --steps K --warmup W]            (N > 1: launched by torch.distributed.run)
+
+N > 1 is the multi-atlas shape of the path: every rank registers its own atlas to the target with
+no data-path collective inside the demons loop (weak scaling); timing is barrier-bracketed and the
+maximum over ranks.  Extra keys: `roofline` (dominant kernel, algorithmic bytes / HIP-event time),
+`cpu_baseline` (the oracle timed on this host's cores, rank 0, N == 1 only), `kernels` (per-kernel
+breakdown) and `registration_s` (one whole 3-level config-2 registration through the drop-in API).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from platipy_amd import _lib  # noqa: E402
+
+# Algorithmic bytes per voxel per iteration (SURVEY 8d / BASELINE.md 2): warp 20, force 20,
+# smooth-update 72, add fused into the first field pass 36, remaining field passes 48 = 196.
+ALGO_BYTES = {
+    "k_fused_force_smooth": 20 + 72,          # ESM update + 3 smoothing passes of the update
+    "k_fused_add_smooth_warp": 36 + 48 + 20,  # add + 3 smoothing passes of the field + warp
+    "k_warp_same_grid": 20,
+    "k_demons_force": 20,
+    "k_conv_axis x3 (update)": 72,
+    "k_conv_axis x3 (add+field)": 84,
+}
+ALGO_BYTES_ITER = 196
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def synth_pair(ctx, shape, spacing, seed, device):
+    """SURVEY 8d synthetic CT pair, generated on the GPU: ellipsoid body, ellipsoidal organs,
+    sigma-1.5-voxel blur, N(0,5^2) noise; moving = fixed warped by a smooth <= 6 mm field + noise."""
+    nz, ny, nx = shape
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.arange(nx, device=device, dtype=torch.float32).view(1, 1, nx)
+    y = torch.arange(ny, device=device, dtype=torch.float32).view(1, ny, 1)
+    z = torch.arange(nz, device=device, dtype=torch.float32).view(nz, 1, 1)
+    vol = torch.full(shape, -1000.0, device=device)
+    body = ((x - nx / 2) / (0.42 * nx)) ** 2 + ((y - ny / 2) / (0.40 * ny)) ** 2 + ((z - nz / 2) / (0.46 * nz)) ** 2 < 1
+    vol[body] = 0.0
+    for _ in range(12):
+        c = torch.rand(3, generator=g) * 0.5 + 0.25
+        r = torch.rand(3, generator=g) * 0.14 + 0.04
+        val = float(torch.rand(1, generator=g)) * 600.0 - 200.0
+        m = ((x - float(c[0]) * nx) / (float(r[0]) * nx)) ** 2 + ((y - float(c[1]) * ny) / (float(r[1]) * ny)) ** 2 + \
+            ((z - float(c[2]) * nz) / (float(r[2]) * nz)) ** 2 < 1
+        vol[m & body] = val
+        del m
+    del body
+    size = (nx, ny, nz)
+    clean = torch.empty_like(vol)
+    ctx.discrete_gaussian(vol, clean, size, (1, 1, 1), (2.25, 2.25, 2.25), 0.01, 32, False)
+    ctx.sync()
+    del vol
+    gd = torch.Generator(device=device).manual_seed(seed + 1)
+    fixed = clean + 5.0 * torch.randn(shape, device=device, generator=gd)
+    coarse = torch.randn((1, 3, 8, 16, 16), device=device, generator=gd)
+    dvf = torch.nn.functional.interpolate(coarse, size=shape, mode="trilinear", align_corners=True)[0].contiguous()
+    dvf *= 6.0 / float(torch.sqrt((dvf ** 2).sum(0)).max())
+    geom = _lib.make_geom(size, spacing)
+    moving = torch.empty_like(clean)
+    ctx.warp(clean, dvf, geom, -1000.0, moving)
+    ctx.sync()
+    moving += 5.0 * torch.randn(shape, device=device, generator=gd)
+    del clean, dvf
+    return fixed.contiguous(), moving.contiguous(), geom
+
+
+def cpu_baseline(fixed, moving, spacing, budget_s=12.0):
+    """The reference's CPU path timed beside the GPU.  SimpleITK (the reference's own arithmetic)
+    is used when importable; otherwise the oracle (C/OpenMP restatement) stands in, labelled "port"."""
+    nz, ny, nx = fixed.shape
+    cz, cy, cx = min(nz, 96), min(ny, 192), min(nx, 192)
+    sl = (slice((nz - cz) // 2, (nz - cz) // 2 + cz), slice((ny - cy) // 2, (ny - cy) // 2 + cy),
+          slice((nx - cx) // 2, (nx - cx) // 2 + cx))
+    f = fixed[sl].cpu().numpy().copy()
+    m = moving[sl].cpu().numpy().copy()
+    nvox = f.size
+    sample = f"centre crop {cx}x{cy}x{cz} of the bench pair"
+    try:
+        import SimpleITK as sitk  # noqa: F401
+
+        def run(n):
+            flt = sitk.FastSymmetricForcesDemonsRegistrationFilter()
+            flt.SetNumberOfThreads(os.cpu_count())
+            flt.SetSmoothUpdateField(True)
+            flt.SetSmoothDisplacementField(True)
+            flt.SetStandardDeviations([1.5 / s for s in spacing])
+            flt.SetNumberOfIterations(n)
+            flt.SetMaximumRMSError(0.0)
+            fi, mi = sitk.GetImageFromArray(f), sitk.GetImageFromArray(m)
+            fi.SetSpacing(spacing)
+            mi.SetSpacing(spacing)
+            t0 = time.perf_counter()
+            flt.Execute(fi, mi)
+            return time.perf_counter() - t0
+
+        kind, cores = "reference", os.cpu_count()
+    except ImportError:
+        from oracle import oracle as O
+
+        def run(n):
+            flt = O.DemonsFilter()
+            flt.SetSmoothUpdateField(True)
+            flt.SetSmoothDisplacementField(True)
+            flt.SetStandardDeviations([1.5 / s for s in spacing])
+            flt.SetNumberOfIterations(n)
+            flt.SetMaximumRMSError(0.0)
+            t0 = time.perf_counter()
+            flt.Execute(O.Vol(f, spacing), O.Vol(m, spacing))
+            return time.perf_counter() - t0
+
+        kind, cores = "port", O.lib().orc_num_threads()
+    run(1)  # thread pool / page-in
+    t1 = run(1)
+    n = int(max(2, min(40, budget_s / max(t1, 1e-3))))
+    t = run(n)
+    return {"value": nvox * n / t / 1e6, "unit": "Mvoxels/s per demons iter", "cores": cores, "kind": kind,
+            "sample": f"{sample}, {n} iterations, {t:.1f} s" +
+                      ("" if kind == "reference" else " (SimpleITK unavailable: C/OpenMP restatement stands in)")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 256], metavar=("NX", "NY", "NZ"))
+    ap.add_argument("--variant", choices=["auto", "fused", "staged"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-registration", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    nx, ny, nz = args.size
+    shape, spacing = (nz, ny, nx), (1.0, 1.0, 1.0)
+    nvox = nx * ny * nz
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = _lib.Context(local_rank, stream)
+    fixed, moving, geom = synth_pair(ctx, shape, spacing, 1234 + 100 * rank, device)
+    field = torch.zeros((3,) + shape, device=device)
+
+    p = ctx.default_demons_params()
+    p.smooth_update = 1
+    p.smooth_displacement = 1
+    p.sigma_d_vox[:] = [1.5 / s for s in spacing]  # deformable.py:253-257
+    p.max_rms_error = 0.0                          # fixed iteration count for timing
+    p.variant = {"auto": _lib.DEMONS_AUTO, "fused": _lib.DEMONS_FUSED, "staged": _lib.DEMONS_STAGED}[args.variant]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    if args.warmup > 0:
+        p.iterations = args.warmup
+        ctx.demons_execute(fixed, moving, geom, p, field, want_stats=False)
+    torch.cuda.synchronize()
+    ctx.profile_enable(True)
+    p.iterations = args.steps
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.demons_execute(fixed, moving, geom, p, field, want_stats=False)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    out = None
+    if rank == 0:
+        kernels = {}
+        for name, (launches, total_ms) in prof.items():
+            if launches == 0:
+                continue
+            avg_ms = total_ms / launches
+            ab = ALGO_BYTES.get(name)
+            kernels[name] = {"launches": launches, "avg_ms": avg_ms,
+                             "algorithmic_bytes_per_voxel": ab,
+                             "achieved_GBps": (ab * nvox / (avg_ms * 1e-3) / 1e9) if ab else None}
+        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if kernels else None
+        roofline = None
+        if dom and kernels[dom]["achieved_GBps"]:
+            a = kernels[dom]["achieved_GBps"]
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": a / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_voxel"] * nvox,
+                        "avg_launch_ms": kernels[dom]["avg_ms"]}
+        ms_per_step = dt * 1e3 / args.steps
+        iter_gbps = ALGO_BYTES_ITER * nvox / (ms_per_step * 1e-3) / 1e9
+        out = {
+            "metric": "Mvoxels/s per demons iter, 512x512x256 fp32",
+            "value": world * nvox * args.steps / dt / 1e6,
+            "unit": "Mvoxels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"config 2 finest level: one fast-symmetric-forces demons iteration on a "
+                                   f"{nx}x{ny}x{nz} fp32 CT-like pair per GPU, sigma_u 1.0 vox, sigma_d 1.5 mm, "
+                                   f"schedule {args.variant}", "parallelism": f"1 atlas-to-target registration per GPU x{world}"},
+            "roofline": roofline,
+            "roofline_iteration": {"achieved": iter_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": iter_gbps / HBM_PEAK_GBS,
+                                   "algorithmic_bytes_per_voxel": ALGO_BYTES_ITER},
+            "kernels": kernels,
+        }
+
+    # one whole config-2 registration (3 levels, 10/10/10) through the drop-in API, for the record
+    if not args.no_registration and world == 1 and (nx, ny, nz) == (512, 512, 256):
+        try:
+            from platipy_amd.image import Image
+            from platipy_amd.registration.deformable import fast_symmetric_forces_demons_registration as reg
+
+            fi, mi = Image(fixed, spacing), Image(moving, spacing)
+            reg(fi, mi)  # warm-up: workspace allocation
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reg(fi, mi)
+            torch.cuda.synchronize()
+            out["registration_s"] = time.perf_counter() - t0
+        except Exception as e:  # keep the headline line even if the optional leg fails
+            out["registration_s"] = f"failed: {e!r}"
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(fixed, moving, spacing)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -93,6 +93,18 @@ int pp_set_stream(pp_ctx* ctx, void* hip_stream);
 int pp_sync(pp_ctx* ctx);
 size_t pp_workspace_bytes(const pp_ctx* ctx);
 
+/* Optional per-kernel timing with HIP events recorded on the ctx stream around every kernel
+ * launch of the demons loop (bench.py's roofline figures).  Off by default: when off no event
+ * is created or recorded.  pp_profile_read synchronises, returns the number of distinct
+ * kernels (<= cap entries written) and resets the accumulators. */
+typedef struct {
+  char name[48];
+  int launches;
+  double total_ms;
+} pp_profile_entry;
+int pp_profile_enable(pp_ctx* ctx, int on);
+int pp_profile_read(pp_ctx* ctx, pp_profile_entry* out, int cap);
+
 /* ---- host helpers ---------------------------------------------------------------- */
 /* itk::GaussianOperator coefficients (every FIR below uses them).  taps gets 2r+1 values,
  * returns r or a negative pp_status. */

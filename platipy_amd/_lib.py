@@ -52,6 +52,10 @@ class DemonsStats(C.Structure):
     ]
 
 
+class ProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int), ("total_ms", C.c_double)]
+
+
 class PlatipyAmdError(RuntimeError):
     pass
 
@@ -65,6 +69,8 @@ _SIGNATURES = {
     "pp_set_stream": (C.c_int, [_P, _P]),
     "pp_sync": (C.c_int, [_P]),
     "pp_workspace_bytes": (C.c_size_t, [_P]),
+    "pp_profile_enable": (C.c_int, [_P, C.c_int]),
+    "pp_profile_read": (C.c_int, [_P, C.POINTER(ProfileEntry), C.c_int]),
     "pp_gauss_taps": (C.c_int, [C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double), C.c_int]),
     "pp_demons_default_params": (None, [C.POINTER(DemonsParams)]),
     "pp_discrete_gaussian_f32": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -205,6 +211,17 @@ class Context:
 
     def workspace_bytes(self):
         return self.lib.pp_workspace_bytes(self.h)
+
+    def profile_enable(self, on=True):
+        self._chk(self.lib.pp_profile_enable(self.h, int(bool(on))), "pp_profile_enable")
+
+    def profile_read(self):
+        """{kernel name: (launches, total ms)} since the last read (synchronises the stream)."""
+        buf = (ProfileEntry * 32)()
+        n = self.lib.pp_profile_read(self.h, buf, 32)
+        if n < 0:
+            self._chk(n, "pp_profile_read")
+        return {buf[i].name.decode(): (buf[i].launches, buf[i].total_ms) for i in range(n)}
 
     def default_demons_params(self):
         p = DemonsParams()

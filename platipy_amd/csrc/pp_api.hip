@@ -3,7 +3,59 @@
 #include "pp_internal.h"
 
 #include <cstdlib>
+#include <string>
 #include <vector>
+
+// ---------------------------------------------------------------------------------------
+// optional HIP-event profiler
+
+struct pp_prof_span {
+  int slot;
+  hipEvent_t a, b;
+};
+struct pp_profiler {
+  std::vector<std::string> names;
+  std::vector<pp_prof_span> spans;   // recorded since the last read
+  std::vector<hipEvent_t> pool;      // idle events
+  int open_slot = -1;
+  hipEvent_t open_a = nullptr;
+};
+
+static hipEvent_t prof_event(pp_profiler* p) {
+  if (!p->pool.empty()) {
+    hipEvent_t e = p->pool.back();
+    p->pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+void pp_prof_begin(pp_ctx* ctx, const char* kernel_name) {
+  pp_profiler* p = ctx->prof;
+  if (!p) return;
+  int slot = -1;
+  for (size_t i = 0; i < p->names.size(); ++i)
+    if (p->names[i] == kernel_name) slot = (int)i;
+  if (slot < 0) {
+    p->names.emplace_back(kernel_name);
+    slot = (int)p->names.size() - 1;
+  }
+  p->open_slot = slot;
+  p->open_a = prof_event(p);
+  if (p->open_a) (void)hipEventRecord(p->open_a, ctx->stream);
+}
+
+void pp_prof_end(pp_ctx* ctx) {
+  pp_profiler* p = ctx->prof;
+  if (!p || p->open_slot < 0) return;
+  hipEvent_t b = prof_event(p);
+  if (b) (void)hipEventRecord(b, ctx->stream);
+  if (p->open_a && b) p->spans.push_back({p->open_slot, p->open_a, b});
+  p->open_slot = -1;
+  p->open_a = nullptr;
+}
 
 int pp_fail(pp_ctx* ctx, int code, const char* fmt, ...) {
   if (ctx) {
@@ -56,11 +108,56 @@ int pp_create(int device, void* hip_stream, pp_ctx** out) {
 
 void pp_destroy(pp_ctx* ctx) {
   if (!ctx) return;
-  if (ctx->ws) {
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(ctx->ws);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->prof) {
+    for (auto& s : ctx->prof->spans) {
+      (void)hipEventDestroy(s.a);
+      (void)hipEventDestroy(s.b);
+    }
+    for (auto e : ctx->prof->pool) (void)hipEventDestroy(e);
+    delete ctx->prof;
   }
   free(ctx);
+}
+
+int pp_profile_enable(pp_ctx* ctx, int on) {
+  if (!ctx) return PP_ERR_ARG;
+  if (on && !ctx->prof) ctx->prof = new pp_profiler();
+  if (!on && ctx->prof) {
+    PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& s : ctx->prof->spans) {
+      (void)hipEventDestroy(s.a);
+      (void)hipEventDestroy(s.b);
+    }
+    for (auto e : ctx->prof->pool) (void)hipEventDestroy(e);
+    delete ctx->prof;
+    ctx->prof = nullptr;
+  }
+  return PP_OK;
+}
+
+int pp_profile_read(pp_ctx* ctx, pp_profile_entry* out, int cap) {
+  if (!ctx || (!out && cap > 0)) return PP_ERR_ARG;
+  pp_profiler* p = ctx->prof;
+  if (!p) return 0;
+  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int n = (int)p->names.size();
+  for (int i = 0; i < n && i < cap; ++i) {
+    memset(&out[i], 0, sizeof(out[i]));
+    snprintf(out[i].name, sizeof(out[i].name), "%s", p->names[i].c_str());
+  }
+  for (auto& s : p->spans) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess && s.slot < cap) {
+      out[s.slot].launches += 1;
+      out[s.slot].total_ms += (double)ms;
+    }
+    p->pool.push_back(s.a);
+    p->pool.push_back(s.b);
+  }
+  p->spans.clear();
+  return n < cap ? n : cap;
 }
 
 const char* pp_last_error(const pp_ctx* ctx) { return ctx ? ctx->err : "null ctx"; }

@@ -606,9 +606,15 @@ int launch_fused_iteration(pp_ctx* ctx, const float* F, const float* M, const fl
                            const pp_warp_scale& sc, double* partials, const int* halt) {
   const pp_dims& d = fu.d;
   const dim3 grid((d.nx + TX - 1) / TX, (d.ny + TY - 1) / TY, (d.nz + fu.zchunk - 1) / fu.zchunk), block(NT);
-  hipLaunchKernelGGL((k_fused_force_smooth<R>), grid, block, 0, ctx->stream, F, Mw_in, Us, fu, K, partials, halt);
+  {
+    pp_prof_scope ps(ctx, "k_fused_force_smooth");
+    hipLaunchKernelGGL((k_fused_force_smooth<R>), grid, block, 0, ctx->stream, F, Mw_in, Us, fu, K, partials, halt);
+  }
   PP_LAUNCH_CHECK(ctx, "k_fused_force_smooth");
-  hipLaunchKernelGGL((k_fused_add_smooth_warp<R>), grid, block, 0, ctx->stream, D, (const float*)Us, M, Dn, Mw_out, fd, sc, halt);
+  {
+    pp_prof_scope ps(ctx, "k_fused_add_smooth_warp");
+    hipLaunchKernelGGL((k_fused_add_smooth_warp<R>), grid, block, 0, ctx->stream, D, (const float*)Us, M, Dn, Mw_out, fd, sc, halt);
+  }
   PP_LAUNCH_CHECK(ctx, "k_fused_add_smooth_warp");
   return PP_OK;
 }
@@ -717,15 +723,23 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     PP_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(pp_dev_stats), ctx->stream));
     PP_HIP(ctx, hipMemsetAsync(field, 0, 3 * N * sizeof(float), ctx->stream));
     for (int it = 0; it < p->iterations; ++it) {
-      rc = pp_warp_same_grid(ctx, moving, field, d, sc, FLT_MAX, Mw, halt);
+      {
+        pp_prof_scope ps(ctx, "k_warp_same_grid");
+        rc = pp_warp_same_grid(ctx, moving, field, d, sc, FLT_MAX, Mw, halt);
+      }
       if (rc) return rc;
-      hipLaunchKernelGGL(k_demons_force, dim3(nb), dim3(NT), 0, ctx->stream, fixed, (const float*)Mw, U, d, K, partials, halt);
+      {
+        pp_prof_scope ps(ctx, "k_demons_force");
+        hipLaunchKernelGGL(k_demons_force, dim3(nb), dim3(NT), 0, ctx->stream, fixed, (const float*)Mw, U, d, K, partials, halt);
+      }
       PP_LAUNCH_CHECK(ctx, "k_demons_force");
       if (p->smooth_update) {
+        pp_prof_scope ps(ctx, "k_conv_axis x3 (update)");
         rc = pp_smooth3_staged(ctx, U, nullptr, U, T1, T2, d, 3, tu, order, halt);
         if (rc) return rc;
       }
       if (p->smooth_displacement) {
+        pp_prof_scope ps(ctx, "k_conv_axis x3 (add+field)");
         rc = pp_smooth3_staged(ctx, field, U, field, T1, T2, d, 3, td, order, halt);  // add fused into pass 1
         if (rc) return rc;
       } else {

@@ -15,12 +15,24 @@
 // ---------------------------------------------------------------------------------------
 // context
 
+struct pp_profiler;
+
 struct pp_ctx {
   int device;
   hipStream_t stream;
   char* ws;          // device scratch, grown on demand
   size_t ws_bytes;
+  pp_profiler* prof;  // NULL unless pp_profile_enable(ctx, 1)
   char err[512];
+};
+
+// HIP-event bracket around one launch (no-ops while profiling is off).
+void pp_prof_begin(pp_ctx* ctx, const char* kernel_name);
+void pp_prof_end(pp_ctx* ctx);
+struct pp_prof_scope {
+  pp_ctx* c;
+  pp_prof_scope(pp_ctx* ctx, const char* name) : c(ctx) { if (c->prof) pp_prof_begin(c, name); }
+  ~pp_prof_scope() { if (c->prof) pp_prof_end(c); }
 };
 
 int pp_fail(pp_ctx* ctx, int code, const char* fmt, ...);

@@ -1,0 +1,214 @@
+"""Drop-in for platipy/imaging/registration/deformable.py:31-306: multi-resolution fast
+symmetric-forces demons.  Same function names, keyword arguments, defaults and return values; the
+voxel-level work (pyramids, warps, the demons inner loop, field composition and regularisation) runs
+in the HIP kernels behind include/platipy_amd.h, on fp32 volumes resident in HBM.
+
+Deviations, all deliberate and visible:
+  * the displacement field is fp32 (the reference keeps sitkVectorFloat64); the tolerance against
+    the fp64 restatement is stated and tested in tests/;
+  * `ncores` is accepted and ignored (it set ITK's CPU thread count);
+  * B-spline interpolation (`interp_order=3`) raises NotImplementedError;
+  * non-identity direction cosines raise NotImplementedError in the demons loop.
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+from ..image import Image, as_image, cast_tensor
+from .. import runtime
+from ..transform import DisplacementFieldTransform, sitkLinear
+from .utils import resample_field, resample_image, smooth_and_resample
+
+
+class HipDemonsFilter:
+    """sitk.FastSymmetricForcesDemonsRegistrationFilter with SimpleITK's defaults, satisfying the
+    duck-typed protocol multiscale_demons needs (reference deformable.py:144,149,157):
+    SetNumberOfIterations / Execute / GetStandardDeviations."""
+
+    def __init__(self, variant="auto"):
+        self._standard_deviations = [1.0, 1.0, 1.0]
+        self._update_field_standard_deviations = [1.0, 1.0, 1.0]
+        self._iterations = 10
+        self._max_rms = 0.02
+        self._max_step = 0.5
+        self._smooth_disp = True
+        self._smooth_update = False
+        self._max_kernel_width = 30
+        self._max_error = 0.1
+        self._intensity_threshold = 0.001
+        self._variant = {"auto": _lib.DEMONS_AUTO, "staged": _lib.DEMONS_STAGED, "fused": _lib.DEMONS_FUSED}[variant]
+        self._stats = None
+        self._commands = []
+
+    # configuration, SimpleITK names
+    def SetNumberOfThreads(self, n):  # CPU concept; kept for signature compatibility
+        pass
+
+    def SetNumberOfIterations(self, n):
+        self._iterations = int(n)
+
+    def GetNumberOfIterations(self):
+        return self._iterations
+
+    def SetStandardDeviations(self, s):
+        self._standard_deviations = [float(v) for v in np.broadcast_to(np.asarray(s, dtype=np.float64), (3,))]
+
+    def GetStandardDeviations(self):
+        return tuple(self._standard_deviations)
+
+    def SetUpdateFieldStandardDeviations(self, s):
+        self._update_field_standard_deviations = [float(v) for v in np.broadcast_to(np.asarray(s, dtype=np.float64), (3,))]
+
+    def SetSmoothUpdateField(self, b):
+        self._smooth_update = bool(b)
+
+    def SetSmoothDisplacementField(self, b):
+        self._smooth_disp = bool(b)
+
+    def SetMaximumRMSError(self, v):
+        self._max_rms = float(v)
+
+    def SetMaximumUpdateStepLength(self, v):
+        self._max_step = float(v)
+
+    def SetIntensityDifferenceThreshold(self, v):
+        self._intensity_threshold = float(v)
+
+    def SetMaximumKernelWidth(self, v):
+        self._max_kernel_width = int(v)
+
+    def SetMaximumError(self, v):
+        self._max_error = float(v)
+
+    def AddCommand(self, event, fn):
+        """Iteration callbacks cannot fire inside the on-device loop; they run once after Execute."""
+        self._commands.append(fn)
+
+    # measurements
+    def GetElapsedIterations(self):
+        return self._stats.elapsed_iterations if self._stats else 0
+
+    def GetMetric(self):
+        return self._stats.metric if self._stats else float("nan")
+
+    def GetRMSChange(self):
+        return self._stats.rms_change if self._stats else float("nan")
+
+    def Execute(self, fixed_image, moving_image):
+        f, m = as_image(fixed_image), as_image(moving_image)
+        if f.GetSize() != m.GetSize():
+            raise ValueError("demons: fixed and moving image must be on the same grid (reference deformable.py:210-211)")
+        if f.direction != (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0):
+            raise NotImplementedError("demons: only identity direction cosines are supported")
+        ctx = runtime.context(f.device)
+        ft = (f.tensor if f.tensor.dtype == torch.float32 else f.tensor.float()).contiguous()
+        mt = (m.tensor if m.tensor.dtype == torch.float32 else m.tensor.float()).contiguous()
+        p = ctx.default_demons_params()
+        p.iterations = self._iterations
+        p.sigma_d_vox[:] = self._standard_deviations
+        p.sigma_u_vox[:] = self._update_field_standard_deviations
+        p.smooth_displacement = int(self._smooth_disp)
+        p.smooth_update = int(self._smooth_update)
+        p.max_rms_error = self._max_rms
+        p.max_step_length = self._max_step
+        p.intensity_threshold = self._intensity_threshold
+        p.max_error = self._max_error
+        p.max_kernel_width = self._max_kernel_width
+        p.variant = self._variant
+        field = torch.empty((3,) + f.shape, dtype=torch.float32, device=ft.device)
+        self._stats = ctx.demons_execute(ft, mt, f.geom(), p, field, want_stats=True)
+        for fn in self._commands:
+            fn()
+        return Image(field, f.spacing, f.origin, f.direction, True)
+
+
+def multiscale_demons(registration_algorithm, fixed_image, moving_image, initial_transform=None,
+                      initial_displacement_field=None, isotropic_resample=None, resolution_staging=None,
+                      smoothing_sigmas=None, iteration_staging=None, interp_order=sitkLinear):
+    """Run `registration_algorithm` coarse-to-fine (reference deformable.py:31-187).  Any object with
+    SetNumberOfIterations / Execute(fixed, moving) -> vector Image / GetStandardDeviations works."""
+    fixed_image, moving_image = as_image(fixed_image), as_image(moving_image)
+    ctx = runtime.context(fixed_image.device)
+    fixed_images, moving_images = [], []
+    for resolution, smoothing_sigma in zip(resolution_staging, smoothing_sigmas):
+        isotropic_voxel_size_mm = resolution if isotropic_resample else None
+        shrink_factor = None if isotropic_resample else resolution
+        fixed_images.append(smooth_and_resample(fixed_image, isotropic_voxel_size_mm=isotropic_voxel_size_mm,
+                                                shrink_factor=shrink_factor, smoothing_sigma=smoothing_sigma,
+                                                interpolator=interp_order))
+        moving_images.append(smooth_and_resample(moving_image, isotropic_voxel_size_mm=isotropic_voxel_size_mm,
+                                                 shrink_factor=shrink_factor, smoothing_sigma=smoothing_sigma,
+                                                 interpolator=interp_order))
+
+    if initial_displacement_field is None:
+        if initial_transform is not None:
+            raise NotImplementedError("initial_transform: pass initial_displacement_field instead")
+        dvf_total = Image(torch.zeros((3,) + fixed_image.shape, dtype=torch.float32, device=fixed_image.device),
+                          fixed_image.spacing, fixed_image.origin, fixed_image.direction, True)
+    else:
+        dvf_total = resample_field(as_image(initial_displacement_field), fixed_image)
+
+    for i in range(len(fixed_images)):
+        f_image, m_image = fixed_images[i], moving_images[i]
+        dvf_total = resample_field(dvf_total, f_image)                                           # :137
+        # :139-140 -- sitk.Resample(m_image, tfm_total, interp_order): default pixel value 0 (quirk N4)
+        m_image = resample_image(m_image, m_image, DisplacementFieldTransform(dvf_total), interp_order, 0.0)
+        registration_algorithm.SetNumberOfIterations(iteration_staging[i])
+        dvf_iter = registration_algorithm.Execute(f_image, m_image)                              # :149
+        ctx.compose_field(dvf_total.tensor, dvf_iter.tensor.contiguous(), f_image.geom())        # :154
+        sigma = registration_algorithm.GetStandardDeviations()                                   # :157
+        ctx.recursive_gaussian_field(dvf_total.tensor, f_image.geom(), sigma)                    # :158 (quirk N2)
+    return resample_field(dvf_total, fixed_image)                                                # :185
+
+
+def fast_symmetric_forces_demons_registration(
+    fixed_image,
+    moving_image,
+    resolution_staging=[8, 4, 1],
+    iteration_staging=[10, 10, 10],
+    isotropic_resample=False,
+    initial_displacement_field=None,
+    regularisation_kernel_mm=1.5,
+    smoothing_sigma_factor=1,
+    smoothing_sigmas=False,
+    default_value=None,
+    ncores=1,
+    interp_order=sitkLinear,
+    verbose=False,
+    variant="auto",
+):
+    """Deformable image propagation using Fast Symmetric-Forces Demons (reference deformable.py:190-306).
+
+    Returns (registered_image, output_transform, deformation_field), the field as a planar fp32 vector
+    Image on the fixed grid.  `variant` ("auto" | "fused" | "staged") picks the kernel schedule."""
+    fixed_image, moving_image = as_image(fixed_image), as_image(moving_image)
+    moving_image_type = moving_image.tensor.dtype
+    fixed_image = fixed_image.astype(torch.float32)    # :236-241 (quirk N1: everything computes in float32)
+    moving_image = moving_image.astype(torch.float32)
+
+    registration_method = HipDemonsFilter(variant=variant)
+    registration_method.SetNumberOfThreads(ncores)
+    registration_method.SetSmoothUpdateField(True)
+    registration_method.SetSmoothDisplacementField(True)
+    regularisation_kernel_vox = np.array(regularisation_kernel_mm) / np.array(fixed_image.GetSpacing())
+    registration_method.SetStandardDeviations(regularisation_kernel_vox.tolist())
+    if verbose:
+        registration_method.AddCommand(None, lambda: print("{0:3} = {1:10.5f}".format(
+            registration_method.GetElapsedIterations(), registration_method.GetMetric())))
+    if not smoothing_sigmas:
+        smoothing_sigmas = [i * smoothing_sigma_factor for i in resolution_staging]
+
+    deformation_field = multiscale_demons(
+        registration_algorithm=registration_method, fixed_image=fixed_image, moving_image=moving_image,
+        resolution_staging=resolution_staging, smoothing_sigmas=smoothing_sigmas, iteration_staging=iteration_staging,
+        isotropic_resample=isotropic_resample, initial_displacement_field=initial_displacement_field,
+        interp_order=interp_order)
+
+    if default_value is None:
+        default_value = 0
+        if float(moving_image.tensor.min()) <= -1000:   # CT-like (:286-291)
+            default_value = -1000
+    output_transform = DisplacementFieldTransform(deformation_field)
+    registered_image = resample_image(moving_image, fixed_image, output_transform, interp_order, default_value)
+    registered_image = registered_image.like(cast_tensor(registered_image.tensor, moving_image_type))
+    return registered_image, output_transform, deformation_field

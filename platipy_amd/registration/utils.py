@@ -1,0 +1,161 @@
+"""Drop-in for platipy/imaging/registration/utils.py:54-267 (apply_transform, its two wrappers and
+smooth_and_resample), on torch tensors in HBM through the HIP C ABI."""
+import logging
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..image import Image, as_image, cast_tensor
+from .. import runtime
+from ..transform import (
+    AffineTransform,
+    CompositeTransform,
+    DisplacementFieldTransform,
+    Transform,
+    sitkBSpline,
+    sitkLinear,
+    sitkNearestNeighbor,
+)
+
+logger = logging.getLogger(__name__)
+
+
+def _check_interp(interpolator):
+    if interpolator == sitkBSpline:
+        raise NotImplementedError("B-spline interpolation is not implemented on the HIP path (nearest and linear are)")
+    if interpolator not in (sitkNearestNeighbor, sitkLinear):
+        raise ValueError(f"unknown interpolator {interpolator!r}")
+    return _lib.INTERP_NEAREST if interpolator == sitkNearestNeighbor else _lib.INTERP_LINEAR
+
+
+def _split_transform(transform, reference):
+    """-> (A, t, field_tensor_on_reference_grid or None) such that q = A p + t + field(p)."""
+    if transform is None or type(transform) is Transform:
+        return None, None, None
+    parts = transform.flatten() if isinstance(transform, CompositeTransform) else [transform]
+    parts = [p for p in parts if type(p) is not Transform]
+    fields = [i for i, p in enumerate(parts) if isinstance(p, DisplacementFieldTransform)]
+    if not fields:
+        A, off = CompositeTransform(parts).matrix_offset()
+        return A, off, None
+    if len(fields) > 1 or fields[0] != len(parts) - 1:
+        raise NotImplementedError("a displacement field is supported alone or as the first-applied (last-listed) member of a composite")
+    dvf = parts[-1].field
+    if not dvf.same_grid(reference):
+        dvf = resample_field(dvf, reference)
+    f = dvf.tensor if dvf.tensor.dtype == torch.float32 else dvf.tensor.float()
+    if len(parts) == 1:
+        return None, None, f.contiguous()
+    A, off = CompositeTransform(parts[:-1]).matrix_offset()
+    # q = A (p + D(p)) + off = A p + off + A D(p)
+    At = torch.tensor(A, dtype=torch.float32, device=f.device)
+    f = torch.einsum("rc,czyx->rzyx", At, f).contiguous()
+    return A, off, f
+
+
+def resample_field(field_image, reference):
+    """sitk.Resample(vector_image, reference): linear, identity transform, default 0."""
+    ctx = runtime.context(field_image.device)
+    src = field_image.tensor if field_image.tensor.dtype == torch.float32 else field_image.tensor.float()
+    out = torch.empty((3,) + reference.shape, dtype=torch.float32, device=src.device)
+    ctx.resample_field(src.contiguous(), field_image.geom(), reference.geom(), out)
+    return Image(out, reference.spacing, reference.origin, reference.direction, True)
+
+
+def resample_image(image, reference, transform=None, interpolator=sitkLinear, default_value=0.0):
+    """sitk.Resample(image, reference, transform, interpolator, default): result keeps fp32/uint8 storage."""
+    interp = _check_interp(interpolator)
+    ctx = runtime.context(image.device)
+    A, t, field = _split_transform(transform, reference)
+    if image.tensor.dtype == torch.uint8:
+        src, u8 = image.tensor, True
+        out = torch.empty(reference.shape, dtype=torch.uint8, device=src.device)
+    else:
+        src, u8 = (image.tensor if image.tensor.dtype == torch.float32 else image.tensor.float()), False
+        out = torch.empty(reference.shape, dtype=torch.float32, device=src.device)
+    ctx.resample(src.contiguous(), image.geom(), reference.geom(), out, affine_A=None if A is None else A.ravel(),
+                 affine_t=None if A is None else t, field=field, interp=interp, default_value=float(default_value), u8=u8)
+    return Image(out, reference.spacing, reference.origin, reference.direction, False)
+
+
+def apply_transform(input_image, reference_image=None, transform=None, default_value=0, interpolator=sitkNearestNeighbor):
+    """Transform a volume or structure (reference: registration/utils.py:148-192)."""
+    input_image = as_image(input_image)
+    reference = as_image(reference_image) if reference_image is not None else input_image
+    original_dtype = input_image.tensor.dtype
+    out = resample_image(input_image, reference, transform, interpolator, default_value)
+    return out.like(cast_tensor(out.tensor, original_dtype))
+
+
+def apply_linear_transform(input_image, reference_image, transform, is_structure=False, default_value=0,
+                           interpolator=sitkNearestNeighbor):
+    """registration/utils.py:54-99"""
+    if is_structure:
+        if default_value != 0 or interpolator != sitkNearestNeighbor:
+            logger.warning("is_structure is set to True, but you have set default_value and/or interpolator. "
+                           "default_value and/or interpolator will be overwritten.")
+        default_value = 0
+        interpolator = sitkNearestNeighbor
+    return apply_transform(input_image=input_image, reference_image=reference_image, transform=transform,
+                           default_value=default_value, interpolator=interpolator)
+
+
+def apply_deformable_transform(input_image, transform, is_structure=False, default_value=0, interpolator=sitkNearestNeighbor):
+    """registration/utils.py:102-145"""
+    if is_structure:
+        if default_value != 0 or interpolator != sitkNearestNeighbor:
+            logger.warning("is_structure is set to True, but you have set default_value and/or interpolator. "
+                           "default_value and/or interpolator will be overwritten.")
+        default_value = 0
+        interpolator = sitkNearestNeighbor
+    return apply_transform(input_image=input_image, reference_image=None, transform=transform, default_value=default_value,
+                           interpolator=interpolator)
+
+
+def discrete_gaussian(image, variance, maximum_kernel_width=32, maximum_error=0.01, use_image_spacing=True):
+    """sitk.DiscreteGaussian on a scalar image (fp32 result)."""
+    ctx = runtime.context(image.device)
+    src = image.tensor if image.tensor.dtype == torch.float32 else image.tensor.float()
+    var = [float(v) for v in np.broadcast_to(np.asarray(variance, dtype=np.float64), (3,))]
+    out = torch.empty_like(src)
+    ctx.discrete_gaussian(src.contiguous(), out, image.GetSize(), image.spacing, var, maximum_error, int(maximum_kernel_width),
+                          use_image_spacing)
+    return image.like(out)
+
+
+def smooth_and_resample(image, isotropic_voxel_size_mm=None, shrink_factor=None, smoothing_sigma=None,
+                        interpolator=sitkLinear):
+    """One pyramid level (reference: registration/utils.py:195-267): optional Gaussian blur with sigma in mm,
+    then linear resampling onto a corner-aligned coarser grid."""
+    image = as_image(image)
+    if smoothing_sigma:
+        if hasattr(smoothing_sigma, "__iter__"):
+            smoothing_variance = [i * i for i in smoothing_sigma]
+        else:
+            smoothing_variance = (smoothing_sigma ** 2,) * 3
+        maximum_kernel_width = int(max([8 * j * i for i, j in zip(image.GetSpacing(), smoothing_variance)]))
+        image = discrete_gaussian(image, smoothing_variance, maximum_kernel_width)
+
+    original_spacing = image.GetSpacing()
+    original_size = image.GetSize()
+
+    if shrink_factor and isotropic_voxel_size_mm:
+        raise AttributeError("Function must be called with either isotropic_voxel_size_mm or shrink_factor, not both.")
+    elif isotropic_voxel_size_mm:
+        scale_factor = isotropic_voxel_size_mm * np.ones(3) / np.array(image.GetSpacing())
+        new_size = [int(sz / float(sf) + 0.5) for sz, sf in zip(original_size, scale_factor)]
+    elif shrink_factor:
+        if isinstance(shrink_factor, list):
+            new_size = [int(sz / float(sf) + 0.5) for sz, sf in zip(original_size, shrink_factor)]
+        else:
+            new_size = [int(sz / float(shrink_factor) + 0.5) for sz in original_size]
+    else:
+        return image
+
+    new_spacing = [((size_o_i - 1) * spacing_o_i) / (size_n_i - 1)
+                   for size_o_i, spacing_o_i, size_n_i in zip(original_size, original_spacing, new_size)]
+    ref = Image(torch.empty((new_size[2], new_size[1], new_size[0]), dtype=torch.float32, device="meta"), new_spacing,
+                image.GetOrigin(), image.GetDirection())
+    out = resample_image(image, ref, None, interpolator, 0.0)
+    return out.like(cast_tensor(out.tensor, image.tensor.dtype))

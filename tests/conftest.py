@@ -34,3 +34,22 @@ def backend(request):
     if request.param == "emu":
         return request.getfixturevalue("emu_backend")
     return request.getfixturevalue("gpu_backend")
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def host_api(request, monkeypatch):
+    """The drop-in Python API (platipy_amd.*).  `gpu`: the product as shipped, tensors on cuda:0.
+    `emu` (CPU suite only): the same host code with its context lookup pointed at the CPU-emulated
+    kernels and tensors kept on the host -- test plumbing, not a product fallback."""
+    import torch
+
+    import platipy_amd
+    from platipy_amd import runtime
+
+    if request.param == "emu":
+        be = request.getfixturevalue("emu_backend")
+        monkeypatch.setattr(runtime, "context", lambda device=None: be.ctx)
+        monkeypatch.setattr(runtime, "default_device", lambda: torch.device("cpu"))
+    else:
+        request.getfixturevalue("gpu_backend")
+    return platipy_amd
