@@ -38,24 +38,25 @@ struct pp_esm_consts {
   float ix, iy, iz;   // 1 / spacing
   float inv_norm;     // 1 / normalizer (unused when !has_norm)
   float denom_thr;
-  double intensity_thr;
+  float intensity_thr;  // smallest float >= the fp64 threshold: |s| < thr decides exactly as in fp64
   int has_norm;
 };
 
 // One axis of the symmetric ESM gradient: itk::CentralDifferenceImageFunction on the fixed
 // image (zero on the first/last index) plus the sentinel-aware difference of the warped moving
 // image that ESMDemonsRegistrationFunction::ComputeUpdate builds "more or less by hand".
-__device__ __forceinline__ float pp_esm_axis(float fm, float fp, float mc, float mm, float mp, int idx, int n, float h,
+// lo / hi: the voxel is the first / last one along this axis (both set: the axis has one voxel).
+__device__ __forceinline__ float pp_esm_axis(float fm, float fp, float mc, float mm, float mp, bool lo, bool hi, float h,
                                              float inv_sp) {
   const float SENT = FLT_MAX;
   float wg;
-  if (n == 1) wg = 0.0f;
-  else if (idx == 0) wg = (mp == SENT) ? 0.0f : (mp - mc) * inv_sp;
-  else if (idx == n - 1) wg = (mm == SENT) ? 0.0f : (mc - mm) * inv_sp;
+  if (lo && hi) wg = 0.0f;
+  else if (lo) wg = (mp == SENT) ? 0.0f : (mp - mc) * inv_sp;
+  else if (hi) wg = (mm == SENT) ? 0.0f : (mc - mm) * inv_sp;
   else if (mp == SENT) wg = (mm == SENT) ? 0.0f : (mc - mm) * inv_sp;
   else if (mm == SENT) wg = (mp - mc) * inv_sp;
   else wg = (mp - mm) * h;
-  const float fg = (idx < 1 || idx > n - 2) ? 0.0f : (fp - fm) * h;
+  const float fg = (lo || hi) ? 0.0f : (fp - fm) * h;
   return fg + wg;
 }
 
@@ -73,10 +74,10 @@ __device__ __forceinline__ pp_esm_out pp_esm_voxel(const pp_esm_consts& K, float
   if (mc == FLT_MAX) return o;  // mapped outside the moving image: no update, not counted
   const float speed = fc - mc;
   const float g2 = gx * gx + gy * gy + gz * gz;
-  if (!(fabs((double)speed) < K.intensity_thr)) {
+  if (!(fabsf(speed) < K.intensity_thr)) {
     const float denom = K.has_norm ? g2 + speed * speed * K.inv_norm : g2;
     if (!(denom < K.denom_thr)) {
-      const float factor = 2.0f * speed / denom;
+      const float factor = __fdividef(2.0f * speed, denom);
       o.ux = factor * gx;
       o.uy = factor * gy;
       o.uz = factor * gz;
@@ -107,9 +108,9 @@ __global__ void __launch_bounds__(NT) k_demons_force(const float* __restrict__ F
     const size_t ym = y > 0 ? i - sy : i, yp = y < d.ny - 1 ? i + sy : i;
     const size_t zm = z > 0 ? i - sz : i, zp = z < d.nz - 1 ? i + sz : i;
     const float fc = F[i], mc = Mw[i];
-    const float gx = pp_esm_axis(F[xm], F[xp], mc, Mw[xm], Mw[xp], x, d.nx, K.hx, K.ix);
-    const float gy = pp_esm_axis(F[ym], F[yp], mc, Mw[ym], Mw[yp], y, d.ny, K.hy, K.iy);
-    const float gz = pp_esm_axis(F[zm], F[zp], mc, Mw[zm], Mw[zp], z, d.nz, K.hz, K.iz);
+    const float gx = pp_esm_axis(F[xm], F[xp], mc, Mw[xm], Mw[xp], x == 0, x == d.nx - 1, K.hx, K.ix);
+    const float gy = pp_esm_axis(F[ym], F[yp], mc, Mw[ym], Mw[yp], y == 0, y == d.ny - 1, K.hy, K.iy);
+    const float gz = pp_esm_axis(F[zm], F[zp], mc, Mw[zm], Mw[zp], z == 0, z == d.nz - 1, K.hz, K.iz);
     const pp_esm_out o = pp_esm_voxel(K, fc, mc, gx, gy, gz);
     U[i] = o.ux;
     U[N + i] = o.uy;
@@ -175,36 +176,54 @@ unsigned grid_for(size_t work, unsigned cap = 65535u * 4u) {
 // ---------------------------------------------------------------------------------------
 // FUSED kernels.  Tile TX x TY outputs per plane, NT = (TX/4) * TY threads; thread (cx, cy) owns
 // the 4 consecutive x outputs x = tx0 + 4 cx .. +3 of row y = ty0 + cy on every plane of its chunk.
+//
+// Grid: one 1-D launch of 8 * per_xcd blocks.  The dispatcher places block b on XCD b % 8 (observed,
+// used for speed only), so block b takes tile rank (b % 8) * per_xcd + b / 8 in (x fastest, y, z
+// slowest) order: each XCD works through a contiguous run of tiles and the tiles resident on it at
+// any moment are x/y neighbours.  Their 2-voxel halos -- whose 272-B rows straddle four 128-B lines
+// instead of two -- then hit that XCD's L2 instead of being fetched once per XCD from the fabric.
 
 constexpr int TX = 64;
 constexpr int TY = 16;
-static_assert((TX / 4) * TY == NT, "thread layout");
-
-template <int R>
+// OPT = outputs per thread along x (4: 256 threads, float4 rows; 2: 512 threads, float2 rows -- half the
+// registers per thread, twice the waves per CU for the same LDS tile).
+template <int R, int OPT>
 struct fused_geom {
+  static constexpr int NTH = TX * TY / OPT;       // threads per block
+  static constexpr int LX = TX / OPT;             // threads along x
   static constexpr int UW = TX + 2 * R;           // smoothing-input tile width  (x from tx0 - R)
   static constexpr int UH = TY + 2 * R;           // smoothing-input tile height (y from ty0 - R)
   static constexpr int UWP = (UW + 3) / 4 * 4;    // row pitch, keeps rows 16-B aligned
   static constexpr int NU = UW * UH;              // voxels per smoothing-input plane
-  static constexpr int KU = (NU + NT - 1) / NT;   // of which one thread owns at most KU
+  static constexpr int KU = (NU + NTH - 1) / NTH;   // of which one thread owns at most KU
   static constexpr int MW = UW + 2;               // image tile (1 more voxel each side for gradients)
   static constexpr int MH = UH + 2;
   static constexpr int MWP = MW;
   static constexpr int NB = MW * MH - UW * UH;    // border ring elements
   static constexpr int XI = UH * (TX / 4);        // x-pass work items per component
+  // LDS carve (floats): region 1 holds the two image tiles during the force phase and is reused for
+  // the x-pass output afterwards; region 2 holds the raw smoothing input.
+  static constexpr int SZ_IMG = 2 * MH * MWP;
+  static constexpr int SZ_X = 3 * UH * TX;
+  static constexpr int R1 = ((SZ_IMG > SZ_X ? SZ_IMG : SZ_X) + 3) / 4 * 4;
+  static constexpr int SZ_U = 3 * UH * UWP;
+  static constexpr int SMEM = R1 + SZ_U;
+  static_assert(SZ_U * 4 >= 3 * NTH * 8, "region 2 doubles as the reduction buffer");
+  static_assert(NB <= NTH, "border ring must fit one pass");
+  static_assert(MH * MWP < 65536 && UH * UWP < 65536, "packed LDS slots are 16 bit");
 };
 
 // x pass: item (row uy, group cx) reads 4 + 2R inputs of `us` and writes 4 outputs to `xs`.
-template <int R>
+template <int R, int OPT>
 __device__ __forceinline__ void fused_xpass(const float* __restrict__ us /*[3][UH][UWP]*/,
                                             float* __restrict__ xs /*[3][UH][TX]*/, const pp_taps_small& wx) {
-  using G = fused_geom<R>;
-  for (int it = threadIdx.x; it < 3 * G::XI; it += NT) {
+  using G = fused_geom<R, OPT>;
+  for (int it = threadIdx.x; it < 3 * G::XI; it += G::NTH) {
     const int c = it / G::XI;
     const int rem = it - c * G::XI;
     const int uy = rem / (TX / 4);
     const int cx = rem - uy * (TX / 4);
-    const float* src = us + ((size_t)c * G::UH + uy) * G::UWP + 4 * cx;
+    const float* src = us + (c * G::UH + uy) * G::UWP + 4 * cx;
     float in[4 + 2 * R];
 #pragma unroll
     for (int q = 0; q < (4 + 2 * R) / 4; ++q) {
@@ -224,34 +243,42 @@ __device__ __forceinline__ void fused_xpass(const float* __restrict__ us /*[3][U
       for (int k = 0; k < 2 * R + 1; ++k) s = fmaf(wx.w[k], in[j + k], s);
       o[j] = s;
     }
-    *reinterpret_cast<float4*>(xs + ((size_t)c * G::UH + uy) * TX + 4 * cx) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(xs + (c * G::UH + uy) * TX + 4 * cx) = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
-// y pass for this thread's 4 outputs of component c.
-template <int R>
+// y pass for this thread's OPT outputs of component c.
+template <int R, int OPT>
 __device__ __forceinline__ void fused_ypass(const float* __restrict__ xs, int c, int cx, int cy, const pp_taps_small& wy,
-                                            float v[4]) {
-  using G = fused_geom<R>;
-  v[0] = v[1] = v[2] = v[3] = 0.0f;
+                                            float v[OPT]) {
+  using G = fused_geom<R, OPT>;
+#pragma unroll
+  for (int j = 0; j < OPT; ++j) v[j] = 0.0f;
 #pragma unroll
   for (int k = 0; k < 2 * R + 1; ++k) {
-    const float4 a = *reinterpret_cast<const float4*>(xs + ((size_t)c * G::UH + cy + k) * TX + 4 * cx);
-    v[0] = fmaf(wy.w[k], a.x, v[0]);
-    v[1] = fmaf(wy.w[k], a.y, v[1]);
-    v[2] = fmaf(wy.w[k], a.z, v[2]);
-    v[3] = fmaf(wy.w[k], a.w, v[3]);
+    const float* p = xs + (c * G::UH + cy + k) * TX + OPT * cx;
+    if (OPT == 4) {
+      const float4 a = *reinterpret_cast<const float4*>(p);
+      v[0] = fmaf(wy.w[k], a.x, v[0]);
+      v[1] = fmaf(wy.w[k], a.y, v[1]);
+      v[2] = fmaf(wy.w[k], a.z, v[2]);
+      v[3] = fmaf(wy.w[k], a.w, v[3]);
+    } else {
+      const float2 a = *reinterpret_cast<const float2*>(p);
+      v[0] = fmaf(wy.w[k], a.x, v[0]);
+      v[1] = fmaf(wy.w[k], a.y, v[1]);
+    }
   }
 }
 
-template <int R>
+template <int R, int OPT>
 struct zring {
-  float r[3][4][2 * R + 1];
-  __device__ __forceinline__ void push(const float v[3][4]) {
+  float r[3][OPT][2 * R + 1];
+  __device__ __forceinline__ void push(const float v[3][OPT]) {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < OPT; ++j) {
 #pragma unroll
         for (int k = 0; k < 2 * R; ++k) r[c][j][k] = r[c][j][k + 1];
         r[c][j][2 * R] = v[c][j];
@@ -268,56 +295,89 @@ struct zring {
 struct fused_args {
   pp_dims d;
   int zchunk;
+  int gx, gy, gz;   // tile grid
+  int per_xcd;      // ceil(gx * gy * gz / 8)
   pp_taps_small wx, wy, wz;
 };
 
+// Tile of this block (see the grid note above); false for the few surplus blocks of the last XCD run.
+__device__ __forceinline__ bool fused_tile(const fused_args& a, int& tx0, int& ty0, int& z0, unsigned& rank) {
+  const unsigned b = blockIdx.x;
+  const unsigned j = b >> 3;
+  rank = (b & 7u) * (unsigned)a.per_xcd + j;
+  const unsigned T = (unsigned)a.gx * a.gy * a.gz;
+  if (rank >= T) return false;
+  const unsigned tx = rank % a.gx, ty = (rank / a.gx) % a.gy, tz = rank / ((unsigned)a.gx * a.gy);
+  tx0 = (int)tx * TX;
+  ty0 = (int)ty * TY;
+  z0 = (int)tz * a.zchunk;
+  return true;
+}
+
+// per-voxel flags packed beside the LDS slots
+constexpr unsigned F_CNT = 1u, F_XLO = 2u, F_XHI = 4u, F_YLO = 8u, F_YHI = 16u, F_VALID = 32u;
+
 // ---- kernel A: ESM update + 3-D Gaussian of the update ---------------------------------
-template <int R>
-__global__ void __launch_bounds__(NT) k_fused_force_smooth(const float* __restrict__ F, const float* __restrict__ Mw,
+#ifndef PP_FUSED_DEFAULT_OPT
+#define PP_FUSED_DEFAULT_OPT 2
+#endif
+#ifndef PP_A_WAVES
+#define PP_A_WAVES 1
+#endif
+#ifndef PP_B_WAVES
+#define PP_B_WAVES 1
+#endif
+template <int R, int OPT>
+__global__ void __launch_bounds__(TX * TY / OPT, PP_A_WAVES) k_fused_force_smooth(const float* __restrict__ F, const float* __restrict__ Mw,
                                                            float* __restrict__ Us, fused_args a, pp_esm_consts K,
                                                            double* __restrict__ partials, const int* __restrict__ halt) {
-  using G = fused_geom<R>;
-  __shared__ __attribute__((aligned(16))) float s_m[G::MH * G::MWP];        // warped moving, current plane
-  __shared__ __attribute__((aligned(16))) float s_f[G::MH * G::MWP];        // fixed, current plane
-  __shared__ __attribute__((aligned(16))) float s_u[3 * G::UH * G::UWP];    // raw update, current plane
-  __shared__ __attribute__((aligned(16))) float s_x[3 * G::UH * TX];        // after the x pass
-  __shared__ double red[3 * NT];
+  using G = fused_geom<R, OPT>;
+  constexpr int NTH = G::NTH;
+  __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
+  float* const s_m = smem;                      // warped moving, current plane   (force phase)
+  float* const s_f = smem + G::MH * G::MWP;     // fixed, current plane           (force phase)
+  float* const s_x = smem;                      // after the x pass               (smoothing phase)
+  float* const s_u = smem + G::R1;              // raw update, current plane
   if (halt && *halt) return;
+  int tx0, ty0, z0;
+  unsigned rank;
+  if (!fused_tile(a, tx0, ty0, z0, rank)) return;
 
   const pp_dims d = a.d;
   const int t = threadIdx.x;
-  const int cx = t % (TX / 4), cy = t / (TX / 4);
-  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY, z0 = blockIdx.z * a.zchunk;
-  const size_t sy = d.nx, sz = (size_t)d.nx * d.ny;
-  const size_t N = sz * d.nz;
+  const int cx = t % G::LX, cy = t / G::LX;
+  const unsigned sy = d.nx, sz = (unsigned)d.nx * d.ny;   // volumes hold < 2^31 voxels
+  const size_t N = (size_t)sz * d.nz;
 
-  // Owned smoothing-input voxels (ux, uy); image values are always fetched at the clamped
-  // position so that out-of-volume halo slots replicate the edge update (ZeroFluxNeumann).
-  int own_l[G::KU];   // LDS slot in s_m / s_f of the clamped position
-  int own_w[G::KU];   // LDS slot this thread fills in s_m / s_f (its unclamped position)
-  int own_u[G::KU];   // slot in s_u
-  int own_x[G::KU], own_y[G::KU];
-  size_t own_g[G::KU];
-  bool own_cnt[G::KU];
+  // Owned smoothing-input voxels (ux, uy).  Image values are always fetched at the clamped position
+  // so out-of-volume halo slots replicate the edge update (ZeroFluxNeumann on the smoothing input).
+  unsigned slots[G::KU];  // read slot of the clamped position | write slot << 16   (in s_m / s_f)
+  unsigned uflag[G::KU];  // slot in s_u | flags << 16
+  unsigned own_g[G::KU];  // in-plane offset of the clamped position
   float mprev[G::KU], mcur[G::KU], mnext[G::KU], fprev[G::KU], fcur[G::KU], fnext[G::KU];
 #pragma unroll
   for (int k = 0; k < G::KU; ++k) {
-    const int e = t + k * NT;
+    const int e = t + k * NTH;
     const int ee = e < G::NU ? e : 0;
     const int uy = ee / G::UW, ux = ee - uy * G::UW;
     const int xg = tx0 - R + ux, yg = ty0 - R + uy;
     const int xc = pp_clampi(xg, 0, d.nx - 1), yc = pp_clampi(yg, 0, d.ny - 1);
-    own_x[k] = xc;
-    own_y[k] = yc;
-    own_g[k] = (size_t)yc * sy + xc;
-    own_w[k] = (uy + 1) * G::MWP + (ux + 1);
-    own_l[k] = (yc - (ty0 - R - 1)) * G::MWP + (xc - (tx0 - R - 1));
-    own_u[k] = uy * G::UWP + ux;
-    own_cnt[k] = e < G::NU && xg >= tx0 && xg < tx0 + TX && xg < d.nx && yg >= ty0 && yg < ty0 + TY && yg < d.ny;
+    own_g[k] = (unsigned)yc * sy + (unsigned)xc;
+    const unsigned wslot = (unsigned)((uy + 1) * G::MWP + (ux + 1));
+    const unsigned rslot = (unsigned)((yc - (ty0 - R - 1)) * G::MWP + (xc - (tx0 - R - 1)));
+    slots[k] = rslot | (wslot << 16);
+    unsigned fl = 0;
+    if (e < G::NU) fl |= F_VALID;
+    if (e < G::NU && xg >= tx0 && xg < tx0 + TX && xg < d.nx && yg >= ty0 && yg < ty0 + TY && yg < d.ny) fl |= F_CNT;
+    if (xc == 0) fl |= F_XLO;
+    if (xc == d.nx - 1) fl |= F_XHI;
+    if (yc == 0) fl |= F_YLO;
+    if (yc == d.ny - 1) fl |= F_YHI;
+    uflag[k] = (unsigned)(uy * G::UWP + ux) | (fl << 16);
   }
   // Border ring of the image tiles (needed only in-plane): one element per low thread.
   int brd_w = -1;
-  size_t brd_g = 0;
+  unsigned brd_g = 0;
   if (t < G::NB) {
     int my, mx;
     if (t < G::MW) { my = 0; mx = t; }
@@ -325,9 +385,8 @@ __global__ void __launch_bounds__(NT) k_fused_force_smooth(const float* __restri
     else { const int q = t - 2 * G::MW; my = 1 + q / 2; mx = (q & 1) ? G::MW - 1 : 0; }
     const int xc = pp_clampi(tx0 - R - 1 + mx, 0, d.nx - 1), yc = pp_clampi(ty0 - R - 1 + my, 0, d.ny - 1);
     brd_w = my * G::MWP + mx;
-    brd_g = (size_t)yc * sy + xc;
+    brd_g = (unsigned)yc * sy + (unsigned)xc;
   }
-  static_assert(G::NB <= NT, "border ring must fit one pass");
 
   const int zs = z0 - R;                                            // first smoothing-input plane
   const int zo_last = (z0 + a.zchunk - 1 < d.nz - 1) ? z0 + a.zchunk - 1 : d.nz - 1;
@@ -335,6 +394,7 @@ __global__ void __launch_bounds__(NT) k_fused_force_smooth(const float* __restri
   const int zlo = pp_clampi(zs, 0, d.nz - 1);
 
   // prime the z window of the image values at plane zlo
+  float bm = 0.0f, bf = 0.0f;
   {
     const size_t pm = (size_t)pp_clampi(zlo - 1, 0, d.nz - 1) * sz, pc = (size_t)zlo * sz,
                  pn = (size_t)pp_clampi(zlo + 1, 0, d.nz - 1) * sz;
@@ -344,131 +404,153 @@ __global__ void __launch_bounds__(NT) k_fused_force_smooth(const float* __restri
       mcur[k] = Mw[pc + own_g[k]];  fcur[k] = F[pc + own_g[k]];
       mnext[k] = Mw[pn + own_g[k]]; fnext[k] = F[pn + own_g[k]];
     }
+    if (brd_w >= 0) {
+      bm = Mw[pc + brd_g];
+      bf = F[pc + brd_g];
+    }
   }
 
-  zring<R> ring;
-  float v[3][4];
-  double a_ssd = 0.0, a_ssc = 0.0, a_n = 0.0;
+  zring<R, OPT> ring;
+  float v[3][OPT];
+  float a_ssd = 0.0f, a_ssc = 0.0f, a_n = 0.0f;   // <= ~40 terms per thread: fp32 is exact enough, folded in fp64 below
   int zc_done = -1;
 
   for (int zi = zs; zi <= ze; ++zi) {
     const int zc = pp_clampi(zi, 0, d.nz - 1);
     if (zc != zc_done) {
-      // (1) publish the current image plane to LDS; prefetch plane zc + 2 into registers
-      float min_[G::KU], fin_[G::KU];
-      const size_t p2 = (size_t)pp_clampi(zc + 2, 0, d.nz - 1) * sz;
+      // (1) prefetch plane zc + 2 (and the border of zc + 1) into registers, publish plane zc to LDS
+      float min_[G::KU], fin_[G::KU], bm_n = 0.0f, bf_n = 0.0f;
+      {
+        const size_t p2 = (size_t)pp_clampi(zc + 2, 0, d.nz - 1) * sz, p1 = (size_t)pp_clampi(zc + 1, 0, d.nz - 1) * sz;
 #pragma unroll
-      for (int k = 0; k < G::KU; ++k) {
-        min_[k] = Mw[p2 + own_g[k]];
-        fin_[k] = F[p2 + own_g[k]];
+        for (int k = 0; k < G::KU; ++k) {
+          min_[k] = Mw[p2 + own_g[k]];
+          fin_[k] = F[p2 + own_g[k]];
+        }
+        if (brd_w >= 0) {
+          bm_n = Mw[p1 + brd_g];
+          bf_n = F[p1 + brd_g];
+        }
       }
-      __syncthreads();  // previous plane's readers of s_m / s_f / s_x are done
+      __syncthreads();  // the previous plane's y pass has finished reading region 1
 #pragma unroll
       for (int k = 0; k < G::KU; ++k)
-        if (t + k * NT < G::NU) {
-          s_m[own_w[k]] = mcur[k];
-          s_f[own_w[k]] = fcur[k];
+        if ((uflag[k] >> 16) & F_VALID) {
+          s_m[slots[k] >> 16] = mcur[k];
+          s_f[slots[k] >> 16] = fcur[k];
         }
       if (brd_w >= 0) {
-        s_m[brd_w] = Mw[(size_t)zc * sz + brd_g];
-        s_f[brd_w] = F[(size_t)zc * sz + brd_g];
+        s_m[brd_w] = bm;
+        s_f[brd_w] = bf;
       }
       __syncthreads();
       // (2) ESM update at every smoothing-input voxel of this plane
       const bool count_plane = (zc >= z0 && zc <= zo_last);
+      const bool zlo_b = (zc == 0), zhi_b = (zc == d.nz - 1);
 #pragma unroll
-      for (int k = 0; k < G::KU; ++k)
-        if (t + k * NT < G::NU) {
-          const int l = own_l[k];
-          const float gx = pp_esm_axis(s_f[l - 1], s_f[l + 1], mcur[k], s_m[l - 1], s_m[l + 1], own_x[k], d.nx, K.hx, K.ix);
-          const float gy = pp_esm_axis(s_f[l - G::MWP], s_f[l + G::MWP], mcur[k], s_m[l - G::MWP], s_m[l + G::MWP], own_y[k],
-                                       d.ny, K.hy, K.iy);
-          const float gz = pp_esm_axis(fprev[k], fnext[k], mcur[k], mprev[k], mnext[k], zc, d.nz, K.hz, K.iz);
+      for (int k = 0; k < G::KU; ++k) {
+        const unsigned fl = uflag[k] >> 16;
+        if (fl & F_VALID) {
+          const int l = (int)(slots[k] & 0xffffu);
+          const float gx = pp_esm_axis(s_f[l - 1], s_f[l + 1], mcur[k], s_m[l - 1], s_m[l + 1], (fl & F_XLO) != 0,
+                                       (fl & F_XHI) != 0, K.hx, K.ix);
+          const float gy = pp_esm_axis(s_f[l - G::MWP], s_f[l + G::MWP], mcur[k], s_m[l - G::MWP], s_m[l + G::MWP],
+                                       (fl & F_YLO) != 0, (fl & F_YHI) != 0, K.hy, K.iy);
+          const float gz = pp_esm_axis(fprev[k], fnext[k], mcur[k], mprev[k], mnext[k], zlo_b, zhi_b, K.hz, K.iz);
           const pp_esm_out o = pp_esm_voxel(K, fcur[k], mcur[k], gx, gy, gz);
-          s_u[own_u[k]] = o.ux;
-          s_u[G::UH * G::UWP + own_u[k]] = o.uy;
-          s_u[2 * G::UH * G::UWP + own_u[k]] = o.uz;
-          if (count_plane && own_cnt[k]) {
-            a_ssd += (double)o.sq_speed;
-            a_ssc += (double)o.sq_update;
-            a_n += (double)o.counted;
+          const int u = (int)(uflag[k] & 0xffffu);
+          s_u[u] = o.ux;
+          s_u[G::UH * G::UWP + u] = o.uy;
+          s_u[2 * G::UH * G::UWP + u] = o.uz;
+          if (count_plane && (fl & F_CNT)) {
+            a_ssd += o.sq_speed;
+            a_ssc += o.sq_update;
+            a_n += (float)o.counted;
           }
         }
-      __syncthreads();
+      }
+      __syncthreads();  // s_u complete; region 1 (image tiles) is dead from here
       // (3) x pass, (4) y pass
-      fused_xpass<R>(s_u, s_x, a.wx);
+      fused_xpass<R, OPT>(s_u, s_x, a.wx);
       __syncthreads();
 #pragma unroll
-      for (int c = 0; c < 3; ++c) fused_ypass<R>(s_x, c, cx, cy, a.wy, v[c]);
+      for (int c = 0; c < 3; ++c) fused_ypass<R, OPT>(s_x, c, cx, cy, a.wy, v[c]);
       // rotate the z window of the image values
 #pragma unroll
       for (int k = 0; k < G::KU; ++k) {
         mprev[k] = mcur[k]; mcur[k] = mnext[k]; mnext[k] = min_[k];
         fprev[k] = fcur[k]; fcur[k] = fnext[k]; fnext[k] = fin_[k];
       }
+      bm = bm_n;
+      bf = bf_n;
       zc_done = zc;
     }
     // (5) z pass out of the register window (repeated planes re-enter: clamped edge)
     ring.push(v);
     const int zo = zi - R;
     if (zo >= z0 && zo <= zo_last) {
-      const int x = tx0 + 4 * cx, y = ty0 + cy;
+      const int x = tx0 + OPT * cx, y = ty0 + cy;
       if (y < d.ny && x < d.nx) {
         const size_t o = (size_t)zo * sz + (size_t)y * sy + x;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float r0 = ring.dot(c, 0, a.wz), r1 = ring.dot(c, 1, a.wz), r2 = ring.dot(c, 2, a.wz),
-                      r3 = ring.dot(c, 3, a.wz);
-          if ((d.nx & 3) == 0) {
-            *reinterpret_cast<float4*>(Us + c * N + o) = make_float4(r0, r1, r2, r3);
+          float r[OPT];
+#pragma unroll
+          for (int j = 0; j < OPT; ++j) r[j] = ring.dot(c, j, a.wz);
+          if ((d.nx % OPT) == 0) {
+            if (OPT == 4) *reinterpret_cast<float4*>(Us + c * N + o) = make_float4(r[0], r[1], r[2], r[OPT - 1]);
+            else *reinterpret_cast<float2*>(Us + c * N + o) = make_float2(r[0], r[1]);
           } else {
-            Us[c * N + o] = r0;
-            if (x + 1 < d.nx) Us[c * N + o + 1] = r1;
-            if (x + 2 < d.nx) Us[c * N + o + 2] = r2;
-            if (x + 3 < d.nx) Us[c * N + o + 3] = r3;
+#pragma unroll
+            for (int j = 0; j < OPT; ++j)
+              if (x + j < d.nx) Us[c * N + o + j] = r[j];
           }
         }
       }
     }
   }
   __syncthreads();
-  pp_block_sum3<NT>(a_ssd, a_ssc, a_n, red);
+  double r_ssd = (double)a_ssd, r_ssc = (double)a_ssc, r_n = (double)a_n;
+  pp_block_sum3<NTH>(r_ssd, r_ssc, r_n, reinterpret_cast<double*>(s_u));
   if (t == 0) {
-    const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    partials[3 * b + 0] = a_ssd;
-    partials[3 * b + 1] = a_ssc;
-    partials[3 * b + 2] = a_n;
+    partials[3 * (size_t)rank + 0] = r_ssd;
+    partials[3 * (size_t)rank + 1] = r_ssc;
+    partials[3 * (size_t)rank + 2] = r_n;
   }
 }
 
 // ---- kernel B: D' = G_d * (D + U), then the next iteration's warped moving image ------
-template <int R>
-__global__ void __launch_bounds__(NT) k_fused_add_smooth_warp(const float* __restrict__ D, const float* __restrict__ Us,
+template <int R, int OPT>
+__global__ void __launch_bounds__(TX * TY / OPT, PP_B_WAVES) k_fused_add_smooth_warp(const float* __restrict__ D, const float* __restrict__ Us,
                                                               const float* __restrict__ M, float* __restrict__ Dn,
                                                               float* __restrict__ Mw, fused_args a, pp_warp_scale sc,
                                                               const int* __restrict__ halt) {
-  using G = fused_geom<R>;
-  __shared__ __attribute__((aligned(16))) float s_u[3 * G::UH * G::UWP];
-  __shared__ __attribute__((aligned(16))) float s_x[3 * G::UH * TX];
+  using G = fused_geom<R, OPT>;
+  constexpr int NTH = G::NTH;
+  __shared__ __attribute__((aligned(16))) float smem[G::SZ_X + G::SZ_U];
+  float* const s_x = smem;
+  float* const s_u = smem + G::SZ_X;
   if (halt && *halt) return;
+  int tx0, ty0, z0;
+  unsigned rank;
+  if (!fused_tile(a, tx0, ty0, z0, rank)) return;
 
   const pp_dims d = a.d;
   const int t = threadIdx.x;
-  const int cx = t % (TX / 4), cy = t / (TX / 4);
-  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY, z0 = blockIdx.z * a.zchunk;
-  const size_t sy = d.nx, sz = (size_t)d.nx * d.ny;
-  const size_t N = sz * d.nz;
+  const int cx = t % G::LX, cy = t / G::LX;
+  const unsigned sy = d.nx, sz = (unsigned)d.nx * d.ny;
+  const size_t N = (size_t)sz * d.nz;
 
-  int own_u[G::KU];
-  size_t own_g[G::KU];
+  unsigned own_g[G::KU];   // in-plane offset of the clamped position
+  unsigned own_u[G::KU];   // slot in s_u (0xffff....: not owned)
 #pragma unroll
   for (int k = 0; k < G::KU; ++k) {
-    const int e = t + k * NT;
+    const int e = t + k * NTH;
     const int ee = e < G::NU ? e : 0;
     const int uy = ee / G::UW, ux = ee - uy * G::UW;
     const int xc = pp_clampi(tx0 - R + ux, 0, d.nx - 1), yc = pp_clampi(ty0 - R + uy, 0, d.ny - 1);
-    own_g[k] = (size_t)yc * sy + xc;
-    own_u[k] = uy * G::UWP + ux;
+    own_g[k] = (unsigned)yc * sy + (unsigned)xc;
+    own_u[k] = e < G::NU ? (unsigned)(uy * G::UWP + ux) : 0xffffffffu;
   }
 
   const int zs = z0 - R;
@@ -476,60 +558,64 @@ __global__ void __launch_bounds__(NT) k_fused_add_smooth_warp(const float* __res
   const int ze = zo_last + R;
   const int zlo = pp_clampi(zs, 0, d.nz - 1);
 
-  float cur[3][G::KU];
+  // raw D and U of the plane about to be smoothed; summed when published
+  float dl[3][G::KU], ul[3][G::KU];
   {
     const size_t pc = (size_t)zlo * sz;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int k = 0; k < G::KU; ++k) cur[c][k] = D[c * N + pc + own_g[k]] + Us[c * N + pc + own_g[k]];
+      for (int k = 0; k < G::KU; ++k) {
+        dl[c][k] = D[c * N + pc + own_g[k]];
+        ul[c][k] = Us[c * N + pc + own_g[k]];
+      }
   }
 
-  zring<R> ring;
-  float v[3][4];
+  zring<R, OPT> ring;
+  float v[3][OPT];
   int zc_done = -1;
 
   for (int zi = zs; zi <= ze; ++zi) {
     const int zc = pp_clampi(zi, 0, d.nz - 1);
     if (zc != zc_done) {
-      // prefetch the next plane's D + U while this one is smoothed
-      float nxt[3][G::KU];
-      const size_t pn = (size_t)pp_clampi(zc + 1, 0, d.nz - 1) * sz;
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int k = 0; k < G::KU; ++k) nxt[c][k] = D[c * N + pn + own_g[k]] + Us[c * N + pn + own_g[k]];
-      __syncthreads();
+      __syncthreads();  // the previous plane's x pass has finished reading s_u
 #pragma unroll
       for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int k = 0; k < G::KU; ++k)
-          if (t + k * NT < G::NU) s_u[c * G::UH * G::UWP + own_u[k]] = cur[c][k];
+          if (own_u[k] != 0xffffffffu) s_u[c * G::UH * G::UWP + own_u[k]] = dl[c][k] + ul[c][k];
+      // issue the next plane's loads now; they are consumed at the top of the next step
+      {
+        const size_t pn = (size_t)pp_clampi(zc + 1, 0, d.nz - 1) * sz;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int k = 0; k < G::KU; ++k) {
+            dl[c][k] = D[c * N + pn + own_g[k]];
+            ul[c][k] = Us[c * N + pn + own_g[k]];
+          }
+      }
       __syncthreads();
-      fused_xpass<R>(s_u, s_x, a.wx);
+      fused_xpass<R, OPT>(s_u, s_x, a.wx);
       __syncthreads();
 #pragma unroll
-      for (int c = 0; c < 3; ++c) fused_ypass<R>(s_x, c, cx, cy, a.wy, v[c]);
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int k = 0; k < G::KU; ++k) cur[c][k] = nxt[c][k];
+      for (int c = 0; c < 3; ++c) fused_ypass<R, OPT>(s_x, c, cx, cy, a.wy, v[c]);
       zc_done = zc;
     }
     ring.push(v);
     const int zo = zi - R;
     if (zo >= z0 && zo <= zo_last) {
-      const int x = tx0 + 4 * cx, y = ty0 + cy;
+      const int x = tx0 + OPT * cx, y = ty0 + cy;
       if (y < d.ny && x < d.nx) {
         const size_t o = (size_t)zo * sz + (size_t)y * sy + x;
-        float dn[3][4];
+        float dn[3][OPT];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) dn[c][j] = ring.dot(c, j, a.wz);
-        float mw[4];
+          for (int j = 0; j < OPT; ++j) dn[c][j] = ring.dot(c, j, a.wz);
+        float mw[OPT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < OPT; ++j) {
           int bx, by, bz;
           float fx, fy, fz;
           pp_split(x + j, dn[0][j] * sc.ix, bx, fx);
@@ -538,14 +624,20 @@ __global__ void __launch_bounds__(NT) k_fused_add_smooth_warp(const float* __res
           const bool inside = (x + j < d.nx) && pp_inside1(bx, fx, d.nx) && pp_inside1(by, fy, d.ny) && pp_inside1(bz, fz, d.nz);
           mw[j] = inside ? pp_trilinear(M, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz) : FLT_MAX;
         }
-        if ((d.nx & 3) == 0) {
+        if ((d.nx % OPT) == 0) {
+          if (OPT == 4) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c)
-            *reinterpret_cast<float4*>(Dn + c * N + o) = make_float4(dn[c][0], dn[c][1], dn[c][2], dn[c][3]);
-          *reinterpret_cast<float4*>(Mw + o) = make_float4(mw[0], mw[1], mw[2], mw[3]);
+            for (int c = 0; c < 3; ++c)
+              *reinterpret_cast<float4*>(Dn + c * N + o) = make_float4(dn[c][0], dn[c][1], dn[c][2], dn[c][OPT - 1]);
+            *reinterpret_cast<float4*>(Mw + o) = make_float4(mw[0], mw[1], mw[2], mw[OPT - 1]);
+          } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) *reinterpret_cast<float2*>(Dn + c * N + o) = make_float2(dn[c][0], dn[c][1]);
+            *reinterpret_cast<float2*>(Mw + o) = make_float2(mw[0], mw[1]);
+          }
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < OPT; ++j)
             if (x + j < d.nx) {
               Dn[o + j] = dn[0][j];
               Dn[N + o + j] = dn[1][j];
@@ -579,7 +671,9 @@ void esm_consts(const pp_geom* g, const pp_demons_params* p, pp_esm_consts* K) {
     K->has_norm = 0;
   }
   K->denom_thr = (float)p->denominator_threshold;
-  K->intensity_thr = p->intensity_threshold;
+  float thr = (float)p->intensity_threshold;
+  if ((double)thr < p->intensity_threshold) thr = nextafterf(thr, INFINITY);
+  K->intensity_thr = thr;
 }
 
 void small_taps(const pp_taps& t, int R, pp_taps_small* s) {
@@ -587,33 +681,55 @@ void small_taps(const pp_taps& t, int R, pp_taps_small* s) {
   for (int k = -t.r; k <= t.r; ++k) s->w[k + R] = t.w[k + t.r];  // centred; outer taps stay 0
 }
 
-int fused_zchunk(const pp_dims& d) {
-  // enough blocks to fill 256 CUs several times over, chunks long enough to amortise the z halo
+// z-chunk length: long chunks amortise the 2R (+3 image) halo planes, but the launch should fill the
+// chip a whole number of times.  `slots` = resident blocks of the slower kernel (256 CUs x blocks/CU).
+int fused_zchunk(const pp_dims& d, int slots) {
   if (const char* e = getenv("PP_FUSED_ZCHUNK")) {
     const int v = atoi(e);
-    if (v >= 1) return v;
+    if (v >= 1) return v < d.nz ? v : d.nz;
   }
   const int tiles = ((d.nx + TX - 1) / TX) * ((d.ny + TY - 1) / TY);
-  int zc = 32;
-  while (zc > 8 && (size_t)tiles * ((d.nz + zc - 1) / zc) < 2048) zc /= 2;
-  if (zc > d.nz) zc = d.nz;
-  return zc;
+  int best = d.nz < 32 ? d.nz : 32;
+  double best_cost = 1e30;
+  for (int zc = 12; zc <= 64 && zc <= d.nz; ++zc) {
+    const int chunks = (d.nz + zc - 1) / zc;
+    if ((chunks - 1) * zc >= d.nz) continue;
+    const long blocks = (long)tiles * chunks;
+    const long waves = (blocks + slots - 1) / slots;
+    // time ~ (number of block waves) x (planes one block walks, halo included)
+    const double cost = (double)waves * (zc + 7);
+    if (cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best = zc;
+    }
+  }
+  return best;
 }
 
-template <int R>
+template <int R, int OPT>
+int fused_occupancy() {
+  int a = 0, b = 0;
+  constexpr int NTH = TX * TY / OPT;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fused_force_smooth<R, OPT>, NTH, 0) != hipSuccess) a = 2;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_fused_add_smooth_warp<R, OPT>, NTH, 0) != hipSuccess) b = 2;
+  (void)hipGetLastError();
+  int m = a < b ? a : b;
+  return m < 1 ? 1 : m;
+}
+
+template <int R, int OPT>
 int launch_fused_iteration(pp_ctx* ctx, const float* F, const float* M, const float* Mw_in, float* Mw_out, const float* D,
                            float* Dn, float* Us, const fused_args& fu, const fused_args& fd, const pp_esm_consts& K,
                            const pp_warp_scale& sc, double* partials, const int* halt) {
-  const pp_dims& d = fu.d;
-  const dim3 grid((d.nx + TX - 1) / TX, (d.ny + TY - 1) / TY, (d.nz + fu.zchunk - 1) / fu.zchunk), block(NT);
+  const dim3 grid(8u * (unsigned)fu.per_xcd), block(TX * TY / OPT);
   {
     pp_prof_scope ps(ctx, "k_fused_force_smooth");
-    hipLaunchKernelGGL((k_fused_force_smooth<R>), grid, block, 0, ctx->stream, F, Mw_in, Us, fu, K, partials, halt);
+    hipLaunchKernelGGL((k_fused_force_smooth<R, OPT>), grid, block, 0, ctx->stream, F, Mw_in, Us, fu, K, partials, halt);
   }
   PP_LAUNCH_CHECK(ctx, "k_fused_force_smooth");
   {
     pp_prof_scope ps(ctx, "k_fused_add_smooth_warp");
-    hipLaunchKernelGGL((k_fused_add_smooth_warp<R>), grid, block, 0, ctx->stream, D, (const float*)Us, M, Dn, Mw_out, fd, sc, halt);
+    hipLaunchKernelGGL((k_fused_add_smooth_warp<R, OPT>), grid, block, 0, ctx->stream, D, (const float*)Us, M, Dn, Mw_out, fd, sc, halt);
   }
   PP_LAUNCH_CHECK(ctx, "k_fused_add_smooth_warp");
   return PP_OK;
@@ -757,7 +873,17 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   const int R = rmax < 1 ? 1 : rmax;
   fused_args fu, fd;
   fu.d = d;
-  fu.zchunk = fused_zchunk(d);
+  int opt = PP_FUSED_DEFAULT_OPT;
+  if (const char* e = getenv("PP_FUSED_OPT")) opt = atoi(e) == 2 ? 2 : 4;
+  if (opt == 2 && ((d.nx & 1) != 0)) opt = 4;
+  int occ;
+  if (opt == 4) occ = R == 1 ? fused_occupancy<1, 4>() : (R == 2 ? fused_occupancy<2, 4>() : fused_occupancy<3, 4>());
+  else occ = R == 1 ? fused_occupancy<1, 2>() : (R == 2 ? fused_occupancy<2, 2>() : fused_occupancy<3, 2>());
+  fu.zchunk = fused_zchunk(d, 256 * occ);
+  fu.gx = (d.nx + TX - 1) / TX;
+  fu.gy = (d.ny + TY - 1) / TY;
+  fu.gz = (d.nz + fu.zchunk - 1) / fu.zchunk;
+  fu.per_xcd = (int)(((size_t)fu.gx * fu.gy * fu.gz + 7) / 8);
   fd = fu;
   small_taps(tu[0], R, &fu.wx);
   small_taps(tu[1], R, &fu.wy);
@@ -765,7 +891,7 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   small_taps(td[0], R, &fd.wx);
   small_taps(td[1], R, &fd.wy);
   small_taps(td[2], R, &fd.wz);
-  const size_t nblk = (size_t)((d.nx + TX - 1) / TX) * ((d.ny + TY - 1) / TY) * ((d.nz + fu.zchunk - 1) / fu.zchunk);
+  const size_t nblk = (size_t)fu.gx * fu.gy * fu.gz;
   const size_t need = 2 * pp_align_up(N * 4, 256) + 2 * pp_align_up(3 * N * 4, 256) + pp_align_up(3 * nblk * 8, 256) + 256;
   rc = pp_reserve(ctx, need);
   if (rc) return rc;
@@ -785,11 +911,11 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     float* mw_out = (it & 1) ? MwB : MwA;
     const float* Dcur = (it & 1) ? D2 : field;
     float* Dnext = (it & 1) ? field : D2;
-    switch (R) {
-      case 1: rc = launch_fused_iteration<1>(ctx, fixed, moving, mw_in, mw_out, Dcur, Dnext, Us, fu, fd, K, sc, partials, halt); break;
-      case 2: rc = launch_fused_iteration<2>(ctx, fixed, moving, mw_in, mw_out, Dcur, Dnext, Us, fu, fd, K, sc, partials, halt); break;
-      default: rc = launch_fused_iteration<3>(ctx, fixed, moving, mw_in, mw_out, Dcur, Dnext, Us, fu, fd, K, sc, partials, halt); break;
-    }
+#define PP_FUSED_CALL(RR, OO) \
+  launch_fused_iteration<RR, OO>(ctx, fixed, moving, mw_in, mw_out, Dcur, Dnext, Us, fu, fd, K, sc, partials, halt)
+    if (opt == 4) rc = R == 1 ? PP_FUSED_CALL(1, 4) : (R == 2 ? PP_FUSED_CALL(2, 4) : PP_FUSED_CALL(3, 4));
+    else rc = R == 1 ? PP_FUSED_CALL(1, 2) : (R == 2 ? PP_FUSED_CALL(2, 2) : PP_FUSED_CALL(3, 2));
+#undef PP_FUSED_CALL
     if (rc) return rc;
     hipLaunchKernelGGL(k_demons_finalize, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nblk, dst, max_rms);
     PP_LAUNCH_CHECK(ctx, "k_demons_finalize");

@@ -95,6 +95,9 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t
   return hipSuccess;
 }
 
+template <typename K>
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 2; return hipSuccess; }
+
 // ---- device intrinsics subset ------------------------------------------------------
 static inline float atomicAdd(float* p, float v) {
   float o, n;
