@@ -182,9 +182,9 @@ int pp_minmax_f32(pp_ctx* ctx, const float* in, size_t n, float* min_out, float*
  * (label/fusion.py:282-288), in place. */
 int pp_rescale_threshold_f32(pp_ctx* ctx, float* data, size_t n, float in_min, float in_max,
                              float lower);
-/* BinaryThreshold(prob / max >= threshold) -> uint8 (label/fusion.py:305-308) */
-int pp_binary_threshold_f32(pp_ctx* ctx, const float* prob, size_t n, float inv_max,
-                            float threshold, uint8_t* out);
+/* BinaryThreshold(prob / max_value >= threshold) -> uint8 (label/fusion.py:305-308) */
+int pp_binary_threshold_f32(pp_ctx* ctx, const float* prob, size_t n, double max_value,
+                            double threshold, uint8_t* out);
 
 /* ---- linear registration ----------------------------------------------------------- */
 /* One evaluation of itk::MeanSquaresImageToImageMetricv4 + its derivative with respect to

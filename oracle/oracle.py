@@ -488,8 +488,8 @@ def process_probability_image(prob, threshold=0.5):
     from scipy import ndimage
 
     a = prob.arr.astype(np.float32)
-    a = a / a.max()
-    b = a >= np.float32(threshold)
+    a = (a.astype(np.float64) / float(a.max())).astype(np.float32)   # Div functor: fp64 quotient, fp32 pixel
+    b = a.astype(np.float64) >= float(threshold)                       # BinaryThreshold: lower <= pixel
     b = ndimage.binary_fill_holes(b)  # face connectivity background, as BinaryFillhole (fullyConnected=False)
     lab, n = ndimage.label(b)  # face connectivity (fullyConnected=False)
     if n == 0:

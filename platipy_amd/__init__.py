@@ -20,3 +20,4 @@ from .transform import (  # noqa: F401
 __version__ = "0.1.0"
 
 from . import registration  # noqa: E402,F401
+from . import label  # noqa: E402,F401

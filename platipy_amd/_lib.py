@@ -93,7 +93,7 @@ _SIGNATURES = {
     "pp_fuse_divide_f32": (C.c_int, [_P, _P, _P, _P, C.c_size_t]),
     "pp_minmax_f32": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pp_rescale_threshold_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, C.c_float]),
-    "pp_binary_threshold_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P]),
+    "pp_binary_threshold_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_double, C.c_double, _P]),
     "pp_meansq_affine_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int), _P,
                                        C.POINTER(C.c_double)]),
@@ -303,8 +303,8 @@ class Context:
         self._chk(self.lib.pp_rescale_threshold_f32(self.h, ptr(data), int(n), float(in_min), float(in_max), float(lower)),
                   "pp_rescale_threshold_f32")
 
-    def binary_threshold(self, prob, n, inv_max, threshold, out):
-        self._chk(self.lib.pp_binary_threshold_f32(self.h, ptr(prob), int(n), float(inv_max), float(threshold), ptr(out)),
+    def binary_threshold(self, prob, n, max_value, threshold, out):
+        self._chk(self.lib.pp_binary_threshold_f32(self.h, ptr(prob), int(n), float(max_value), float(threshold), ptr(out)),
                   "pp_binary_threshold_f32")
 
     def meansq_affine(self, fixed, fsize, moving, msize, A, b, start, step, mask=None):

@@ -133,10 +133,13 @@ __global__ void __launch_bounds__(NT) k_rescale_threshold(float* __restrict__ da
   }
 }
 
-__global__ void __launch_bounds__(NT) k_binary_threshold(const float* __restrict__ prob, size_t n, float inv_max,
-                                                         float threshold, uint8_t* __restrict__ out) {
-  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT)
-    out[i] = (prob[i] * inv_max >= threshold) ? (uint8_t)1 : (uint8_t)0;
+// sitk image / max (Div functor: fp64 quotient cast to the fp32 pixel) then BinaryThreshold(lower <= pixel).
+__global__ void __launch_bounds__(NT) k_binary_threshold(const float* __restrict__ prob, size_t n, double max_value,
+                                                         double threshold, uint8_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+    const float q = (float)((double)prob[i] / max_value);
+    out[i] = ((double)q >= threshold) ? (uint8_t)1 : (uint8_t)0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -299,10 +302,10 @@ int pp_rescale_threshold_f32(pp_ctx* ctx, float* data, size_t n, float in_min, f
   return PP_OK;
 }
 
-int pp_binary_threshold_f32(pp_ctx* ctx, const float* prob, size_t n, float inv_max, float threshold, uint8_t* out) {
+int pp_binary_threshold_f32(pp_ctx* ctx, const float* prob, size_t n, double max_value, double threshold, uint8_t* out) {
   if (!ctx) return PP_ERR_ARG;
   PP_REQUIRE(ctx, prob && out, "pp_binary_threshold_f32: NULL argument");
-  hipLaunchKernelGGL(k_binary_threshold, dim3(grid_for(n, 65535u)), dim3(NT), 0, ctx->stream, prob, n, inv_max, threshold, out);
+  hipLaunchKernelGGL(k_binary_threshold, dim3(grid_for(n, 65535u)), dim3(NT), 0, ctx->stream, prob, n, max_value, threshold, out);
   PP_LAUNCH_CHECK(ctx, "k_binary_threshold");
   return PP_OK;
 }

@@ -1,0 +1,89 @@
+"""Drop-in label-fusion API (platipy_amd.label.fusion) against the oracle's restatement of
+platipy/imaging/label/fusion.py."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import dice, phantom, smooth_noise
+
+SHAPE, SPACING, ORIGIN = (16, 28, 44), (0.95, 1.05, 2.5), (3.0, -7.0, 11.0)
+
+
+def _atlases(n=4):
+    tgt = phantom(SHAPE, seed=200)
+    out = []
+    for i in range(n):
+        ct = phantom(SHAPE, seed=200, noise=0) + (15 + 10 * i) * smooth_noise(SHAPE, 210 + i).astype(np.float32)
+        lab = (smooth_noise(SHAPE, 220, cells=4) + 0.25 * smooth_noise(SHAPE, 230 + i, cells=5) > 0.1).astype(np.uint8)
+        sub = (smooth_noise(SHAPE, 240, cells=5) + 0.2 * smooth_noise(SHAPE, 250 + i, cells=5) > 0.6).astype(np.uint8)
+        out.append((ct.astype(np.float32), lab, sub))
+    return tgt, out
+
+
+@pytest.mark.parametrize("vote", ["unweighted", "global", "local", "block"])
+def test_compute_weight_map(host_api, vote):
+    pa = host_api
+    tgt, atl = _atlases(1)
+    want = O.compute_weight_map(O.Vol(tgt, SPACING, ORIGIN), O.Vol(atl[0][0], SPACING, ORIGIN), vote).arr
+    got = pa.label.compute_weight_map(pa.image_from_array(tgt, SPACING, ORIGIN), pa.image_from_array(atl[0][0], SPACING, ORIGIN),
+                                      vote_type=vote)
+    assert got.tensor.dtype.is_floating_point and got.GetSize() == (44, 28, 16)
+    # local: fp32 FIR of (T-M)^2 then 1/x; block: box mean then pow(-3); global: fp64 sum
+    rtol = {"unweighted": 0, "global": 1e-6, "local": 3e-5, "block": 2e-4}[vote]
+    np.testing.assert_allclose(got.numpy(), want, rtol=rtol, atol=0)
+    with pytest.raises(NotImplementedError):
+        pa.label.compute_weight_map(pa.image_from_array(tgt, SPACING, ORIGIN), pa.image_from_array(tgt, SPACING, ORIGIN),
+                                    vote_type="patch_correlation")
+    with pytest.raises(ValueError):
+        pa.label.compute_weight_map(pa.image_from_array(tgt, SPACING, ORIGIN), pa.image_from_array(tgt, SPACING, ORIGIN),
+                                    vote_type="nope")
+
+
+def test_combine_labels_and_postprocess(host_api):
+    pa = host_api
+    tgt, atl = _atlases(4)
+    aset_o, aset_g = {}, {}
+    for i, (ct, lab, sub) in enumerate(atl):
+        w = O.compute_weight_map(O.Vol(tgt, SPACING, ORIGIN), O.Vol(ct, SPACING, ORIGIN), "local")
+        cid = f"{i:03d}"
+        aset_o[cid] = {"DIR": {"Weight Map": w, "HEART": O.Vol(lab, SPACING, ORIGIN)}}
+        aset_g[cid] = {"DIR": {"Weight Map": pa.image_from_array(w.arr, SPACING, ORIGIN),
+                               "HEART": pa.image_from_array(lab, SPACING, ORIGIN)}}
+        if i != 2:  # one atlas lacks the sub-structure (fusion.py:251-252)
+            aset_o[cid]["DIR"]["SUB"] = O.Vol(sub, SPACING, ORIGIN)
+            aset_g[cid]["DIR"]["SUB"] = pa.image_from_array(sub, SPACING, ORIGIN)
+    want = O.combine_labels(aset_o, ["HEART", "SUB"])
+    got = pa.label.combine_labels(aset_g, ["HEART", "SUB"])
+    assert set(got) == {"HEART", "SUB"}
+    for k in want:
+        g = got[k].numpy()
+        # fp32 weighted sums (w * L may be contracted to fma on the GPU), divide, 1-voxel blur, rescale
+        np.testing.assert_allclose(g, want[k].arr, rtol=0, atol=5e-6)
+        assert g.max() == 1.0 and g.min() == 0.0
+        assert ((g > 0) & (g < 1e-4)).sum() == 0      # Threshold(lower=1e-4) zeroed the tail
+        wm = O.process_probability_image(want[k], 0.5).arr
+        gm = pa.label.process_probability_image(got[k], 0.5).numpy()
+        assert gm.dtype == np.uint8
+        np.testing.assert_array_equal(gm, wm)          # binary result: bit-exact
+        assert 0 < gm.sum() < gm.size
+    # single structure given as str
+    one = pa.label.combine_labels(aset_g, "HEART")
+    np.testing.assert_array_equal(one["HEART"].numpy(), got["HEART"].numpy())
+    assert dice(pa.label.process_probability_image(one["HEART"]).numpy(), atl[0][1]) > 0.8
+
+
+def test_process_probability_image_edge_cases(host_api):
+    pa = host_api
+    z = np.zeros(SHAPE, np.float32)
+    z[2:5, 3:9, 4:12] = 0.9   # large blob with a hole
+    z[3, 5:7, 6:9] = 0.0
+    z[10:12, 20:22, 30:33] = 1.0  # small, brighter blob
+    want = O.process_probability_image(O.Vol(z, SPACING, ORIGIN), 0.5).arr
+    got = pa.label.process_probability_image(pa.image_from_array(z, SPACING, ORIGIN), 0.5).numpy()
+    np.testing.assert_array_equal(got, want)
+    assert got[3, 5, 7] == 1 and got[10, 20, 30] == 0  # hole filled, small component dropped
+    # nothing above threshold -> the (empty) binary image comes back
+    e = np.full(SHAPE, 0.1, np.float32)
+    e[0, 0, 0] = 1.0
+    got = pa.label.process_probability_image(pa.image_from_array(e, SPACING, ORIGIN), 0.5).numpy()
+    assert got.sum() == 1

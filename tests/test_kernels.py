@@ -348,7 +348,7 @@ def test_weight_map_and_fusion_ops(backend, grid):
     np.testing.assert_allclose(backend.host(prob), want_p, rtol=0, atol=3e-6)
     out = backend.empty(shape, np.uint8)
     lo2, hi2 = ctx.minmax(prob, n)
-    ctx.binary_threshold(prob, n, 1.0 / hi2, 0.5, out)
+    ctx.binary_threshold(prob, n, hi2, 0.5, out)
     b = backend.host(out)
     pr = backend.host(prob)
-    np.testing.assert_array_equal(b, (pr * np.float32(1.0 / hi2) >= np.float32(0.5)).astype(np.uint8))
+    np.testing.assert_array_equal(b, ((pr.astype(np.float64) / hi2).astype(np.float32) >= 0.5).astype(np.uint8))
