@@ -187,15 +187,17 @@ int pp_binary_threshold_f32(pp_ctx* ctx, const float* prob, size_t n, double max
                             double threshold, uint8_t* out);
 
 /* ---- linear registration ----------------------------------------------------------- */
-/* One evaluation of itk::MeanSquaresImageToImageMetricv4 + its derivative with respect to
- * the 12 parameters of an affine map in *index* space (registration/linear.py:141-148,238):
- * for fixed voxels on the lattice {start + k*step}, m = moving(A x + b) trilinear;
- * value = sum (f - m)^2, grad[12] = d value / d(A,b), count = valid samples.
- * result (host, 14 doubles): value, count, grad[12].  Synchronises. */
+/* One evaluation of the mean-squares metric (itk::MeanSquaresImageToImageMetricv4, selected at
+ * registration/linear.py:141-148, evaluated inside registration.Execute at :238) and its gradient
+ * with respect to an affine map in INDEX space.  Sample points: every `stride`-th voxel, raster
+ * order, of a virtual grid vsize (REGULAR sampling, linear.py:152-153).  For virtual index v:
+ * f = trilinear(fixed, Af v + bf), m = trilinear(moving, Am v + bm); samples leaving either buffer or
+ * rejected by a mask (nearest voxel == 0) are skipped.  result (host, 14 doubles):
+ * [0] sum (f-m)^2, [1] count, [2..10] d/dAm (row-major), [11..13] d/dbm.  Synchronises. */
 int pp_meansq_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], const float* moving,
-                         const int msize[3], const double A[9], const double b[3],
-                         const int start[3], const int step[3], const uint8_t* fixed_mask,
-                         double* result);
+                         const int msize[3], const double Af[9], const double bf[3],
+                         const double Am[9], const double bm[3], const int vsize[3], int stride,
+                         const uint8_t* fixed_mask, const uint8_t* moving_mask, double* result);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,69 @@
+"""oracle/linear_oracle.py -- TEST INFRASTRUCTURE ONLY (see oracle/pp_oracle.h; PARITY UNPINNED).
+
+Vectorised fp64 restatement of the mean-squares metric evaluation the product computes in
+pp_meansq_affine_f32: itk::MeanSquaresImageToImageMetricv4 over the regularly sampled virtual domain
+(reference call sites platipy/imaging/registration/linear.py:141-153,238), with the gradient of the
+trilinear interpolant as the moving-image gradient."""
+import numpy as np
+
+
+def _sample(img, c):
+    """img [Z,Y,X]; c [n,3] continuous indices (x,y,z).  -> inside mask, value, gradient wrt index (n,3)."""
+    nz, ny, nx = img.shape
+    n = np.array([nx, ny, nz])
+    inside = np.all((c >= -0.5) & (c < n[None, :] - 0.5), axis=1)
+    cc = np.where(inside[:, None], c, 0.0)
+    fl = np.floor(cc)
+    b = fl.astype(np.int64)
+    i0 = np.maximum(b, 0)
+    i1 = np.minimum(i0 + 1, n[None, :] - 1)
+    w = np.where(b < 0, 0.0, cc - fl)
+    a = img.astype(np.float64)
+
+    def at(ix, iy, iz):
+        return a[iz, iy, ix]
+
+    x0, y0, z0, x1, y1, z1 = i0[:, 0], i0[:, 1], i0[:, 2], i1[:, 0], i1[:, 1], i1[:, 2]
+    a000, a100 = at(x0, y0, z0), at(x1, y0, z0)
+    a010, a110 = at(x0, y1, z0), at(x1, y1, z0)
+    a001, a101 = at(x0, y0, z1), at(x1, y0, z1)
+    a011, a111 = at(x0, y1, z1), at(x1, y1, z1)
+    wx, wy, wz = w[:, 0], w[:, 1], w[:, 2]
+    v00, v10 = a000 + (a100 - a000) * wx, a010 + (a110 - a010) * wx
+    v01, v11 = a001 + (a101 - a001) * wx, a011 + (a111 - a011) * wx
+    v0, v1 = v00 + (v10 - v00) * wy, v01 + (v11 - v01) * wy
+    val = v0 + (v1 - v0) * wz
+    gx0 = (a100 - a000) + ((a110 - a010) - (a100 - a000)) * wy
+    gx1 = (a101 - a001) + ((a111 - a011) - (a101 - a001)) * wy
+    g = np.stack([gx0 + (gx1 - gx0) * wz, (v10 - v00) + ((v11 - v01) - (v10 - v00)) * wz, v1 - v0], axis=1)
+    return inside, val, g
+
+
+def _nn_mask(mask, c):
+    q = np.floor(c + 0.5).astype(np.int64)
+    return mask[q[:, 2], q[:, 1], q[:, 0]] != 0
+
+
+def meansq_affine(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None):
+    """-> 14 floats: sum (f-m)^2, count, d/dAm (row-major 9), d/dbm (3)."""
+    Af, Am = np.asarray(Af, dtype=np.float64).reshape(3, 3), np.asarray(Am, dtype=np.float64).reshape(3, 3)
+    bf, bm = np.asarray(bf, dtype=np.float64), np.asarray(bm, dtype=np.float64)
+    nv = int(vsize[0]) * int(vsize[1]) * int(vsize[2])
+    lin = np.arange(0, nv, int(stride), dtype=np.int64)
+    v = np.stack([lin % vsize[0], (lin // vsize[0]) % vsize[1], lin // (vsize[0] * vsize[1])], axis=1).astype(np.float64)
+    cf, cm = v @ Af.T + bf, v @ Am.T + bm
+    inf_, fval, _ = _sample(np.asarray(fixed), cf)
+    inm, mval, g = _sample(np.asarray(moving), cm)
+    ok = inf_ & inm
+    if fixed_mask is not None:
+        ok &= np.where(inf_, _nn_mask(np.asarray(fixed_mask), np.where(inf_[:, None], cf, 0.0)), False)
+    if moving_mask is not None:
+        ok &= np.where(inm, _nn_mask(np.asarray(moving_mask), np.where(inm[:, None], cm, 0.0)), False)
+    diff = np.where(ok, fval - mval, 0.0)
+    s = (-2.0 * diff)[:, None] * np.where(ok[:, None], g, 0.0)
+    out = np.zeros(14)
+    out[0] = float((diff * diff).sum())
+    out[1] = float(ok.sum())
+    out[2:11] = (s[:, :, None] * v[:, None, :]).sum(0).ravel()
+    out[11:14] = s.sum(0)
+    return out

@@ -11,7 +11,13 @@ from .transform import (  # noqa: F401
     AffineTransform,
     CompositeTransform,
     DisplacementFieldTransform,
+    Euler3DTransform,
+    FullAffineTransform,
+    ScaleTransform,
+    Similarity3DTransform,
     Transform,
+    TranslationTransform,
+    VersorRigid3DTransform,
     sitkBSpline,
     sitkLinear,
     sitkNearestNeighbor,

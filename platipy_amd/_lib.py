@@ -95,8 +95,8 @@ _SIGNATURES = {
     "pp_rescale_threshold_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, C.c_float]),
     "pp_binary_threshold_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_double, C.c_double, _P]),
     "pp_meansq_affine_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double),
-                                       C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int), _P,
-                                       C.POINTER(C.c_double)]),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(C.c_double)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -307,8 +307,10 @@ class Context:
         self._chk(self.lib.pp_binary_threshold_f32(self.h, ptr(prob), int(n), float(max_value), float(threshold), ptr(out)),
                   "pp_binary_threshold_f32")
 
-    def meansq_affine(self, fixed, fsize, moving, msize, A, b, start, step, mask=None):
+    def meansq_affine(self, fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None):
+        """-> (sum sq diff, count, dAm[9], dbm[3]) as a list of 14 floats."""
         res = (C.c_double * 14)()
-        self._chk(self.lib.pp_meansq_affine_f32(self.h, ptr(fixed), _i3(fsize), ptr(moving), _i3(msize), _dn(A, 9), _dn(b, 3),
-                                                _i3(start), _i3(step), ptr(mask), res), "pp_meansq_affine_f32")
+        self._chk(self.lib.pp_meansq_affine_f32(self.h, ptr(fixed), _i3(fsize), ptr(moving), _i3(msize), _dn(Af, 9), _dn(bf, 3),
+                                                _dn(Am, 9), _dn(bm, 3), _i3(vsize), int(stride), ptr(fixed_mask),
+                                                ptr(moving_mask), res), "pp_meansq_affine_f32")
         return [res[i] for i in range(14)]

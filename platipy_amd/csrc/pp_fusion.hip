@@ -143,40 +143,64 @@ __global__ void __launch_bounds__(NT) k_binary_threshold(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------
-// mean-squares metric + gradient w.r.t. an affine index map (12 parameters).
-// sample x = start + k*step (fixed voxel lattice); c = A x + b in moving index space;
-// m = trilinear(moving, c) with the moving gradient taken from the same 8 samples;
-// value = sum (f - m)^2; d value / d A[r][q] = sum -2 (f - m) g_r x_q; d / d b[r] = sum -2 (f - m) g_r.
+// Mean-squares metric and its gradient with respect to an affine map in INDEX space.
+// Sample points are every `stride`-th voxel (raster order, first voxel included) of a virtual
+// grid, as itk::ImageRegistrationMethodv4's REGULAR sampling walks its virtual domain.  For a
+// sample with virtual index v:   f = trilinear(fixed,  Af v + bf),   m = trilinear(moving, Am v + bm),
+// g = gradient of the moving interpolant in moving-index units; samples whose fixed or moving
+// point leaves the buffer (or a mask) are skipped.  Accumulated in fp64:
+//   [0] sum (f-m)^2   [1] count   [2..10] d/dAm[r][q] = sum -2 (f-m) g_r v_q   [11..13] d/dbm[r] = sum -2 (f-m) g_r
 struct msq_args {
-  double A[9], b[3];
-  int start[3], step[3], count[3];
+  double Af[9], bf[3], Am[9], bm[3];
+  int vsize[3];
+  int stride;
 };
 
+__device__ __forceinline__ bool msq_locate(const double c[3], const pp_dims& n, int b[3], float f[3]) {
+  if (!(c[0] >= -0.5 && c[0] < n.nx - 0.5 && c[1] >= -0.5 && c[1] < n.ny - 0.5 && c[2] >= -0.5 && c[2] < n.nz - 0.5)) return false;
+  for (int k = 0; k < 3; ++k) {
+    const double fl = floor(c[k]);
+    b[k] = (int)fl;
+    f[k] = (float)(c[k] - fl);
+  }
+  return true;
+}
+
 __global__ void __launch_bounds__(NT) k_meansq_affine(const float* __restrict__ F, pp_dims df, const float* __restrict__ M,
-                                                      pp_dims dm, const uint8_t* __restrict__ mask, msq_args a,
+                                                      pp_dims dm, const uint8_t* __restrict__ fmask,
+                                                      const uint8_t* __restrict__ mmask, msq_args a,
                                                       double* __restrict__ partials /* [grid][14] */) {
   __shared__ double red[3 * NT];
   double acc[14];
   for (int k = 0; k < 14; ++k) acc[k] = 0.0;
-  const size_t total = (size_t)a.count[0] * a.count[1] * a.count[2];
-  for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
-    const int kx = (int)(e % a.count[0]);
-    const int ky = (int)((e / a.count[0]) % a.count[1]);
-    const int kz = (int)(e / ((size_t)a.count[0] * a.count[1]));
-    const int x = a.start[0] + kx * a.step[0], y = a.start[1] + ky * a.step[1], z = a.start[2] + kz * a.step[2];
-    const size_t fi = ((size_t)z * df.ny + y) * df.nx + x;
-    if (mask && !mask[fi]) continue;
-    const double xd = x, yd = y, zd = z;
-    const double cx = a.A[0] * xd + a.A[1] * yd + a.A[2] * zd + a.b[0];
-    const double cy = a.A[3] * xd + a.A[4] * yd + a.A[5] * zd + a.b[1];
-    const double cz = a.A[6] * xd + a.A[7] * yd + a.A[8] * zd + a.b[2];
-    if (!(cx >= -0.5 && cx < dm.nx - 0.5 && cy >= -0.5 && cy < dm.ny - 0.5 && cz >= -0.5 && cz < dm.nz - 0.5)) continue;
-    const double flx = floor(cx), fly = floor(cy), flz = floor(cz);
+  const size_t nvirt = (size_t)a.vsize[0] * a.vsize[1] * a.vsize[2];
+  const size_t nsamp = (nvirt + a.stride - 1) / a.stride;
+  for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nsamp; e += (size_t)gridDim.x * NT) {
+    const size_t lin = e * (size_t)a.stride;
+    const double v[3] = {(double)(lin % a.vsize[0]), (double)((lin / a.vsize[0]) % a.vsize[1]),
+                         (double)(lin / ((size_t)a.vsize[0] * a.vsize[1]))};
+    double cf[3], cm[3];
+    for (int r = 0; r < 3; ++r) {
+      cf[r] = a.Af[r * 3 + 0] * v[0] + a.Af[r * 3 + 1] * v[1] + a.Af[r * 3 + 2] * v[2] + a.bf[r];
+      cm[r] = a.Am[r * 3 + 0] * v[0] + a.Am[r * 3 + 1] * v[1] + a.Am[r * 3 + 2] * v[2] + a.bm[r];
+    }
+    int bf_[3], bm_[3];
+    float ff[3], fm[3];
+    if (!msq_locate(cf, df, bf_, ff) || !msq_locate(cm, dm, bm_, fm)) continue;
+    if (fmask) {
+      const int qx = (int)floor(cf[0] + 0.5), qy = (int)floor(cf[1] + 0.5), qz = (int)floor(cf[2] + 0.5);
+      if (!fmask[((size_t)qz * df.ny + qy) * df.nx + qx]) continue;
+    }
+    if (mmask) {
+      const int qx = (int)floor(cm[0] + 0.5), qy = (int)floor(cm[1] + 0.5), qz = (int)floor(cm[2] + 0.5);
+      if (!mmask[((size_t)qz * dm.ny + qy) * dm.nx + qx]) continue;
+    }
+    const float fval = pp_trilinear(F, df.nx, df.ny, df.nz, bf_[0], ff[0], bf_[1], ff[1], bf_[2], ff[2]);
     int x0, x1, y0, y1, z0, z1;
     float wx, wy, wz;
-    pp_axis_setup((int)flx, (float)(cx - flx), dm.nx, x0, x1, wx);
-    pp_axis_setup((int)fly, (float)(cy - fly), dm.ny, y0, y1, wy);
-    pp_axis_setup((int)flz, (float)(cz - flz), dm.nz, z0, z1, wz);
+    pp_axis_setup(bm_[0], fm[0], dm.nx, x0, x1, wx);
+    pp_axis_setup(bm_[1], fm[1], dm.ny, y0, y1, wy);
+    pp_axis_setup(bm_[2], fm[2], dm.nz, z0, z1, wz);
     const size_t sy = dm.nx, sz = (size_t)dm.nx * dm.ny;
     const float a000 = M[z0 * sz + y0 * sy + x0], a100 = M[z0 * sz + y0 * sy + x1];
     const float a010 = M[z0 * sz + y1 * sy + x0], a110 = M[z0 * sz + y1 * sy + x1];
@@ -186,21 +210,21 @@ __global__ void __launch_bounds__(NT) k_meansq_affine(const float* __restrict__ 
     const float v01 = a001 + (a101 - a001) * wx, v11 = a011 + (a111 - a011) * wx;
     const float v0 = v00 + (v10 - v00) * wy, v1 = v01 + (v11 - v01) * wy;
     const float m = v0 + (v1 - v0) * wz;
-    // gradient of the trilinear interpolant (per moving voxel)
+    // gradient of the trilinear interpolant, per moving voxel
     const float gx0 = (a100 - a000) + ((a110 - a010) - (a100 - a000)) * wy;
     const float gx1 = (a101 - a001) + ((a111 - a011) - (a101 - a001)) * wy;
     const float gx = gx0 + (gx1 - gx0) * wz;
     const float gy = (v10 - v00) + ((v11 - v01) - (v10 - v00)) * wz;
     const float gz = v1 - v0;
-    const double diff = (double)F[fi] - (double)m;
+    const double diff = (double)fval - (double)m;
     acc[0] += diff * diff;
     acc[1] += 1.0;
     const double s = -2.0 * diff;
     const double g[3] = {s * gx, s * gy, s * gz};
     for (int r = 0; r < 3; ++r) {
-      acc[2 + r * 3 + 0] += g[r] * xd;
-      acc[2 + r * 3 + 1] += g[r] * yd;
-      acc[2 + r * 3 + 2] += g[r] * zd;
+      acc[2 + r * 3 + 0] += g[r] * v[0];
+      acc[2 + r * 3 + 1] += g[r] * v[1];
+      acc[2 + r * 3 + 2] += g[r] * v[2];
       acc[11 + r] += g[r];
     }
   }
@@ -311,27 +335,26 @@ int pp_binary_threshold_f32(pp_ctx* ctx, const float* prob, size_t n, double max
 }
 
 int pp_meansq_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], const float* moving, const int msize[3],
-                         const double A[9], const double b[3], const int start[3], const int step[3],
-                         const uint8_t* fixed_mask, double* result) {
+                         const double Af[9], const double bf[3], const double Am[9], const double bm[3],
+                         const int vsize[3], int stride, const uint8_t* fixed_mask, const uint8_t* moving_mask,
+                         double* result) {
   if (!ctx) return PP_ERR_ARG;
-  PP_REQUIRE(ctx, fixed && fsize && moving && msize && A && b && start && step && result, "pp_meansq_affine_f32: NULL argument");
+  PP_REQUIRE(ctx, fixed && fsize && moving && msize && Af && bf && Am && bm && vsize && result, "pp_meansq_affine_f32: NULL argument");
+  PP_REQUIRE(ctx, stride >= 1 && vsize[0] >= 1 && vsize[1] >= 1 && vsize[2] >= 1, "pp_meansq_affine_f32: bad sampling lattice");
   msq_args a;
-  memcpy(a.A, A, sizeof(a.A));
-  memcpy(a.b, b, sizeof(a.b));
-  size_t total = 1;
-  for (int k = 0; k < 3; ++k) {
-    PP_REQUIRE(ctx, step[k] >= 1 && start[k] >= 0 && start[k] < fsize[k], "pp_meansq_affine_f32: bad lattice");
-    a.start[k] = start[k];
-    a.step[k] = step[k];
-    a.count[k] = (fsize[k] - 1 - start[k]) / step[k] + 1;
-    total *= (size_t)a.count[k];
-  }
+  memcpy(a.Af, Af, sizeof(a.Af));
+  memcpy(a.bf, bf, sizeof(a.bf));
+  memcpy(a.Am, Am, sizeof(a.Am));
+  memcpy(a.bm, bm, sizeof(a.bm));
+  for (int k = 0; k < 3; ++k) a.vsize[k] = vsize[k];
+  a.stride = stride;
+  const size_t nsamp = ((size_t)vsize[0] * vsize[1] * vsize[2] + stride - 1) / stride;
   const pp_dims df{fsize[0], fsize[1], fsize[2]}, dm{msize[0], msize[1], msize[2]};
-  const unsigned nb = grid_for(total, 1024u);
+  const unsigned nb = grid_for(nsamp, 1024u);
   int rc = pp_reserve(ctx, pp_align_up(((size_t)nb * 14 + 14) * sizeof(double), 256));
   if (rc) return rc;
   double* partials = reinterpret_cast<double*>(ctx->ws);
-  hipLaunchKernelGGL(k_meansq_affine, dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, a, partials);
+  hipLaunchKernelGGL(k_meansq_affine, dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, partials);
   PP_LAUNCH_CHECK(ctx, "k_meansq_affine");
   hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, 14, 14, partials + (size_t)nb * 14);
   PP_LAUNCH_CHECK(ctx, "k_sum_final");

@@ -1,5 +1,358 @@
-"""placeholder replaced below"""
+"""Drop-in for platipy/imaging/registration/linear.py:50-260 (linear_registration).
+
+What the reference delegates to ITKv4's ImageRegistrationMethod is rebuilt here around ONE GPU
+kernel: the mean-squares metric and its gradient over the regularly sampled virtual domain
+(pp_meansq_affine_f32, a 14-number fp64 reduction); everything else -- transform models,
+physical-shift parameter scales, learning-rate estimation, gradient descent with ITK's window
+convergence test, optional golden-section line search, L-BFGS-B -- is host arithmetic on <= 12
+parameters, as it is in ITK.
+
+Deliberate, visible deviations from ITK (SURVEY 7 "hard parts": bit parity of the optimiser
+trajectory is not a goal for this stage; it is judged by final metric / transform / Dice):
+  * REGULAR sampling takes every ceil(1/rate)-th voxel of the shrunk fixed grid like ITK but
+    without ITK's seeded sub-voxel jitter of the sample points;
+  * the moving-image gradient is the analytic gradient of the trilinear interpolant, not ITK's
+    Gaussian-derivative-filtered gradient image;
+  * versor parameters are updated additively and re-normalised;
+  * each level returns the best parameters it visited (ITK's returnBestParametersAndValue=True; SimpleITK's
+    default is False).  ITK re-estimates the learning rate at the start of every level so that the first step
+    moves the volume corners by one voxel; when the previous level already converged that first step overshoots,
+    and keeping the best visited point makes the result insensitive to it;
+  * metrics other than "mean_squares" and the "exhaustive" optimiser raise NotImplementedError.
+"""
+import numpy as np
+import torch
+
+from .. import runtime
+from ..image import Image, as_image, cast_tensor
+from ..transform import (
+    AffineTransform,
+    CompositeTransform,
+    Euler3DTransform,
+    FullAffineTransform,
+    ScaleTransform,
+    Similarity3DTransform,
+    TranslationTransform,
+    VersorRigid3DTransform,
+    _Parametrised,
+)
+from .utils import apply_transform, discrete_gaussian
+
+_MODELS = {
+    "translation": TranslationTransform,
+    "similarity": Similarity3DTransform,
+    "affine": FullAffineTransform,
+    "rigid": VersorRigid3DTransform,
+    "scale": ScaleTransform,
+}
 
 
-def linear_registration(*a, **k):
-    raise NotImplementedError
+def _i2p(image):
+    d = np.asarray(image.direction, dtype=np.float64).reshape(3, 3)
+    return d * np.asarray(image.spacing, dtype=np.float64)[None, :]
+
+
+def _p2i(image):
+    return np.linalg.inv(_i2p(image))
+
+
+def centered_transform_initializer(fixed_image, moving_image):
+    """sitk.CenteredTransformInitializer(fixed, moving, Euler3DTransform(), GEOMETRY) (linear.py:129-131):
+    centre of rotation = geometric centre of the fixed image, translation = moving centre - fixed centre."""
+    def centre(img):
+        n = np.asarray(img.GetSize(), dtype=np.float64)
+        return np.asarray(img.origin) + _i2p(img) @ ((n - 1.0) / 2.0)
+
+    t = Euler3DTransform(center=centre(fixed_image))
+    p = np.zeros(6)
+    p[3:6] = centre(moving_image) - centre(fixed_image)
+    t.SetParameters(p)
+    return t
+
+
+def _shrink_geometry(image, factor):
+    """itk::ShrinkImageFilter::GenerateOutputInformation: size floor(n/f), spacing*f, same physical centre."""
+    n = np.asarray(image.GetSize(), dtype=np.float64)
+    f = np.broadcast_to(np.asarray(factor, dtype=np.float64), (3,))
+    size = np.maximum(1, np.floor(n / f)).astype(int)
+    spacing = np.asarray(image.spacing) * f
+    d = np.asarray(image.direction, dtype=np.float64).reshape(3, 3)
+    centre_in = np.asarray(image.origin) + _i2p(image) @ ((n - 1.0) / 2.0)
+    centre_out = np.asarray(image.origin) + (d * spacing[None, :]) @ ((size - 1.0) / 2.0)
+    origin = np.asarray(image.origin) + (centre_in - centre_out)
+    return size, spacing, origin, d
+
+
+class _MeanSquares:
+    """value / gradient of the mean-squares metric for one pyramid level."""
+
+    def __init__(self, ctx, fixed, moving, vsize, vspacing, vorigin, vdir, initial, sampling_rate, fixed_mask, moving_mask):
+        self.ctx = ctx
+        self.fixed, self.moving = fixed, moving
+        self.ft = fixed.tensor.contiguous()
+        self.mt = moving.tensor.contiguous()
+        self.vsize = [int(v) for v in vsize]
+        self.i2p_v = vdir * vspacing[None, :]
+        self.o_v = vorigin
+        self.stride = int(np.ceil(1.0 / sampling_rate)) if sampling_rate < 1.0 else 1   # REGULAR: every ceil(1/p)-th voxel
+        self.initial = initial
+        p2i_f = _p2i(fixed)
+        self.Af = p2i_f @ self.i2p_v
+        self.bf = p2i_f @ (self.o_v - np.asarray(fixed.origin))
+        self.p2i_m = _p2i(moving)
+        self.o_m = np.asarray(moving.origin)
+        self.fmask = None if fixed_mask is None else fixed_mask.tensor.to(torch.uint8).contiguous()
+        self.mmask = None if moving_mask is None else moving_mask.tensor.to(torch.uint8).contiguous()
+        n = np.asarray(self.vsize, dtype=np.float64) - 1.0
+        corners_idx = np.array([[i, j, k] for k in (0.0, n[2]) for j in (0.0, n[1]) for i in (0.0, n[0])])
+        self.corners = self.o_v[None, :] + corners_idx @ self.i2p_v.T     # 8 physical corner points of the virtual domain
+        self.min_spacing = float(np.min(vspacing))
+        self.evaluations = 0
+
+    def total(self, model, params):
+        """(A, off) of initial o model(params): q = A p + off."""
+        A, t = model.decode(params)
+        off = t + model.center - A @ model.center
+        Ai, oi = self.initial.matrix_offset()
+        return Ai @ A, Ai @ off + oi
+
+    def index_map(self, model, params):
+        A, off = self.total(model, params)
+        Am = self.p2i_m @ A @ self.i2p_v
+        bm = self.p2i_m @ (A @ self.o_v + off - self.o_m)
+        return Am, bm
+
+    def raw(self, model, params):
+        Am, bm = self.index_map(model, params)
+        self.evaluations += 1
+        return self.ctx.meansq_affine(self.ft, self.fixed.GetSize(), self.mt, self.moving.GetSize(), self.Af.ravel(), self.bf,
+                                      Am.ravel(), bm, self.vsize, self.stride, self.fmask, self.mmask)
+
+    def value(self, model, params):
+        r = self.raw(model, params)
+        if r[1] <= 0:
+            raise RuntimeError("linear_registration: no valid sample points (images do not overlap)")
+        return r[0] / r[1]
+
+    def value_and_gradient(self, model, params):
+        r = self.raw(model, params)
+        if r[1] <= 0:
+            raise RuntimeError("linear_registration: no valid sample points (images do not overlap)")
+        value = r[0] / r[1]
+        g_idx = np.asarray(r[2:14]) / r[1]              # d value / d (Am row-major, bm)
+        params = np.asarray(params, dtype=np.float64)
+        grad = np.zeros(len(params))
+        for i in range(len(params)):                     # chain rule through params -> (Am, bm), numerically
+            h = 1e-6 * max(1.0, abs(params[i]))
+            pp, pm = params.copy(), params.copy()
+            pp[i] += h
+            pm[i] -= h
+            Ap, bp = self.index_map(model, pp)
+            An, bn = self.index_map(model, pm)
+            d = np.concatenate([(Ap - An).ravel(), bp - bn]) / (2 * h)
+            grad[i] = float(g_idx @ d)
+        return value, grad
+
+    # -- itk::RegistrationParameterScalesFromPhysicalShift over the 8 corners ------------
+    def max_shift(self, model, params, delta):
+        A0, o0 = self.total(model, params)
+        A1, o1 = self.total(model, np.asarray(params) + delta)
+        d = (self.corners @ (A1 - A0).T) + (o1 - o0)[None, :]
+        return float(np.sqrt((d ** 2).sum(1)).max())
+
+    def scales(self, model, params, variation=0.01):
+        n = len(params)
+        s = np.zeros(n)
+        for i in range(n):
+            dlt = np.zeros(n)
+            dlt[i] = variation
+            s[i] = self.max_shift(model, params, dlt)
+        nz = s[s > 1e-12]
+        fill = nz.min() if nz.size else 1.0
+        s[s <= 1e-12] = fill
+        return (s * s) / (variation * variation)
+
+    def step_scale(self, model, params, step, variation=0.01):
+        m = float(np.max(np.abs(step)))
+        if m <= 1e-300:
+            return 0.0
+        factor = variation / m
+        return self.max_shift(model, params, step * factor) / factor
+
+
+def _window_convergence(values, window):
+    """itk::Function::WindowConvergenceMonitoringFunction: slope of a straight-line fit to the last `window`
+    energies, normalised by their total magnitude; returns a large number until the window is full."""
+    if len(values) < window:
+        return float("inf")
+    e = np.asarray(values[-window:], dtype=np.float64)
+    tot = np.abs(e).sum()
+    if tot == 0.0:
+        return 0.0
+    e = e / tot
+    t = np.linspace(0.0, 1.0, window)
+    slope = np.polyfit(t, e, 1)[0]
+    return -float(slope)
+
+
+def _golden_section(f, a, b, c, eps=0.01, max_iter=20):
+    """itk::GradientDescentLineSearchOptimizerv4::GoldenSectionSearch on the learning rate (a < b < c)."""
+    resphi = 2.0 - (1.0 + np.sqrt(5.0)) / 2.0
+    fb = None
+    for _ in range(max_iter):
+        x = b + resphi * (c - b) if (c - b) > (b - a) else b - resphi * (b - a)
+        if abs(c - a) < eps * (abs(b) + abs(x)):
+            return (c + a) / 2.0
+        fx = f(x)
+        if fb is None:
+            fb = f(b)
+        if fx < fb:
+            if (c - b) > (b - a):
+                a, b, fb = b, x, fx
+            else:
+                c, b, fb = b, x, fx
+        else:
+            if (c - b) > (b - a):
+                c = x
+            else:
+                a = x
+    return (c + a) / 2.0
+
+
+def linear_registration(
+    fixed_image,
+    moving_image,
+    fixed_structure=None,
+    moving_structure=None,
+    reg_method="similarity",
+    metric="mean_squares",
+    optimiser="gradient_descent",
+    shrink_factors=[8, 2, 1],
+    smooth_sigmas=[4, 2, 0],
+    sampling_rate=0.25,
+    final_interp=2,
+    number_of_iterations=50,
+    default_value=None,
+    verbose=False,
+):
+    """Initial linear registration between two images (reference registration/linear.py:50-260).
+
+    Returns (registered_image, CompositeTransform([initial_centering_transform, optimised_transform])).
+    """
+    fixed_image, moving_image = as_image(fixed_image), as_image(moving_image)
+    moving_image_type = moving_image.tensor.dtype
+    fixed_image = fixed_image.astype(torch.float32)
+    moving_image = moving_image.astype(torch.float32)
+    ctx = runtime.context(fixed_image.device)
+
+    if metric.lower() != "mean_squares":
+        raise NotImplementedError(f"metric {metric!r}: only 'mean_squares' runs on the HIP path")
+    initial_transform = centered_transform_initializer(fixed_image, moving_image)
+
+    if isinstance(reg_method, str):
+        key = reg_method.lower()
+        if key in ("scaleversor", "scaleskewversor"):
+            raise NotImplementedError(f"reg_method {reg_method!r} is not implemented on the HIP path")
+        if key not in _MODELS:
+            raise ValueError(
+                "You have selected a registration method that does not exist.\n Please select from"
+                " Translation, Similarity, Affine, Rigid, ScaleVersor, ScaleSkewVersor")
+        model = _MODELS[key]()
+    elif isinstance(reg_method, _Parametrised):
+        model = reg_method
+    elif isinstance(reg_method, AffineTransform):
+        model = FullAffineTransform(center=reg_method.center)
+        model.SetParameters(np.concatenate([reg_method.matrix.ravel(), reg_method.translation]))
+    else:
+        raise ValueError("'reg_method' must be either a string (see docs for acceptable registration names), "
+                         "or a transform instance.")
+    opt = optimiser.lower()
+    if opt == "exhaustive":
+        raise NotImplementedError("the 'exhaustive' optimiser is not implemented on the HIP path")
+    if opt not in ("gradient_descent", "gradient_descent_line_search", "lbfgsb"):
+        raise ValueError(f"unknown optimiser {optimiser!r}")
+
+    fixed_mask = as_image(fixed_structure) if fixed_structure is not None else None
+    moving_mask = as_image(moving_structure) if moving_structure is not None else None
+    params = np.asarray(model.GetParameters(), dtype=np.float64)
+
+    for level, (shrink, sigma) in enumerate(zip(shrink_factors, smooth_sigmas)):
+        # ImageRegistrationMethodv4::InitializeRegistrationAtEachLevel: smooth both (physical sigma), shrink the virtual domain
+        f_l = discrete_gaussian(fixed_image, sigma * sigma) if sigma > 0 else fixed_image
+        m_l = discrete_gaussian(moving_image, sigma * sigma) if sigma > 0 else moving_image
+        vsize, vspacing, vorigin, vdir = _shrink_geometry(fixed_image, shrink)
+        ms = _MeanSquares(ctx, f_l, m_l, vsize, vspacing, vorigin, vdir, initial_transform, sampling_rate, fixed_mask, moving_mask)
+
+        if opt == "lbfgsb":
+            from scipy.optimize import fmin_l_bfgs_b
+
+            # optimise in physical-shift units (x = theta * sqrt(scale)) so rotations and translations are commensurate
+            root = np.sqrt(ms.scales(model, params))
+            start_value = ms.value(model, params)
+
+            def fun(x):
+                try:
+                    v, g = ms.value_and_gradient(model, x / root)
+                except RuntimeError:                      # the trial left the overlap
+                    return 10.0 * start_value + 1.0, np.zeros_like(x)
+                return v, g / root
+
+            x, _, _ = fmin_l_bfgs_b(fun, params * root, m=50, factr=1e7, pgtol=1e-5, maxiter=number_of_iterations, maxfun=1024)
+            if ms.value(model, x / root) <= start_value:
+                params = x / root
+            continue
+
+        scales = ms.scales(model, params)
+        learning_rate = 1.0
+        history = []
+        best_value, best_params = float("inf"), params.copy()
+        for it in range(number_of_iterations):
+            try:
+                value, grad = ms.value_and_gradient(model, params)
+            except RuntimeError:
+                if it == 0:
+                    raise
+                break                                           # stepped off the overlap: keep the best point
+            if value < best_value:
+                best_value, best_params = value, params.copy()
+            history.append(value)
+            if verbose:
+                print("{0:3} = {1:10.5f}".format(it, value))
+            if _window_convergence(history, 10) <= 1e-6:
+                break
+            g = grad / scales                                   # ModifyGradientByScales
+            if it == 0:                                         # estimateLearningRate = Once
+                ss = ms.step_scale(model, params, -g)
+                if ss > 1e-300:
+                    learning_rate = ms.min_spacing / ss
+            if opt == "gradient_descent_line_search":
+                base = params.copy()
+
+                def trial(e):
+                    try:
+                        return ms.value(model, base - e * g)
+                    except RuntimeError:
+                        return float("inf")
+
+                lr = _golden_section(trial, 0.0, learning_rate, 5.0 * learning_rate)
+                learning_rate = lr if lr > 0 else learning_rate
+            params = params - learning_rate * g
+        try:
+            last = ms.value(model, params)
+        except RuntimeError:
+            last = float("inf")
+        if last > best_value:
+            params = best_params
+
+    model.SetParameters(params)
+    output_transform = model
+    combined_transform = CompositeTransform([initial_transform, output_transform])     # linear.py:240
+
+    if default_value is None:
+        default_value = 0
+        if float(moving_image.tensor.min()) <= -1000:
+            default_value = -1000
+    registered_image = apply_transform(input_image=moving_image, reference_image=fixed_image, transform=combined_transform,
+                                       default_value=default_value, interpolator=final_interp)
+    registered_image = registered_image.like(cast_tensor(registered_image.tensor, moving_image_type))
+    return registered_image, combined_transform

@@ -81,3 +81,120 @@ class CompositeTransform(Transform):
         for t in self.transforms:
             out.extend(t.flatten() if isinstance(t, CompositeTransform) else [t])
         return out
+
+
+# --------------------------------------------------------------------------------------
+# parametrised linear transforms (the models linear_registration optimises, reference
+# registration/linear.py:166-181).  All are MatrixOffsetTransformBase: q = A (p - c) + c + t.
+
+
+def _versor_matrix(v):
+    x, y, z = (float(a) for a in v)
+    n2 = x * x + y * y + z * z
+    if n2 > 1.0:  # keep the versor valid under additive updates
+        s = 1.0 / np.sqrt(n2)
+        x, y, z = x * s, y * s, z * s
+        n2 = 1.0
+    w = np.sqrt(max(0.0, 1.0 - n2))
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+class _Parametrised(AffineTransform):
+    n_params = 0
+
+    def __init__(self, center=(0.0, 0.0, 0.0)):
+        super().__init__(np.eye(3), (0.0, 0.0, 0.0), center)
+        self.SetParameters(self.identity_parameters())
+
+    def identity_parameters(self):
+        raise NotImplementedError
+
+    def decode(self, params):
+        """-> (A, t) for a parameter vector."""
+        raise NotImplementedError
+
+    def GetParameters(self):
+        return tuple(self._params)
+
+    def SetParameters(self, params):
+        self._params = np.asarray(params, dtype=np.float64).copy()
+        self.matrix, self.translation = self.decode(self._params)
+
+    def GetNumberOfParameters(self):
+        return self.n_params
+
+    def SetCenter(self, c):
+        self.center = np.asarray(c, dtype=np.float64).reshape(3)
+
+
+class TranslationTransform(_Parametrised):
+    n_params = 3
+
+    def identity_parameters(self):
+        return np.zeros(3)
+
+    def decode(self, p):
+        return np.eye(3), np.asarray(p[:3], dtype=np.float64).copy()
+
+
+class VersorRigid3DTransform(_Parametrised):
+    """parameters: versor (x, y, z), translation (3)"""
+    n_params = 6
+
+    def identity_parameters(self):
+        return np.zeros(6)
+
+    def decode(self, p):
+        return _versor_matrix(p[:3]), np.asarray(p[3:6], dtype=np.float64).copy()
+
+
+class Similarity3DTransform(_Parametrised):
+    """parameters: versor (x, y, z), translation (3), isotropic scale"""
+    n_params = 7
+
+    def identity_parameters(self):
+        return np.array([0, 0, 0, 0, 0, 0, 1.0])
+
+    def decode(self, p):
+        return float(p[6]) * _versor_matrix(p[:3]), np.asarray(p[3:6], dtype=np.float64).copy()
+
+
+class ScaleTransform(_Parametrised):
+    n_params = 3
+
+    def identity_parameters(self):
+        return np.ones(3)
+
+    def decode(self, p):
+        return np.diag(np.asarray(p[:3], dtype=np.float64)), np.zeros(3)
+
+
+class FullAffineTransform(_Parametrised):
+    """sitk.AffineTransform(3): parameters = matrix (row-major, 9), translation (3)"""
+    n_params = 12
+
+    def identity_parameters(self):
+        return np.concatenate([np.eye(3).ravel(), np.zeros(3)])
+
+    def decode(self, p):
+        return np.asarray(p[:9], dtype=np.float64).reshape(3, 3).copy(), np.asarray(p[9:12], dtype=np.float64).copy()
+
+
+class Euler3DTransform(_Parametrised):
+    """parameters: angles (x, y, z; ZXY order as ITK's default), translation (3)"""
+    n_params = 6
+
+    def identity_parameters(self):
+        return np.zeros(6)
+
+    def decode(self, p):
+        ax, ay, az = (float(a) for a in p[:3])
+        cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
+        Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        return Rz @ Rx @ Ry, np.asarray(p[3:6], dtype=np.float64).copy()
