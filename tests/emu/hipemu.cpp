@@ -1,12 +1,80 @@
-// tests/emu/hipemu.cpp -- TEST INFRASTRUCTURE ONLY: block/thread scheduler of the CPU HIP
-// stand-in (see include/hip/hip_runtime.h).
+// tests/emu/hipemu.cpp -- TEST INFRASTRUCTURE ONLY: block/thread scheduler of the CPU HIP stand-in
+// (see include/hip/hip_runtime.h).
+//
+// A thread block runs as blockDim cooperative fibers (ucontext) on ONE OS thread: a fiber runs until
+// it reaches __syncthreads() (or returns), then the next fiber runs; when every live fiber has
+// arrived the round restarts.  Blocks are independent, so a pool of OS threads executes different
+// blocks in parallel; `__shared__` is `static thread_local`, i.e. private to the OS thread and thus
+// to the block it is currently running.
 #include <hip/hip_runtime.h>
+#include <ucontext.h>
+
+#include <condition_variable>
+#include <mutex>
 
 namespace hipemu {
 
-thread_local dim3 t_threadIdx, t_blockIdx;
+thread_local Fiber* t_current = nullptr;
 dim3 g_blockDim, g_gridDim;
-pthread_barrier_t* g_barrier = nullptr;
+
+namespace {
+
+constexpr size_t STACK_BYTES = 256 * 1024;
+
+struct Worker {
+  std::vector<Fiber> fibers;
+  std::vector<char*> stacks;
+  ucontext_t sched;
+  const std::function<void()>* body = nullptr;
+};
+
+thread_local Worker* t_worker = nullptr;
+
+void fiber_entry() {
+  Fiber* f = t_current;
+  (*t_worker->body)();
+  f->done = true;
+  swapcontext(&f->ctx, &t_worker->sched);
+}
+
+void run_block(Worker& w, dim3 grid, dim3 block, unsigned long b, const std::function<void()>& body) {
+  const unsigned n = block.x * block.y * block.z;
+  if (w.fibers.size() < n) w.fibers.resize(n);
+  while (w.stacks.size() < n) w.stacks.push_back(static_cast<char*>(malloc(STACK_BYTES)));
+  w.body = &body;
+  t_worker = &w;
+  const dim3 bidx((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((unsigned long)grid.x * grid.y)));
+  for (unsigned t = 0; t < n; ++t) {
+    Fiber& f = w.fibers[t];
+    f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+    f.bid = bidx;
+    f.done = false;
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = w.stacks[t];
+    f.ctx.uc_stack.ss_size = STACK_BYTES;
+    f.ctx.uc_link = &w.sched;
+    makecontext(&f.ctx, fiber_entry, 0);
+  }
+  unsigned live = n;
+  while (live) {
+    // one round: every live fiber runs to its next barrier (or to the end)
+    for (unsigned t = 0; t < n; ++t) {
+      Fiber& f = w.fibers[t];
+      if (f.done) continue;
+      t_current = &f;
+      swapcontext(&w.sched, &f.ctx);
+      if (f.done) --live;
+    }
+  }
+  t_current = nullptr;
+}
+
+}  // namespace
+
+void fiber_yield() {
+  Fiber* f = t_current;
+  swapcontext(&f->ctx, &t_worker->sched);
+}
 
 void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   const unsigned nthreads = block.x * block.y * block.z;
@@ -14,25 +82,30 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   if (nthreads == 0 || nblocks == 0) return;
   g_blockDim = block;
   g_gridDim = grid;
-  pthread_barrier_t bar;
-  pthread_barrier_init(&bar, nullptr, nthreads);
-  g_barrier = &bar;
-  std::vector<std::thread> pool;
-  pool.reserve(nthreads);
-  for (unsigned t = 0; t < nthreads; ++t) {
-    pool.emplace_back([=, &bar, &body]() {
-      t_threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-      for (unsigned long b = 0; b < nblocks; ++b) {
-        t_blockIdx = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y),
-                          (unsigned)(b / ((unsigned long)grid.x * grid.y)));
-        body();
-        pthread_barrier_wait(&bar);  // no thread enters the next block while LDS is in use
-      }
-    });
+  unsigned nworkers = std::thread::hardware_concurrency();
+  if (nworkers < 1) nworkers = 1;
+  if (nworkers > 16) nworkers = 16;
+  if (nworkers > nblocks) nworkers = (unsigned)nblocks;
+  std::atomic<unsigned long> next{0};
+  auto work = [&]() {
+    static thread_local Worker w;  // stacks are reused across launches on pooled threads; fresh threads allocate
+    for (;;) {
+      const unsigned long b = next.fetch_add(1);
+      if (b >= nblocks) break;
+      run_block(w, grid, block, b, body);
+    }
+    for (char* s : w.stacks) free(s);
+    w.stacks.clear();
+    w.fibers.clear();
+  };
+  if (nworkers == 1) {
+    work();
+    return;
   }
+  std::vector<std::thread> pool;
+  pool.reserve(nworkers);
+  for (unsigned i = 0; i < nworkers; ++i) pool.emplace_back(work);
   for (auto& th : pool) th.join();
-  pthread_barrier_destroy(&bar);
-  g_barrier = nullptr;
 }
 
 }  // namespace hipemu

@@ -3,12 +3,13 @@
 // TEST INFRASTRUCTURE ONLY.  A CPU stand-in for the small part of the HIP runtime that
 // platipy_amd/csrc uses, so the *unmodified* kernel sources can be compiled with g++ and
 // their indexing / LDS / barrier logic checked against the oracle in the CPU test suite
-// (there is no GPU in the build container).  Each thread block runs as blockDim real
-// threads with a pthread barrier for __syncthreads(); blocks run one after another.
+// (there is no GPU in the build container).  Each thread block runs as blockDim cooperative
+// fibers on one OS thread (__syncthreads() yields to the next fiber); a pool of OS threads runs
+// different blocks in parallel, and `__shared__` is thread-local to the OS thread, i.e. per block.
 // It is never on the product's include path and nothing under platipy_amd/ refers to it.
 #pragma once
 
-#include <pthread.h>
+#include <ucontext.h>
 
 #include <atomic>
 #include <chrono>
@@ -26,7 +27,7 @@
 #define __host__
 #define __constant__ static
 #define __forceinline__ inline __attribute__((always_inline))
-#define __shared__ static
+#define __shared__ static thread_local
 #define __launch_bounds__(...)
 
 struct dim3 {
@@ -46,18 +47,23 @@ static inline uchar4 make_uchar4(unsigned char a, unsigned char b, unsigned char
 }
 
 namespace hipemu {
-extern thread_local dim3 t_threadIdx, t_blockIdx;
+struct Fiber {
+  ucontext_t ctx;
+  dim3 tid, bid;
+  bool done = false;
+};
+extern thread_local Fiber* t_current;
 extern dim3 g_blockDim, g_gridDim;
-extern pthread_barrier_t* g_barrier;
+void fiber_yield();
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 }  // namespace hipemu
 
-#define threadIdx (::hipemu::t_threadIdx)
-#define blockIdx (::hipemu::t_blockIdx)
+#define threadIdx (::hipemu::t_current->tid)
+#define blockIdx (::hipemu::t_current->bid)
 #define blockDim (::hipemu::g_blockDim)
 #define gridDim (::hipemu::g_gridDim)
 
-static inline void __syncthreads() { pthread_barrier_wait(::hipemu::g_barrier); }
+static inline void __syncthreads() { ::hipemu::fiber_yield(); }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   ::hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })

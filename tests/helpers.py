@@ -106,3 +106,39 @@ def dice(a, b):
     a = a > 0
     b = b > 0
     return 2.0 * (a & b).sum() / max(1, a.sum() + b.sum())
+
+
+def install_emu_runtime(setattr_fn=None):
+    """TEST PLUMBING: point platipy_amd's context lookup at the CPU-emulated kernels (tensors stay on the host).
+    linear_registration evaluates the metric thousands of times; emulating each 256-thread reduction launch
+    thread-by-thread is too slow for the CPU suite, so here (only) the metric evaluation is the oracle's vectorised
+    restatement -- the kernel itself is compared with it in tests/test_linear.py::test_meansq_kernel_*.
+    `setattr_fn(obj, name, value)` defaults to plain setattr (used by spawned worker processes)."""
+    import torch
+
+    from oracle import linear_oracle
+    from platipy_amd import runtime
+
+    be = EmuBackend()
+    sa = setattr_fn or setattr
+    sa(runtime, "context", lambda device=None: be.ctx)
+    sa(runtime, "default_device", lambda: torch.device("cpu"))
+
+    def fake_meansq(fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None):
+        tn = lambda t: None if t is None else t.numpy()  # noqa: E731
+        return list(linear_oracle.meansq_affine(fixed.numpy(), moving.numpy(), Af, bf, Am, bm, vsize, stride, tn(fixed_mask),
+                                                tn(moving_mask)))
+
+    sa(be.ctx, "meansq_affine", fake_meansq)
+    return be
+
+
+def sphere_case(i, shape=(30, 64, 64)):
+    """The reference's synthetic cardiac case i (platipy/imaging/tests/test_cardiac.py:43-71) at half size:
+    a -1000 volume holding a sphere of value 1, its mask, a small sub-structure, slightly different spacing."""
+    nz, ny, nx = shape
+    zz, yy, xx = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    m = (zz - (nz // 2 + i)) ** 2 + (yy - (ny // 2 + i)) ** 2 + (xx - nx // 2) ** 2 <= (nx * 25 // 128) ** 2
+    sub = (zz - (nz // 2 + i)) ** 2 + (yy - (ny // 2 - 2 + i)) ** 2 + (xx - (nx // 2 - 2)) ** 2 <= (nx * 5 // 128 + 1) ** 2
+    ct = np.where(m, 1.0, -1000.0).astype(np.float32)
+    return ct, m.astype(np.uint8), sub.astype(np.uint8), (0.9 + i * 0.01, 0.9 + i * 0.01, 2.5 + i * 0.01)

@@ -1,0 +1,108 @@
+"""Multi-atlas segmentation harness (platipy_amd.projects.multiatlas.run_segmentation) on the reference's own
+acceptance data -- synthetic spheres, Dice of the fused whole-heart contour (platipy/imaging/tests/test_cardiac.py:142
+asserts > 0.99 at full size with its full settings; this half-size, short-schedule CPU run asserts > 0.93) -- and the
+world_size-2 `gloo` run of the same job: one atlas chain per rank, ONE all_reduce for the fusion."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import dice, sphere_case
+
+ORIGIN = (320.0, -52.0, 60.0)
+
+
+def _settings(ids):
+    from platipy_amd.projects.multiatlas import MUTLIATLAS_SETTINGS_DEFAULTS
+
+    s = copy.deepcopy(MUTLIATLAS_SETTINGS_DEFAULTS)
+    s["atlas_settings"]["atlas_id_list"] = ids
+    s["atlas_settings"]["atlas_structure_list"] = ["WHOLEHEART", "SUBSTRUCTURE"]
+    s["auto_crop_target_image_settings"]["expansion_mm"] = [8, 8, 10]
+    s["linear_registration_settings"].update({"shrink_factors": [4, 2], "smooth_sigmas": [0, 0], "number_of_iterations": 20,
+                                              "reg_method": "similarity"})
+    s["deformable_registration_settings"].update({"isotropic_resample": False, "resolution_staging": [4, 2, 1],
+                                                  "iteration_staging": [8, 8, 8], "smoothing_sigmas": [0, 0, 0]})
+    s["label_fusion_settings"]["vote_type"] = "local"
+    return s
+
+
+def _data(pa, ids):
+    atlases = {}
+    for k, cid in enumerate(ids):
+        ct, m, sub, sp = sphere_case(k)
+        atlases[cid] = {"CT Image": pa.image_from_array(ct, sp, ORIGIN), "WHOLEHEART": pa.image_from_array(m, sp, ORIGIN),
+                        "SUBSTRUCTURE": pa.image_from_array(sub, sp, ORIGIN)}
+    ct, m, sub, sp = sphere_case(4)
+    return pa.image_from_array(ct, sp, ORIGIN), m, sub, atlases
+
+
+def test_run_segmentation_sphere_fixture(host_api):
+    pa = host_api
+    ids = ["001", "002", "003"]
+    target, tmask, tsub, atlases = _data(pa, ids)
+    streams = 2 if target.device.type == "cuda" else 1
+    results, prob = pa.projects.multiatlas.run_segmentation(target, _settings(ids), atlases=atlases, streams_per_gpu=streams)
+    assert set(results) == {"WHOLEHEART", "SUBSTRUCTURE"}
+    wh = results["WHOLEHEART"]
+    assert wh.GetSize() == target.GetSize() and wh.tensor.dtype == torch.uint8
+    assert prob["WHOLEHEART"].GetSize() == target.GetSize()
+    d = dice(wh.numpy(), tmask)
+    assert d > 0.93, d
+    assert dice(results["SUBSTRUCTURE"].numpy(), tsub) > 0.5
+    p = prob["WHOLEHEART"].numpy()
+    assert 0.0 <= p.min() and p.max() <= 1.0
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world)})
+    import torch.distributed as dist
+
+    import platipy_amd as pa
+    from tests.helpers import install_emu_runtime
+
+    install_emu_runtime()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ids = ["001", "002", "003"]
+        target, _, _, atlases = _data(pa, ids)
+        mine = {k: v for k, v in atlases.items() if k in ids[rank::world]}   # a rank only needs its own share
+        results, prob = pa.projects.multiatlas.run_segmentation(target, _settings(ids), atlases=mine)
+        np.save(os.path.join(out_dir, f"wh_{rank}.npy"), results["WHOLEHEART"].numpy())
+        np.save(os.path.join(out_dir, f"prob_{rank}.npy"), prob["WHOLEHEART"].numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_run_segmentation_two_ranks_gloo(tmp_path):
+    """world_size 2 over gloo on the CPU: ranks split the atlases, the fusion all_reduce makes every rank hold the
+    same result, and that result equals the single-process run (fp32 sums in a different order: probabilities within
+    1e-5, masks identical)."""
+    import torch.multiprocessing as mp
+
+    import platipy_amd as pa
+    from tests.helpers import install_emu_runtime
+
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    wh0, wh1 = np.load(tmp_path / "wh_0.npy"), np.load(tmp_path / "wh_1.npy")
+    p0, p1 = np.load(tmp_path / "prob_0.npy"), np.load(tmp_path / "prob_1.npy")
+    np.testing.assert_array_equal(wh0, wh1)
+    np.testing.assert_array_equal(p0, p1)
+    # single-process reference
+    from platipy_amd import runtime
+
+    saved = (runtime.context, runtime.default_device)
+    try:
+        install_emu_runtime()
+        ids = ["001", "002", "003"]
+        target, tmask, _, atlases = _data(pa, ids)
+        results, prob = pa.projects.multiatlas.run_segmentation(target, _settings(ids), atlases=atlases)
+    finally:
+        runtime.context, runtime.default_device = saved
+    np.testing.assert_allclose(p0, prob["WHOLEHEART"].numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(wh0, results["WHOLEHEART"].numpy())
+    assert dice(wh0, tmask) > 0.93
