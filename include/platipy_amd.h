@@ -186,6 +186,13 @@ int pp_rescale_threshold_f32(pp_ctx* ctx, float* data, size_t n, float in_min, f
 int pp_binary_threshold_f32(pp_ctx* ctx, const float* prob, size_t n, double max_value,
                             double threshold, uint8_t* out);
 
+/* BinaryFillhole -> ConnectedComponent -> keep the largest component (label/fusion.py:310-328), face
+ * connectivity.  `in`/`out` are uint8 masks (non-zero = foreground); fill_holes = 0 skips the hole filling.
+ * If there is no foreground the (filled) input comes back, as the reference returns its binary image.
+ * component_voxels (host, may be NULL) receives the size of the kept component; non-NULL synchronises. */
+int pp_fillhole_largest_component_u8(pp_ctx* ctx, const uint8_t* in, const int size[3], int fill_holes,
+                                     uint8_t* out, int64_t* component_voxels);
+
 /* ---- linear registration ----------------------------------------------------------- */
 /* One evaluation of the mean-squares metric (itk::MeanSquaresImageToImageMetricv4, selected at
  * registration/linear.py:141-148, evaluated inside registration.Execute at :238) and its gradient

@@ -94,6 +94,7 @@ _SIGNATURES = {
     "pp_minmax_f32": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pp_rescale_threshold_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, C.c_float]),
     "pp_binary_threshold_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_double, C.c_double, _P]),
+    "pp_fillhole_largest_component_u8": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.c_int, _P, C.POINTER(C.c_int64)]),
     "pp_meansq_affine_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                        C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(C.c_double)]),
@@ -306,6 +307,12 @@ class Context:
     def binary_threshold(self, prob, n, max_value, threshold, out):
         self._chk(self.lib.pp_binary_threshold_f32(self.h, ptr(prob), int(n), float(max_value), float(threshold), ptr(out)),
                   "pp_binary_threshold_f32")
+
+    def fillhole_largest_component(self, mask, size, out, fill_holes=True, want_count=False):
+        n = C.c_int64(0)
+        self._chk(self.lib.pp_fillhole_largest_component_u8(self.h, ptr(mask), _i3(size), int(bool(fill_holes)), ptr(out),
+                                                            C.byref(n) if want_count else None), "pp_fillhole_largest_component_u8")
+        return n.value if want_count else None
 
     def meansq_affine(self, fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None):
         """-> (sum sq diff, count, dAm[9], dbm[3]) as a list of 14 floats."""

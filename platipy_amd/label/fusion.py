@@ -122,10 +122,8 @@ def combine_labels(atlas_set, structure_name, label="DIR", threshold=1e-4, smoot
 
 def process_probability_image(probability_image, threshold=0.5):
     """Generate a mask given a probability image (reference fusion.py:295-328): /max, BinaryThreshold(>= thr),
-    BinaryFillhole, ConnectedComponent, keep the largest component, uint8.  Normalisation and threshold run on
-    the GPU; hole filling and labelling are irregular and run on the host."""
-    from scipy import ndimage
-
+    BinaryFillhole, ConnectedComponent, keep the largest component, uint8 -- all on the GPU (union-find labelling,
+    pp_fillhole_largest_component_u8)."""
     if not isinstance(probability_image, Image):
         probability_image = Image(torch.as_tensor(np.asarray(probability_image)).to(runtime.default_device()))
     ctx = runtime.context(probability_image.device)
@@ -134,14 +132,9 @@ def process_probability_image(probability_image, threshold=0.5):
     _, hi = ctx.minmax(prob, n)
     binary = torch.empty(prob.shape, dtype=torch.uint8, device=prob.device)
     ctx.binary_threshold(prob, n, hi, threshold, binary)
-    b = binary.cpu().numpy().astype(bool)
-    b = ndimage.binary_fill_holes(b)     # face-connected background, as BinaryFillhole(fullyConnected=False)
-    lab, ncomp = ndimage.label(b)        # face connectivity, as ConnectedComponent(fullyConnected=False)
-    if ncomp == 0:
-        return probability_image.like(torch.from_numpy(b.astype(np.uint8)).to(prob.device))
-    counts = np.bincount(lab.ravel())[1:]
-    best = 1 + int(np.argmax(counts))    # first maximal component in raster order, like np.argmax over ITK's labels
-    return probability_image.like(torch.from_numpy((lab == best).astype(np.uint8)).to(prob.device))
+    out = torch.empty_like(binary)
+    ctx.fillhole_largest_component(binary, probability_image.GetSize(), out, fill_holes=True)
+    return probability_image.like(out)
 
 
 def combine_labels_staple(label_list_dict, threshold=1e-4):

@@ -352,3 +352,42 @@ def test_weight_map_and_fusion_ops(backend, grid):
     b = backend.host(out)
     pr = backend.host(prob)
     np.testing.assert_array_equal(b, ((pr.astype(np.float64) / hi2).astype(np.float32) >= 0.5).astype(np.uint8))
+
+
+def test_fillhole_largest_component(backend):
+    """BinaryFillhole -> ConnectedComponent -> largest (fusion.py:310-328) vs scipy, bit-exact."""
+    from scipy import ndimage
+
+    rng = np.random.default_rng(5)
+    for shape, seed in [((12, 20, 37), 1), ((9, 33, 64), 2), ((6, 7, 5), 3)]:
+        base = smooth_noise(shape, 90 + seed, cells=4) > 0.15
+        m = base.copy()
+        holes = rng.random(shape) < 0.04
+        m &= ~holes                                   # punch holes (some open to the border, some enclosed)
+        m |= rng.random(shape) < 0.01                 # specks: extra small components
+        m = m.astype(np.uint8)
+        for fill in (True, False):
+            b = m.astype(bool)
+            if fill:
+                b = ndimage.binary_fill_holes(b)
+            lab, ncomp = ndimage.label(b)
+            counts = np.bincount(lab.ravel())[1:]
+            want = (lab == 1 + int(np.argmax(counts))).astype(np.uint8)
+            out = backend.empty(shape, np.uint8)
+            cnt = backend.ctx.fillhole_largest_component(backend.dev(m), (shape[2], shape[1], shape[0]), out, fill_holes=fill,
+                                                         want_count=True)
+            np.testing.assert_array_equal(backend.host(out), want)
+            assert cnt == counts.max()
+    # ties: two equal components -> the first in raster order (np.argmax over ITK's label order)
+    t = np.zeros((4, 6, 10), np.uint8)
+    t[1, 1, 1:4] = 1
+    t[2, 4, 5:8] = 1
+    out = backend.empty(t.shape, np.uint8)
+    backend.ctx.fillhole_largest_component(backend.dev(t), (10, 6, 4), out)
+    want = np.zeros_like(t)
+    want[1, 1, 1:4] = 1
+    np.testing.assert_array_equal(backend.host(out), want)
+    # empty mask: comes back unchanged
+    z = np.zeros((4, 6, 10), np.uint8)
+    backend.ctx.fillhole_largest_component(backend.dev(z), (10, 6, 4), out)
+    assert backend.host(out).sum() == 0

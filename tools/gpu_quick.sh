@@ -8,7 +8,7 @@ timeout 600 python -m pytest tests/test_kernels.py -m gpu -x -q -k "demons" 2>&1
 for zc in ${ZCS:-auto}; do
   if [ "$zc" = "auto" ]; then unset PP_FUSED_ZCHUNK; else export PP_FUSED_ZCHUNK=$zc; fi
   echo "== zchunk $zc"
-  timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-registration 2>&1 | python -c "
+  timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-registration --no-atlas 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     l=l.strip()
