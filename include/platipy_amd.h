@@ -193,6 +193,17 @@ int pp_binary_threshold_f32(pp_ctx* ctx, const float* prob, size_t n, double max
 int pp_fillhole_largest_component_u8(pp_ctx* ctx, const uint8_t* in, const int size[3], int fill_holes,
                                      uint8_t* out, int64_t* component_voxels);
 
+/* ---- iterative atlas removal ------------------------------------------------------- */
+/* sitk.LabelContour(mask) with face connectivity (label/projection.py:85): object voxels that have a face
+ * neighbour of a different value. */
+int pp_label_contour_u8(pp_ctx* ctx, const uint8_t* mask, const int size[3], uint8_t* out);
+/* sitk.SignedMaurerDistanceMap(mask, squaredDistance=False, useImageSpacing=True) (label/projection.py:80-82,
+ * registration/utils.py:288-293): exact Euclidean distance (mm) to the nearest border voxel of the object
+ * (object voxel with background in its 26-neighbourhood), 0 on the border; want_signed = 0 gives the absolute
+ * map, otherwise inside is negative unless inside_positive. */
+int pp_distance_map_f32(pp_ctx* ctx, const uint8_t* mask, const pp_geom* g, int want_signed,
+                        int inside_positive, float* out);
+
 /* ---- linear registration ----------------------------------------------------------- */
 /* One evaluation of the mean-squares metric (itk::MeanSquaresImageToImageMetricv4, selected at
  * registration/linear.py:141-148, evaluated inside registration.Execute at :238) and its gradient

@@ -498,3 +498,74 @@ def process_probability_image(prob, threshold=0.5):
     # ITK labels components in raster order of their first pixel; np.argmax picks the first maximal one
     best = 1 + int(np.argmax(counts))
     return prob.like((lab == best).astype(np.uint8))
+
+
+# --------------------------------------------------------------------------------------
+# platipy/imaging/label/projection.py:67-92 helpers
+
+
+def maurer_distance_map(mask_vol, signed=True, inside_positive=False):
+    """sitk.SignedMaurerDistanceMap(mask, squaredDistance=False, useImageSpacing=True): exact Euclidean distance
+    (mm) to the nearest BORDER voxel of the object -- object voxels with a background voxel in their
+    26-neighbourhood (itkSignedMaurerDistanceMapImageFilter extracts it with BinaryContourImageFilter,
+    FullyConnected on) -- zero on the border, negative inside unless inside_positive."""
+    from scipy import ndimage
+
+    obj = mask_vol.arr != 0
+    bg_near = ndimage.binary_dilation(~obj, structure=np.ones((3, 3, 3), bool))   # voxels outside the image are ignored
+    border = obj & bg_near
+    d = ndimage.distance_transform_edt(~border, sampling=mask_vol.spacing[::-1])
+    if signed:
+        d = np.where(obj != bool(inside_positive), -d, d)
+    return mask_vol.like(d.astype(np.float32))
+
+
+def label_contour(mask_vol):
+    """sitk.LabelContour(mask) (fullyConnected=False): object voxels with a face neighbour of another value."""
+    obj = mask_vol.arr != 0
+    p = np.pad(obj, 1, mode="edge")   # a voxel outside the image never differs
+    diff = np.zeros_like(obj)
+    for ax in range(3):
+        for sh in (0, 2):
+            sl = [slice(1, -1)] * 3
+            sl[ax] = slice(sh, p.shape[ax] - 2 + sh)
+            diff |= p[tuple(sl)] != obj
+    return mask_vol.like((obj & diff).astype(np.uint8))
+
+
+def evaluate_distance_to_reference(reference_volume, test_volume, resample_factor=1):
+    """projection.py:67-92"""
+    d = np.abs(maurer_distance_map(test_volume, signed=True).arr)
+    pts = label_contour(reference_volume).arr == 1
+    return d[pts][::resample_factor]
+
+
+def iar_q_values(atlas_set, reference_structure, label="DIR"):
+    """The per-atlas Q metric of one run_iar pass (iar.py:91-229, MAD statistic, no spherical projection)."""
+    from scipy.optimize import curve_fit
+    from scipy.stats import norm
+
+    ids = list(atlas_set.keys())
+    prob = combine_labels(atlas_set, reference_structure, label=label)[reference_structure]
+    rf = 5 if len(ids) < 12 else 1
+    ref = process_probability_image(prob, 0.95)
+    g = [evaluate_distance_to_reference(ref, process_probability_image(atlas_set[i][label][reference_structure], 0.1), rf) for i in ids]
+    q = {}
+    for k, cid in enumerate(ids):
+        rest = g[:k] + g[k + 1:]
+        med = np.median(rest, axis=0)
+        mad = 1.4826 * np.median(np.abs(rest - np.median(rest, axis=0)), axis=0)
+        if np.any(mad == 0):
+            mad[mad == 0] = np.median(mad)
+        z = np.ravel((g[k] - med) / mad)
+        dens, edges = np.histogram(z, bins=np.linspace(-15, 15, 501), density=True)
+        c = (edges[1:] + edges[:-1]) / 2.0
+        f = lambda x, a, m, s: a * norm.pdf(x, loc=m, scale=s)  # noqa: E731
+        try:
+            popt, _ = curve_fit(f=f, xdata=c, ydata=dens)
+            diff = np.abs(dens - f(c, *popt))
+        except (RuntimeError, ValueError):
+            diff = np.abs(dens - f(c, 1, dens.mean(), dens.std()))
+        trap = np.trapezoid if hasattr(np, "trapezoid") else np.trapz
+        q[cid] = float(trap(diff * np.abs(c) ** 2, c))
+    return q

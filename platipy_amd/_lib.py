@@ -95,6 +95,8 @@ _SIGNATURES = {
     "pp_rescale_threshold_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, C.c_float]),
     "pp_binary_threshold_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_double, C.c_double, _P]),
     "pp_fillhole_largest_component_u8": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.c_int, _P, C.POINTER(C.c_int64)]),
+    "pp_label_contour_u8": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P]),
+    "pp_distance_map_f32": (C.c_int, [_P, _P, C.POINTER(Geom), C.c_int, C.c_int, _P]),
     "pp_meansq_affine_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                        C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(C.c_double)]),
@@ -313,6 +315,13 @@ class Context:
         self._chk(self.lib.pp_fillhole_largest_component_u8(self.h, ptr(mask), _i3(size), int(bool(fill_holes)), ptr(out),
                                                             C.byref(n) if want_count else None), "pp_fillhole_largest_component_u8")
         return n.value if want_count else None
+
+    def label_contour(self, mask, size, out):
+        self._chk(self.lib.pp_label_contour_u8(self.h, ptr(mask), _i3(size), ptr(out)), "pp_label_contour_u8")
+
+    def distance_map(self, mask, geom, out, signed=False, inside_positive=False):
+        self._chk(self.lib.pp_distance_map_f32(self.h, ptr(mask), C.byref(geom), int(bool(signed)), int(bool(inside_positive)),
+                                               ptr(out)), "pp_distance_map_f32")
 
     def meansq_affine(self, fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None):
         """-> (sum sq diff, count, dAm[9], dbm[3]) as a list of 14 floats."""

@@ -391,3 +391,23 @@ def test_fillhole_largest_component(backend):
     z = np.zeros((4, 6, 10), np.uint8)
     backend.ctx.fillhole_largest_component(backend.dev(z), (10, 6, 4), out)
     assert backend.host(out).sum() == 0
+
+
+@pytest.mark.parametrize("grid", GRIDS)
+def test_distance_map_and_contour(backend, grid):
+    """|SignedMaurerDistanceMap| and LabelContour (label/projection.py:80-90): exact EDT vs scipy."""
+    shape, spacing, origin = grid
+    mask = (smooth_noise(shape, 95, cells=4) > 0.2).astype(np.uint8)
+    mask[:, :2, :] = 0
+    mask[3:6, 8:14, 10:20] = 1
+    mask[4, 10, 14] = 0  # interior hole -> extra border voxels
+    g = geom_of(shape, spacing, origin)
+    for signed in (False, True):
+        want = O.maurer_distance_map(O.Vol(mask, spacing, origin), signed=signed).arr
+        out = backend.empty(shape)
+        backend.ctx.distance_map(backend.dev(mask), g, out, signed=signed)
+        # exact EDT; fp32 squares of <= ~120 mm distances
+        np.testing.assert_allclose(backend.host(out), want, rtol=2e-6, atol=2e-5)
+    c = backend.empty(shape, np.uint8)
+    backend.ctx.label_contour(backend.dev(mask), size_of(shape), c)
+    np.testing.assert_array_equal(backend.host(c), O.label_contour(O.Vol(mask, spacing, origin)).arr)
