@@ -13,12 +13,13 @@ so one atlas's small coarse-level kernels overlap another's.  There are exactly 
 fp32 summation order differs from the reference's left fold by a few ulp; thresholded masks are
 insensitive to it except at exact ties.
 
-Atlases are passed in memory ({atlas_id: {"CT Image": Image, "<structure>": Image, ...}}); reading
-NIfTI files is SURVEY 8(f) item 3.  Settings keep the reference's schema (MUTLIATLAS_SETTINGS_DEFAULTS,
-spelling included).
+Atlases are passed in memory ({atlas_id: {"CT Image": Image, "<structure>": Image, ...}}) or, as in the
+reference, read from NIfTI files under settings["atlas_settings"]["atlas_path"] (platipy_amd.io; each rank reads
+only its own share).  Settings keep the reference's schema (MUTLIATLAS_SETTINGS_DEFAULTS, spelling included).
 """
 import copy
 import logging
+import os
 from concurrent.futures import ThreadPoolExecutor
 
 import torch
@@ -34,10 +35,15 @@ from ..utils.crop import crop_to_roi, label_to_roi, paste
 
 logger = logging.getLogger(__name__)
 
+ATLAS_PATH = os.environ.get("ATLAS_PATH", "/atlas")
+
 MUTLIATLAS_SETTINGS_DEFAULTS = {
     "atlas_settings": {
         "atlas_id_list": ["03"],
         "atlas_structure_list": ["WHOLEHEART"],
+        "atlas_path": ATLAS_PATH,
+        "atlas_image_format": "Case_{0}/Images/Case_{0}_CROP.nii.gz",
+        "atlas_label_format": "Case_{0}/Structures/Case_{0}_{1}_CROP.nii.gz",
         "crop_atlas_to_structures": False,
         "crop_atlas_expansion_mm": (20, 20, 40),
     },
@@ -147,8 +153,6 @@ def run_segmentation(img, settings=MUTLIATLAS_SETTINGS_DEFAULTS, atlases=None, s
     holding at least this rank's share (atlas_id_list[rank::world_size]); a rank may hold them all.
     Returns (results, results_prob): {structure: uint8 Image}, {structure: fp32 probability Image}, on every rank.
     """
-    if atlases is None:
-        raise NotImplementedError("pass the atlases in memory (atlases=...): reading NIfTI files is not part of this build")
     img = as_image(img)
     settings = copy.deepcopy(settings)
     dd = _Dist()
@@ -156,6 +160,16 @@ def run_segmentation(img, settings=MUTLIATLAS_SETTINGS_DEFAULTS, atlases=None, s
     atlas_id_list = list(settings["atlas_settings"]["atlas_id_list"])
     atlas_structure_list = list(settings["atlas_settings"]["atlas_structure_list"])
     my_ids = atlas_id_list[dd.rank::dd.world]
+    if atlases is None:     # multiatlas/run.py:155-170: read this rank's atlases from disk
+        from ..io import read_image
+
+        a = settings["atlas_settings"]
+        atlases = {}
+        for atlas_id in my_ids:
+            entry = {"CT Image": read_image(f"{a['atlas_path']}/{a['atlas_image_format'].format(atlas_id)}", device)}
+            for struct in atlas_structure_list:
+                entry[struct] = read_image(f"{a['atlas_path']}/{a['atlas_label_format'].format(atlas_id, struct)}", device)
+            atlases[atlas_id] = entry
 
     # ---- initialisation: optional crop of each atlas to its structures (:172-190) ----
     atlas_set = {}
