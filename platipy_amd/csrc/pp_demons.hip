@@ -48,14 +48,14 @@ struct pp_esm_consts {
 // lo / hi: the voxel is the first / last one along this axis (both set: the axis has one voxel).
 __device__ __forceinline__ float pp_esm_axis(float fm, float fp, float mc, float mm, float mp, bool lo, bool hi, float h,
                                              float inv_sp) {
+  // Branch-free form of ITK's case analysis: a neighbour is usable when it exists and is not the sentinel;
+  // both usable -> central difference, one usable -> one-sided, none -> 0.  Unused candidates may hold
+  // inf (sentinel arithmetic) but are only ever selected away, never blended.
   const float SENT = FLT_MAX;
-  float wg;
-  if (lo && hi) wg = 0.0f;
-  else if (lo) wg = (mp == SENT) ? 0.0f : (mp - mc) * inv_sp;
-  else if (hi) wg = (mm == SENT) ? 0.0f : (mc - mm) * inv_sp;
-  else if (mp == SENT) wg = (mm == SENT) ? 0.0f : (mc - mm) * inv_sp;
-  else if (mm == SENT) wg = (mp - mc) * inv_sp;
-  else wg = (mp - mm) * h;
+  const bool up = !hi && (mp != SENT);
+  const bool um = !lo && (mm != SENT);
+  const float cen = (mp - mm) * h, fwd = (mp - mc) * inv_sp, bwd = (mc - mm) * inv_sp;
+  const float wg = (up && um) ? cen : (up ? fwd : (um ? bwd : 0.0f));
   const float fg = (lo || hi) ? 0.0f : (fp - fm) * h;
   return fg + wg;
 }
@@ -67,25 +67,21 @@ struct pp_esm_out {
 };
 
 __device__ __forceinline__ pp_esm_out pp_esm_voxel(const pp_esm_consts& K, float fc, float mc, float gx, float gy, float gz) {
-  pp_esm_out o;
-  o.ux = o.uy = o.uz = 0.0f;
-  o.sq_speed = o.sq_update = 0.0f;
-  o.counted = 0;
-  if (mc == FLT_MAX) return o;  // mapped outside the moving image: no update, not counted
+  // Straight-line: every guard of ComputeUpdate becomes a select (a zero denominator only feeds a lane whose
+  // result is discarded).  mc == sentinel: no update and the voxel is not counted.
+  const bool mapped = (mc != FLT_MAX);
   const float speed = fc - mc;
   const float g2 = gx * gx + gy * gy + gz * gz;
-  if (!(fabsf(speed) < K.intensity_thr)) {
-    const float denom = K.has_norm ? g2 + speed * speed * K.inv_norm : g2;
-    if (!(denom < K.denom_thr)) {
-      const float factor = __fdividef(2.0f * speed, denom);
-      o.ux = factor * gx;
-      o.uy = factor * gy;
-      o.uz = factor * gz;
-    }
-  }
-  o.sq_speed = speed * speed;
+  const float denom = K.has_norm ? g2 + speed * speed * K.inv_norm : g2;
+  const bool live = mapped && !(fabsf(speed) < K.intensity_thr) && !(denom < K.denom_thr);
+  const float factor = live ? __fdividef(2.0f * speed, denom) : 0.0f;
+  pp_esm_out o;
+  o.ux = live ? factor * gx : 0.0f;
+  o.uy = live ? factor * gy : 0.0f;
+  o.uz = live ? factor * gz : 0.0f;
+  o.sq_speed = mapped ? speed * speed : 0.0f;
   o.sq_update = o.ux * o.ux + o.uy * o.uy + o.uz * o.uz;
-  o.counted = 1;
+  o.counted = mapped ? 1 : 0;
   return o;
 }
 
@@ -314,6 +310,12 @@ __device__ __forceinline__ bool fused_tile(const fused_args& a, int& tx0, int& t
   return true;
 }
 
+// Load through a wave-uniform base pointer plus a 32-bit per-lane BYTE offset: the address form
+// global_load takes directly (scalar base + unsigned VGPR offset), no 64-bit VALU arithmetic.
+__device__ __forceinline__ float ld_off(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)byte_off);
+}
+
 // per-voxel flags packed beside the LDS slots
 constexpr unsigned F_CNT = 1u, F_XLO = 2u, F_XHI = 4u, F_YLO = 8u, F_YHI = 16u, F_VALID = 32u;
 
@@ -353,7 +355,7 @@ __global__ void __launch_bounds__(TX * TY / OPT, PP_A_WAVES) k_fused_force_smoot
   // so out-of-volume halo slots replicate the edge update (ZeroFluxNeumann on the smoothing input).
   unsigned slots[G::KU];  // read slot of the clamped position | write slot << 16   (in s_m / s_f)
   unsigned uflag[G::KU];  // slot in s_u | flags << 16
-  unsigned own_g[G::KU];  // in-plane offset of the clamped position
+  unsigned own_g[G::KU];  // in-plane BYTE offset of the clamped position
   float mprev[G::KU], mcur[G::KU], mnext[G::KU], fprev[G::KU], fcur[G::KU], fnext[G::KU];
 #pragma unroll
   for (int k = 0; k < G::KU; ++k) {
@@ -362,7 +364,7 @@ __global__ void __launch_bounds__(TX * TY / OPT, PP_A_WAVES) k_fused_force_smoot
     const int uy = ee / G::UW, ux = ee - uy * G::UW;
     const int xg = tx0 - R + ux, yg = ty0 - R + uy;
     const int xc = pp_clampi(xg, 0, d.nx - 1), yc = pp_clampi(yg, 0, d.ny - 1);
-    own_g[k] = (unsigned)yc * sy + (unsigned)xc;
+    own_g[k] = ((unsigned)yc * sy + (unsigned)xc) * 4u;
     const unsigned wslot = (unsigned)((uy + 1) * G::MWP + (ux + 1));
     const unsigned rslot = (unsigned)((yc - (ty0 - R - 1)) * G::MWP + (xc - (tx0 - R - 1)));
     slots[k] = rslot | (wslot << 16);
@@ -385,7 +387,7 @@ __global__ void __launch_bounds__(TX * TY / OPT, PP_A_WAVES) k_fused_force_smoot
     else { const int q = t - 2 * G::MW; my = 1 + q / 2; mx = (q & 1) ? G::MW - 1 : 0; }
     const int xc = pp_clampi(tx0 - R - 1 + mx, 0, d.nx - 1), yc = pp_clampi(ty0 - R - 1 + my, 0, d.ny - 1);
     brd_w = my * G::MWP + mx;
-    brd_g = (unsigned)yc * sy + (unsigned)xc;
+    brd_g = ((unsigned)yc * sy + (unsigned)xc) * 4u;
   }
 
   const int zs = z0 - R;                                            // first smoothing-input plane
@@ -400,13 +402,13 @@ __global__ void __launch_bounds__(TX * TY / OPT, PP_A_WAVES) k_fused_force_smoot
                  pn = (size_t)pp_clampi(zlo + 1, 0, d.nz - 1) * sz;
 #pragma unroll
     for (int k = 0; k < G::KU; ++k) {
-      mprev[k] = Mw[pm + own_g[k]]; fprev[k] = F[pm + own_g[k]];
-      mcur[k] = Mw[pc + own_g[k]];  fcur[k] = F[pc + own_g[k]];
-      mnext[k] = Mw[pn + own_g[k]]; fnext[k] = F[pn + own_g[k]];
+      mprev[k] = ld_off(Mw + pm, own_g[k]); fprev[k] = ld_off(F + pm, own_g[k]);
+      mcur[k] = ld_off(Mw + pc, own_g[k]);  fcur[k] = ld_off(F + pc, own_g[k]);
+      mnext[k] = ld_off(Mw + pn, own_g[k]); fnext[k] = ld_off(F + pn, own_g[k]);
     }
     if (brd_w >= 0) {
-      bm = Mw[pc + brd_g];
-      bf = F[pc + brd_g];
+      bm = ld_off(Mw + pc, brd_g);
+      bf = ld_off(F + pc, brd_g);
     }
   }
 
@@ -424,12 +426,12 @@ __global__ void __launch_bounds__(TX * TY / OPT, PP_A_WAVES) k_fused_force_smoot
         const size_t p2 = (size_t)pp_clampi(zc + 2, 0, d.nz - 1) * sz, p1 = (size_t)pp_clampi(zc + 1, 0, d.nz - 1) * sz;
 #pragma unroll
         for (int k = 0; k < G::KU; ++k) {
-          min_[k] = Mw[p2 + own_g[k]];
-          fin_[k] = F[p2 + own_g[k]];
+          min_[k] = ld_off(Mw + p2, own_g[k]);
+          fin_[k] = ld_off(F + p2, own_g[k]);
         }
         if (brd_w >= 0) {
-          bm_n = Mw[p1 + brd_g];
-          bf_n = F[p1 + brd_g];
+          bm_n = ld_off(Mw + p1, brd_g);
+          bf_n = ld_off(F + p1, brd_g);
         }
       }
       __syncthreads();  // the previous plane's y pass has finished reading region 1
@@ -541,7 +543,7 @@ __global__ void __launch_bounds__(TX * TY / OPT, PP_B_WAVES) k_fused_add_smooth_
   const unsigned sy = d.nx, sz = (unsigned)d.nx * d.ny;
   const size_t N = (size_t)sz * d.nz;
 
-  unsigned own_g[G::KU];   // in-plane offset of the clamped position
+  unsigned own_g[G::KU];   // in-plane BYTE offset of the clamped position
   unsigned own_u[G::KU];   // slot in s_u (0xffff....: not owned)
 #pragma unroll
   for (int k = 0; k < G::KU; ++k) {
@@ -549,7 +551,7 @@ __global__ void __launch_bounds__(TX * TY / OPT, PP_B_WAVES) k_fused_add_smooth_
     const int ee = e < G::NU ? e : 0;
     const int uy = ee / G::UW, ux = ee - uy * G::UW;
     const int xc = pp_clampi(tx0 - R + ux, 0, d.nx - 1), yc = pp_clampi(ty0 - R + uy, 0, d.ny - 1);
-    own_g[k] = (unsigned)yc * sy + (unsigned)xc;
+    own_g[k] = ((unsigned)yc * sy + (unsigned)xc) * 4u;
     own_u[k] = e < G::NU ? (unsigned)(uy * G::UWP + ux) : 0xffffffffu;
   }
 
@@ -566,8 +568,8 @@ __global__ void __launch_bounds__(TX * TY / OPT, PP_B_WAVES) k_fused_add_smooth_
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int k = 0; k < G::KU; ++k) {
-        dl[c][k] = D[c * N + pc + own_g[k]];
-        ul[c][k] = Us[c * N + pc + own_g[k]];
+        dl[c][k] = ld_off(D + c * N + pc, own_g[k]);
+        ul[c][k] = ld_off(Us + c * N + pc, own_g[k]);
       }
   }
 
@@ -591,8 +593,8 @@ __global__ void __launch_bounds__(TX * TY / OPT, PP_B_WAVES) k_fused_add_smooth_
         for (int c = 0; c < 3; ++c)
 #pragma unroll
           for (int k = 0; k < G::KU; ++k) {
-            dl[c][k] = D[c * N + pn + own_g[k]];
-            ul[c][k] = Us[c * N + pn + own_g[k]];
+            dl[c][k] = ld_off(D + c * N + pn, own_g[k]);
+            ul[c][k] = ld_off(Us + c * N + pn, own_g[k]);
           }
       }
       __syncthreads();
