@@ -877,7 +877,6 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   fu.d = d;
   int opt = PP_FUSED_DEFAULT_OPT;
   if (const char* e = getenv("PP_FUSED_OPT")) opt = atoi(e) == 2 ? 2 : 4;
-  if (opt == 2 && ((d.nx & 1) != 0)) opt = 4;
   int occ;
   if (opt == 4) occ = R == 1 ? fused_occupancy<1, 4>() : (R == 2 ? fused_occupancy<2, 4>() : fused_occupancy<3, 4>());
   else occ = R == 1 ? fused_occupancy<1, 2>() : (R == 2 ? fused_occupancy<2, 2>() : fused_occupancy<3, 2>());

@@ -240,6 +240,23 @@ __global__ void __launch_bounds__(NT) k_meansq_affine(const float* __restrict__ 
   }
 }
 
+// Fold [count][14] partial rows into 14 sums with one tree (8 barrier steps for all fields at once).
+__global__ void __launch_bounds__(NT) k_sum14_final(const double* __restrict__ partials, int count, double* __restrict__ result) {
+  __shared__ double red[NT * 14];
+  double acc[14];
+  for (int f = 0; f < 14; ++f) acc[f] = 0.0;
+  for (int i = threadIdx.x; i < count; i += NT)
+    for (int f = 0; f < 14; ++f) acc[f] += partials[(size_t)i * 14 + f];
+  for (int f = 0; f < 14; ++f) red[f * NT + threadIdx.x] = acc[f];
+  __syncthreads();
+  for (int s = NT / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+      for (int f = 0; f < 14; ++f) red[f * NT + threadIdx.x] += red[f * NT + threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x < 14) result[threadIdx.x] = red[threadIdx.x * NT];
+}
+
 }  // namespace
 
 extern "C" {
@@ -350,14 +367,14 @@ int pp_meansq_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], co
   a.stride = stride;
   const size_t nsamp = ((size_t)vsize[0] * vsize[1] * vsize[2] + stride - 1) / stride;
   const pp_dims df{fsize[0], fsize[1], fsize[2]}, dm{msize[0], msize[1], msize[2]};
-  const unsigned nb = grid_for(nsamp, 1024u);
+  const unsigned nb = grid_for(nsamp, 512u);
   int rc = pp_reserve(ctx, pp_align_up(((size_t)nb * 14 + 14) * sizeof(double), 256));
   if (rc) return rc;
   double* partials = reinterpret_cast<double*>(ctx->ws);
   hipLaunchKernelGGL(k_meansq_affine, dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, partials);
   PP_LAUNCH_CHECK(ctx, "k_meansq_affine");
-  hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, 14, 14, partials + (size_t)nb * 14);
-  PP_LAUNCH_CHECK(ctx, "k_sum_final");
+  hipLaunchKernelGGL(k_sum14_final, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, partials + (size_t)nb * 14);
+  PP_LAUNCH_CHECK(ctx, "k_sum14_final");
   PP_HIP(ctx, hipMemcpyAsync(result, partials + (size_t)nb * 14, 14 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PP_OK;

@@ -96,6 +96,7 @@ class _MeanSquares:
         self.o_v = vorigin
         self.stride = int(np.ceil(1.0 / sampling_rate)) if sampling_rate < 1.0 else 1   # REGULAR: every ceil(1/p)-th voxel
         self.initial = initial
+        self.Ai, self.oi = initial.matrix_offset()
         p2i_f = _p2i(fixed)
         self.Af = p2i_f @ self.i2p_v
         self.bf = p2i_f @ (self.o_v - np.asarray(fixed.origin))
@@ -113,8 +114,7 @@ class _MeanSquares:
         """(A, off) of initial o model(params): q = A p + off."""
         A, t = model.decode(params)
         off = t + model.center - A @ model.center
-        Ai, oi = self.initial.matrix_offset()
-        return Ai @ A, Ai @ off + oi
+        return self.Ai @ A, self.Ai @ off + self.oi
 
     def index_map(self, model, params):
         A, off = self.total(model, params)
