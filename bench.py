@@ -187,13 +187,18 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("PP_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" only to smoke-test the N > 1 path
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     nx, ny, nz = args.size
     shape, spacing = (nz, ny, nx), (1.0, 1.0, 1.0)
@@ -214,6 +219,11 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def max_over_ranks(x):
+        tt = torch.tensor([x], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     if args.warmup > 0:
         p.iterations = args.warmup
         ctx.demons_execute(fixed, moving, geom, p, field, want_stats=False)
@@ -230,9 +240,7 @@ def main():
     prof = ctx.profile_read()
     ctx.profile_enable(False)
     if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = max_over_ranks(dt)
 
     out = None
     if rank == 0:
@@ -297,9 +305,7 @@ def main():
         try:
             dt_a, nvox_label = multi_atlas_leg(ctx, fixed, moving, spacing, rank, world, device)
             if world > 1:
-                tt = torch.tensor([dt_a], device=device, dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt_a = float(tt.item())
+                dt_a = max_over_ranks(dt_a)
             if rank == 0:
                 out["multi_atlas"] = {"atlases": world, "atlases_per_gpu": 1, "structures": 1, "seconds": dt_a,
                                       "atlases_per_min": 60.0 * world / dt_a, "fused_label_voxels": nvox_label,

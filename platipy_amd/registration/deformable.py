@@ -8,7 +8,10 @@ Deviations, all deliberate and visible:
     the fp64 restatement is stated and tested in tests/;
   * `ncores` is accepted and ignored (it set ITK's CPU thread count);
   * B-spline interpolation (`interp_order=3`) raises NotImplementedError;
-  * non-identity direction cosines raise NotImplementedError in the demons loop.
+  * non-identity direction cosines (axis flips / oblique acquisitions): the registration runs in the image's
+    own index-aligned frame -- every stage is linear in the field and the pyramid grids share one origin and
+    one direction, so this is the same computation -- and the field is rotated back to physical (LPS)
+    components at the end.  (ITK's behaviour for this case could not be checked: parity unpinned.)
 """
 import numpy as np
 import torch
@@ -186,6 +189,20 @@ def fast_symmetric_forces_demons_registration(
     fixed_image = fixed_image.astype(torch.float32)    # :236-241 (quirk N1: everything computes in float32)
     moving_image = moving_image.astype(torch.float32)
 
+    identity = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
+    true_direction = fixed_image.direction
+    if true_direction != identity:
+        if moving_image.direction != true_direction:
+            raise NotImplementedError("demons: fixed and moving image must share their direction cosines")
+        # work in the index-aligned frame: q_local = R^T (q - origin) + origin keeps every index map unchanged
+        fixed_image = Image(fixed_image.tensor, fixed_image.spacing, fixed_image.origin, identity)
+        moving_image = Image(moving_image.tensor, moving_image.spacing, moving_image.origin, identity)
+        if initial_displacement_field is not None:
+            f0 = as_image(initial_displacement_field)
+            Rt = torch.tensor(true_direction, dtype=torch.float32, device=f0.device).reshape(3, 3).t()
+            initial_displacement_field = Image(torch.einsum("rc,czyx->rzyx", Rt, f0.tensor.float()).contiguous(), f0.spacing,
+                                               f0.origin, identity, True)
+
     registration_method = HipDemonsFilter(variant=variant)
     registration_method.SetNumberOfThreads(ncores)
     registration_method.SetSmoothUpdateField(True)
@@ -211,4 +228,10 @@ def fast_symmetric_forces_demons_registration(
     output_transform = DisplacementFieldTransform(deformation_field)
     registered_image = resample_image(moving_image, fixed_image, output_transform, interp_order, default_value)
     registered_image = registered_image.like(cast_tensor(registered_image.tensor, moving_image_type))
+    if true_direction != identity:
+        R = torch.tensor(true_direction, dtype=torch.float32, device=deformation_field.device).reshape(3, 3)
+        phys = torch.einsum("rc,czyx->rzyx", R, deformation_field.tensor).contiguous()
+        deformation_field = Image(phys, deformation_field.spacing, deformation_field.origin, true_direction, True)
+        output_transform = DisplacementFieldTransform(deformation_field)
+        registered_image = Image(registered_image.tensor, registered_image.spacing, registered_image.origin, true_direction)
     return registered_image, output_transform, deformation_field
