@@ -257,8 +257,17 @@ def main():
         roofline = None
         if dom and kernels[dom]["achieved_GBps"]:
             a = kernels[dom]["achieved_GBps"]
+            # HBM bytes per launch from the committed PMC passes of this build (FETCH_SIZE corrected per the guide's
+            # calibration), when they were taken at this size; PMC cannot be collected inside an untraced run.
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_final_pmc.json")))
+                if list(pmc["size"]) == [nx, ny, nz]:
+                    traffic = pmc["hbm_bytes_per_launch"].get(dom)
+            except (OSError, ValueError, KeyError):
+                pass
             roofline = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": a / HBM_PEAK_GBS, "traffic": None,
+                        "frac": a / HBM_PEAK_GBS, "traffic": traffic,
                         "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_voxel"] * nvox,
                         "avg_launch_ms": kernels[dom]["avg_ms"]}
         ms_per_step = dt * 1e3 / args.steps
