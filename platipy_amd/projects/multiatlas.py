@@ -276,8 +276,12 @@ def run_segmentation(img, settings=MUTLIATLAS_SETTINGS_DEFAULTS, atlases=None, s
                 a = ndimage.binary_closing(np.pad(a, [(r, r) for r in radius[::-1]]), structure=ball)
                 a = a[radius[2]:a.shape[0] - radius[2], radius[1]:a.shape[1] - radius[1], radius[0]:a.shape[2] - radius[0]]
                 results[s] = img.like(torch.from_numpy(a.astype(np.uint8)).to(device))
-        if len(pp["structures_for_overlap_correction"]) >= 2:
-            raise NotImplementedError("overlap correction is post-processing outside this build's scope (SURVEY 2)")
+        if len(pp["structures_for_overlap_correction"]) >= 2:      # :425-434
+            from ..label.utils import correct_volume_overlap
+
+            fixed = correct_volume_overlap({s: results[s] for s in pp["structures_for_overlap_correction"]})
+            for s in pp["structures_for_overlap_correction"]:
+                results[s] = fixed[s]
 
     if return_atlas_set:
         return results, results_prob, atlas_set

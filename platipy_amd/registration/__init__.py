@@ -4,5 +4,7 @@ from .utils import (  # noqa: F401
     apply_deformable_transform,
     apply_linear_transform,
     apply_transform,
+    convert_mask_to_distance_map,
+    convert_mask_to_reg_structure,
     smooth_and_resample,
 )

@@ -159,3 +159,35 @@ def smooth_and_resample(image, isotropic_voxel_size_mm=None, shrink_factor=None,
                 image.GetOrigin(), image.GetDirection())
     out = resample_image(image, ref, None, interpolator, 0.0)
     return out.like(cast_tensor(out.tensor, image.tensor.dtype))
+
+
+def convert_mask_to_distance_map(mask, squared_distance=False, normalise=False):
+    """Generate a distance map from a binary label (reference registration/utils.py:270-299):
+    sitk.SignedMaurerDistanceMap(mask, insideIsPositive=True, squaredDistance=..., useImageSpacing=True)."""
+    from ..label.iar import distance_map
+
+    mask = as_image(mask)
+    t = mask.tensor
+    vals = torch.unique(t[t > 0])
+    if len(vals) > 2:   # more than one value: threshold at the median (:283-287)
+        cutoff = float(np.median(vals.cpu().numpy()))
+        mask = mask.like(((t >= cutoff) & (t <= float(vals.max()))).to(torch.uint8))
+    raw = distance_map(mask, signed=True, inside_positive=True)
+    if squared_distance:
+        raw = raw.like(torch.sign(raw.tensor) * raw.tensor * raw.tensor)
+    if normalise:
+        return raw.like(raw.tensor / raw.tensor.max())
+    return raw
+
+
+def convert_mask_to_reg_structure(mask, expansion=(0, 0, 0), scale=lambda x: x):
+    """Mask-like image for structure-guided registration (reference registration/utils.py:302-344): the inside
+    distance map, zero outside, scaled to [0, 1].  Binary dilation (`expansion`) is not implemented."""
+    mask = as_image(mask)
+    if not hasattr(expansion, "__iter__"):
+        expansion = [int(expansion / i) for i in mask.GetSpacing()]
+    if any(expansion):
+        raise NotImplementedError("convert_mask_to_reg_structure: expansion (binary dilation) is not implemented")
+    dm = convert_mask_to_distance_map(mask, squared_distance=False)
+    inside = dm.tensor * (mask.tensor != 0).to(dm.tensor.dtype)
+    return scale(dm.like(inside / inside.max()))

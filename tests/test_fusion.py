@@ -87,3 +87,31 @@ def test_process_probability_image_edge_cases(host_api):
     e[0, 0, 0] = 1.0
     got = pa.label.process_probability_image(pa.image_from_array(e, SPACING, ORIGIN), 0.5).numpy()
     assert got.sum() == 1
+
+
+def test_overlap_correction_and_distance_map_helpers(host_api):
+    pa = host_api
+    a = np.zeros(SHAPE, np.uint8)
+    b = np.zeros(SHAPE, np.uint8)
+    c = np.zeros(SHAPE, np.uint8)
+    a[2:12, 4:20, 6:30] = 1          # largest
+    b[8:14, 10:24, 20:40] = 1        # overlaps a
+    c[9:11, 12:16, 24:28] = 1        # inside both
+    imgs = {k: pa.image_from_array(v, SPACING, ORIGIN) for k, v in (("B", b), ("A", a), ("C", c))}
+    out = pa.label.correct_volume_overlap(imgs)
+    oa, ob, oc = out["A"].numpy(), out["B"].numpy(), out["C"].numpy()
+    np.testing.assert_array_equal(oa, a)                          # the largest keeps everything
+    np.testing.assert_array_equal(ob, b & ~a)
+    np.testing.assert_array_equal(oc, c & ~a & ~b)
+    assert (oa + ob + oc).max() == 1
+    small_first = pa.label.correct_volume_overlap(imgs, assign_overlap_to_largest=False)
+    np.testing.assert_array_equal(small_first["C"].numpy(), c)
+    # inside-positive signed distance map and the registration structure built from it
+    dm = pa.registration.convert_mask_to_distance_map(imgs["A"]).numpy()
+    want = O.maurer_distance_map(O.Vol(a, SPACING, ORIGIN), signed=True, inside_positive=True).arr
+    np.testing.assert_allclose(dm, want, rtol=2e-6, atol=2e-5)
+    assert dm[6, 10, 15] > 0 > dm[0, 0, 0]
+    rs = pa.registration.convert_mask_to_reg_structure(imgs["A"]).numpy()
+    assert rs.max() == 1.0 and rs[0, 0, 0] == 0.0
+    with pytest.raises(NotImplementedError):
+        pa.registration.convert_mask_to_reg_structure(imgs["A"], expansion=2)
