@@ -69,6 +69,17 @@ MUTLIATLAS_SETTINGS_DEFAULTS = {
         "verbose": False,
     },
     "label_fusion_settings": {"vote_type": "unweighted", "vote_params": None, "optimal_threshold": {}},
+    # iterative atlas removal, schema of cardiac/run.py:156-165; off unless a reference structure is named
+    "iar_settings": {
+        "reference_structure": False,
+        "smooth_distance_maps": True,
+        "smooth_sigma": 1,
+        "z_score_statistic": "mad",
+        "outlier_method": "iqr",
+        "outlier_factor": 1.5,
+        "min_best_atlases": 5,
+        "project_on_sphere": False,
+    },
     "postprocessing_settings": {
         "run_postprocessing": True,
         "binaryfillhole_mm": 3,
@@ -104,6 +115,14 @@ class _Dist:
         if self.dist:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t
+
+    def all_gather(self, t):
+        """-> list of world tensors shaped like t (rank order)."""
+        if not self.dist:
+            return [t]
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return out
 
 
 def _map_atlases(fn, ids, streams_per_gpu, device):
@@ -227,6 +246,39 @@ def run_segmentation(img, settings=MUTLIATLAS_SETTINGS_DEFAULTS, atlases=None, s
     for atlas_id, out in _map_atlases(chain, my_ids, streams_per_gpu, device).items():
         atlas_set[atlas_id]["Original"] = None
         atlas_set[atlas_id]["DIR"] = out
+
+    # ---- optional: iterative atlas removal (cardiac/run.py:879-891 -> label/iar.py) ----
+    iar = dict(settings.get("iar_settings") or {})
+    ref_struct = iar.pop("reference_structure", False)
+    if ref_struct:
+        from ..label.iar import run_iar
+
+        # every rank needs every atlas's propagated reference structure + weight map: all_gather them slot by slot
+        # (slot k of rank r is atlas_id_list[r + k * world]); all ranks then run the same, deterministic selection.
+        slots = (len(atlas_id_list) + dd.world - 1) // dd.world
+        full_set = {}
+        for k in range(slots):
+            have = k < len(my_ids)
+            if have:
+                d = atlas_set[my_ids[k]]["DIR"]
+                m = (d[ref_struct].tensor != 0).to(torch.uint8).contiguous()
+                w = d["Weight Map"].tensor.float().contiguous()
+            else:
+                m = torch.zeros(img_crop.shape, dtype=torch.uint8, device=device)
+                w = torch.zeros(img_crop.shape, dtype=torch.float32, device=device)
+            ms, ws = dd.all_gather(m), dd.all_gather(w)
+            for r in range(dd.world):
+                idx = r + k * dd.world
+                if idx < len(atlas_id_list):
+                    full_set[atlas_id_list[idx]] = {"DIR": {"Weight Map": img_crop.like(ws[r]), ref_struct: img_crop.like(ms[r])}}
+        full_set = {i: full_set[i] for i in atlas_id_list}          # reference order
+        kept = run_iar(atlas_set=full_set, reference_structure=ref_struct, **iar)
+        removed = [i for i in atlas_id_list if i not in kept]
+        if removed:
+            logger.info("IAR removed atlases: %s", removed)
+        my_ids = [i for i in my_ids if i in kept]
+        run_segmentation.last_iar_removed = removed
+        del full_set, kept
 
     # ---- step 4b: label fusion, the one cross-atlas exchange (fusion.py:263-288) ----
     ctx = runtime.context(device)

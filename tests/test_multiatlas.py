@@ -128,3 +128,28 @@ def test_run_segmentation_two_ranks_gloo(tmp_path):
     np.testing.assert_allclose(p0, prob["WHOLEHEART"].numpy(), rtol=0, atol=1e-5)
     np.testing.assert_array_equal(wh0, results["WHOLEHEART"].numpy())
     assert dice(wh0, tmask) > 0.93
+
+
+def test_run_segmentation_with_iterative_atlas_removal(host_api):
+    """Config 5's "iterative atlas selection": an atlas whose label is grossly wrong is dropped before fusion."""
+    pa = host_api
+    from tests.helpers import smooth_noise
+
+    ids = [f"{i:03d}" for i in range(1, 7)]
+    target, tmask, _, atlases = _data(pa, ids)
+    for k, cid in enumerate(ids):       # observers differ: wobble every atlas contour by about a voxel (identical contours make
+        ct, m, _, sp = sphere_case(k)   # the reference's MAD z-scores 0/0)
+        zz, yy, xx = np.meshgrid(*[np.arange(n) for n in m.shape], indexing="ij")
+        r = 12 + 1.2 * smooth_noise(m.shape, 500 + k, cells=5)
+        wob = ((zz - (15 + k)) ** 2 + (yy - (32 + k)) ** 2 + (xx - 32) ** 2 <= r ** 2).astype(np.uint8)
+        atlases[cid]["WHOLEHEART"] = pa.image_from_array(wob, sp, ORIGIN)
+    bad = ids[-1]
+    wrong = np.roll(atlases[bad]["WHOLEHEART"].numpy(), (0, 14, -12), axis=(0, 1, 2))      # label far from where the CT says
+    atlases[bad]["WHOLEHEART"] = pa.image_from_array(wrong, atlases[bad]["CT Image"].spacing, ORIGIN)
+    st = _settings(ids)
+    st["atlas_settings"]["atlas_structure_list"] = ["WHOLEHEART"]
+    st["iar_settings"].update({"reference_structure": "WHOLEHEART", "min_best_atlases": 3})
+    res, _ = pa.projects.multiatlas.run_segmentation(target, st, atlases=atlases)
+    removed = pa.projects.multiatlas.run_segmentation.last_iar_removed
+    assert bad in removed and len(removed) <= 3          # the IQR fence on six atlases may also drop a borderline one
+    assert dice(res["WHOLEHEART"].numpy(), tmask) > 0.9
