@@ -59,82 +59,82 @@ def evaluate_distance_to_reference(reference_volume, test_volume, resample_facto
     return surface_values[::resample_factor].cpu().numpy()
 
 
+def _z_scores(own, others, statistic):
+    """Robust z-score of one atlas's distance samples against the remaining atlases (iar.py:166-199)."""
+    others = np.asarray(others)
+    kind = statistic.lower()
+    if kind == "std":
+        centre, spread = others.mean(axis=0), others.std(axis=0)
+        if np.any(spread == 0):
+            spread[spread == 0] = spread.mean()
+    elif kind == "mad":
+        centre = np.median(others, axis=0)
+        spread = 1.4826 * median_absolute_deviation(others, axis=0)
+        if np.any(spread == 0):
+            spread[spread == 0] = np.median(spread)
+    else:
+        raise ValueError("z_score must be one of: MAD, STD")
+    return np.ravel((own - centre) / spread)
+
+
+def _q_metric(z):
+    """Excess of the z-score histogram over its best-fit Gaussian, weighted by z^2 (iar.py:211-230)."""
+    density, edges = np.histogram(z, bins=np.linspace(-15, 15, 501), density=True)
+    centres = (edges[1:] + edges[:-1]) / 2.0
+    try:
+        popt, _ = curve_fit(f=gaussian_curve, xdata=centres, ydata=density)
+        ideal = gaussian_curve(centres, *popt)
+    except (RuntimeError, ValueError):
+        ideal = gaussian_curve(centres, a=1, m=density.mean(), s=density.std())
+    trap = np.trapezoid if hasattr(np, "trapezoid") else np.trapz
+    return np.float64(trap(np.abs(density - ideal) * np.abs(centres) ** 2, centres))
+
+
+def _outlier_limit(q_values, method, factor, min_best):
+    """Fence computed on all but (at most) the three worst atlases (iar.py:232-249)."""
+    finite = [q for q in q_values if ~np.isnan(q) and np.isfinite(q)]
+    best = np.sort(finite)[: max([min_best, len(finite) - 3])]
+    kind = method.lower()
+    if kind == "iqr":
+        q75, q25 = np.percentile(best, [75, 25], axis=0)
+        return q75 + factor * (q75 - q25)
+    if kind == "std":
+        return np.mean(best, axis=0) + factor * np.std(best, axis=0)
+    logger.error(" outlier_method must be one of: IQR, STD")
+    sys.exit()
+
+
 def run_iar(atlas_set, reference_structure, smooth_distance_maps=False, smooth_sigma=1, z_score_statistic="MAD",
             outlier_method="IQR", min_best_atlases=10, outlier_factor=1.5, iteration=0, single_step=False,
             project_on_sphere=False, label="DIR"):
-    """Perform iterative atlas removal on the atlas_set (reference iar.py:59-301)."""
+    """Perform iterative atlas removal on the atlas_set (reference iar.py:59-301): build the consensus contour,
+    sample every atlas's distance to it, score each atlas by how non-Gaussian its robust z-scores are, drop the
+    ones beyond the fence, repeat until nothing is dropped."""
     if project_on_sphere:
         raise NotImplementedError("project_on_sphere=True is outside this build's scope (SURVEY 2)")
-    remaining_id_list = list(atlas_set.keys())
-    probability_label = combine_labels(atlas_set, reference_structure, label=label)[reference_structure]
-
-    if len(remaining_id_list) < 12:       # iar.py:104-112 (the second branch is unreachable there too)
-        resample_factor = 5
-    elif len(remaining_id_list) < 7:
-        resample_factor = 10
-    else:
-        resample_factor = 1
-
-    reference_volume = process_probability_image(probability_label, threshold=0.95)
-    g_val_list = []
-    for test_id in remaining_id_list:
-        test_volume = process_probability_image(atlas_set[test_id][label][reference_structure], 0.1)
-        g_val_list.append(evaluate_distance_to_reference(reference_volume, test_volume, resample_factor=resample_factor))
+    ids = list(atlas_set.keys())
+    consensus = combine_labels(atlas_set, reference_structure, label=label)[reference_structure]
+    # iar.py:104-112: fewer atlases -> thinner sampling (the "< 7" branch there is unreachable and stays so here)
+    resample_factor = 5 if len(ids) < 12 else 1
+    reference_volume = process_probability_image(consensus, threshold=0.95)
+    samples = [evaluate_distance_to_reference(reference_volume, process_probability_image(atlas_set[i][label][reference_structure], 0.1),
+                                              resample_factor=resample_factor) for i in ids]
 
     q_results = {}
-    for i, (test_id, g_vals) in enumerate(zip(remaining_id_list, g_val_list)):
-        g_val_list_test = g_val_list[:]
-        g_val_list_test.pop(i)
-        if z_score_statistic.lower() == "std":
-            g_val_mean = np.mean(g_val_list_test, axis=0)
-            g_val_std = np.std(g_val_list_test, axis=0)
-            if np.any(g_val_std == 0):
-                g_val_std[g_val_std == 0] = g_val_std.mean()
-            z_score_vals_array = (g_vals - g_val_mean) / g_val_std
-        elif z_score_statistic.lower() == "mad":
-            g_val_median = np.median(g_val_list_test, axis=0)
-            g_val_mad = 1.4826 * median_absolute_deviation(g_val_list_test, axis=0)
-            if np.any(g_val_mad == 0):
-                g_val_mad[g_val_mad == 0] = np.median(g_val_mad)
-            z_score_vals_array = (g_vals - g_val_median) / g_val_mad
-        else:
-            raise ValueError("z_score must be one of: MAD, STD")
-        z_score_vals = np.ravel(z_score_vals_array)
-
-        bins = np.linspace(-15, 15, 501)
-        z_density, bin_edges = np.histogram(z_score_vals, bins=bins, density=True)
-        bin_centers = (bin_edges[1:] + bin_edges[:-1]) / 2.0
-        try:
-            popt, _ = curve_fit(f=gaussian_curve, xdata=bin_centers, ydata=z_density)
-            z_ideal = gaussian_curve(bin_centers, *popt)
-            z_diff = np.abs(z_density - z_ideal)
-        except (RuntimeError, ValueError):
-            z_ideal = gaussian_curve(bin_centers, a=1, m=z_density.mean(), s=z_density.std())
-            z_diff = np.abs(z_density - z_ideal)
-        trap = np.trapezoid if hasattr(np, "trapezoid") else np.trapz
-        q_value = trap(z_diff * np.abs(bin_centers) ** 2, bin_centers)
-        q_results[test_id] = np.float64(q_value)
-
-    result_list = [r for r in q_results.values() if ~np.isnan(r) and np.isfinite(r)]
-    best_results = np.sort(result_list)[: max([min_best_atlases, len(result_list) - 3])]
-    if outlier_method.lower() == "iqr":
-        outlier_limit = np.percentile(best_results, 75, axis=0) + outlier_factor * np.subtract(
-            *np.percentile(best_results, [75, 25], axis=0))
-    elif outlier_method.lower() == "std":
-        outlier_limit = np.mean(best_results, axis=0) + outlier_factor * np.std(best_results, axis=0)
-    else:
-        logger.error(" outlier_method must be one of: IQR, STD")
-        sys.exit()
-
-    keep_id_list = [idx for idx, result in q_results.items() if result <= outlier_limit]
+    for k, atlas_id in enumerate(ids):
+        z = _z_scores(samples[k], samples[:k] + samples[k + 1:], z_score_statistic)
+        q_results[atlas_id] = _q_metric(z)
+    limit = _outlier_limit(list(q_results.values()), outlier_method, outlier_factor, min_best_atlases)
+    keep = [i for i, q in q_results.items() if q <= limit]
     run_iar.last_q_results = dict(q_results)       # diagnostic hook for tests / logging
-    if len(keep_id_list) < len(remaining_id_list):
-        iteration += 1
-        atlas_set_new = {i: atlas_set[i] for i in keep_id_list}
-        if single_step:
-            return atlas_set_new
-        return run_iar(atlas_set=atlas_set_new, reference_structure=reference_structure,
-                       smooth_distance_maps=smooth_distance_maps, smooth_sigma=smooth_sigma, z_score_statistic=z_score_statistic,
-                       outlier_method=outlier_method, min_best_atlases=min_best_atlases, outlier_factor=outlier_factor,
-                       iteration=iteration, project_on_sphere=project_on_sphere, label=label)
-    return atlas_set
+    logger.info("IAR step %d: limit %.4g, Q = %s", iteration, limit, {i: round(float(q), 4) for i, q in q_results.items()})
+
+    if len(keep) == len(ids):
+        return atlas_set
+    survivors = {i: atlas_set[i] for i in keep}
+    if single_step:
+        return survivors
+    return run_iar(atlas_set=survivors, reference_structure=reference_structure, smooth_distance_maps=smooth_distance_maps,
+                   smooth_sigma=smooth_sigma, z_score_statistic=z_score_statistic, outlier_method=outlier_method,
+                   min_best_atlases=min_best_atlases, outlier_factor=outlier_factor, iteration=iteration + 1,
+                   project_on_sphere=project_on_sphere, label=label)
