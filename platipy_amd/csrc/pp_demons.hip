@@ -13,7 +13,7 @@
 //            A  force+smooth:  F, M.D  -> G_u * U            (+ metric / RMS partial sums)
 //            B  add+smooth+warp:  D, U, M -> D' = G_d * (D+U),  M.D'
 //          Real traffic ~64 B/voxel/iteration plus halo re-reads (served by L2/MALL).
-//          Kernel radii <= 3 (the reference's sigma_u = 1 and sigma_d = 1.5 mm give 1..3).
+//          Kernel radii <= 5 (sigma_d = 1.5 mm gives 1..5 for voxel spacings >= 0.5 mm).
 //
 // The early-halt rule (MaximumRMSError) is evaluated on device: the per-iteration finalize
 // kernel raises a flag that turns every later launch into a no-op, so a whole Execute is
@@ -708,33 +708,51 @@ int fused_zchunk(const pp_dims& d, int slots) {
   return best;
 }
 
+// Per-kernel dispatch on (radius, outputs per thread).  The two kernels are independent: the update is smoothed
+// with sigma_u (radius RA) and the field with sigma_d (radius RB), so each runs the narrowest template that fits.
 template <int R, int OPT>
-int fused_occupancy() {
-  int a = 0, b = 0;
-  constexpr int NTH = TX * TY / OPT;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fused_force_smooth<R, OPT>, NTH, 0) != hipSuccess) a = 2;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_fused_add_smooth_warp<R, OPT>, NTH, 0) != hipSuccess) b = 2;
+int occ_force() {
+  int a = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fused_force_smooth<R, OPT>, TX * TY / OPT, 0) != hipSuccess) a = 2;
   (void)hipGetLastError();
-  int m = a < b ? a : b;
-  return m < 1 ? 1 : m;
+  return a < 1 ? 1 : a;
+}
+template <int R, int OPT>
+int occ_warp() {
+  int a = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fused_add_smooth_warp<R, OPT>, TX * TY / OPT, 0) != hipSuccess) a = 2;
+  (void)hipGetLastError();
+  return a < 1 ? 1 : a;
 }
 
+#define PP_BY_RADIUS(R, OPT, CALL)                                                                   \
+  ((OPT) == 4 ? ((R) == 1 ? CALL(1, 4) : ((R) == 2 ? CALL(2, 4) : CALL(3, 4)))                       \
+              : ((R) == 1 ? CALL(1, 2) : ((R) == 2 ? CALL(2, 2) : ((R) == 3 ? CALL(3, 2) : ((R) == 4 ? CALL(4, 2) : CALL(5, 2))))))
+
 template <int R, int OPT>
-int launch_fused_iteration(pp_ctx* ctx, const float* F, const float* M, const float* Mw_in, float* Mw_out, const float* D,
-                           float* Dn, float* Us, const fused_args& fu, const fused_args& fd, const pp_esm_consts& K,
-                           const pp_warp_scale& sc, double* partials, const int* halt) {
-  const dim3 grid(8u * (unsigned)fu.per_xcd), block(TX * TY / OPT);
-  {
-    pp_prof_scope ps(ctx, "k_fused_force_smooth");
-    hipLaunchKernelGGL((k_fused_force_smooth<R, OPT>), grid, block, 0, ctx->stream, F, Mw_in, Us, fu, K, partials, halt);
-  }
-  PP_LAUNCH_CHECK(ctx, "k_fused_force_smooth");
-  {
-    pp_prof_scope ps(ctx, "k_fused_add_smooth_warp");
-    hipLaunchKernelGGL((k_fused_add_smooth_warp<R, OPT>), grid, block, 0, ctx->stream, D, (const float*)Us, M, Dn, Mw_out, fd, sc, halt);
-  }
-  PP_LAUNCH_CHECK(ctx, "k_fused_add_smooth_warp");
+int launch_force(pp_ctx* ctx, const float* F, const float* Mw_in, float* Us, const fused_args& fu, const pp_esm_consts& K,
+                 double* partials, const int* halt) {
+  pp_prof_scope ps(ctx, "k_fused_force_smooth");
+  hipLaunchKernelGGL((k_fused_force_smooth<R, OPT>), dim3(8u * (unsigned)fu.per_xcd), dim3(TX * TY / OPT), 0, ctx->stream, F, Mw_in, Us,
+                     fu, K, partials, halt);
   return PP_OK;
+}
+template <int R, int OPT>
+int launch_warp(pp_ctx* ctx, const float* D, const float* Us, const float* M, float* Dn, float* Mw_out, const fused_args& fd,
+                const pp_warp_scale& sc, const int* halt) {
+  pp_prof_scope ps(ctx, "k_fused_add_smooth_warp");
+  hipLaunchKernelGGL((k_fused_add_smooth_warp<R, OPT>), dim3(8u * (unsigned)fd.per_xcd), dim3(TX * TY / OPT), 0, ctx->stream, D, Us, M,
+                     Dn, Mw_out, fd, sc, halt);
+  return PP_OK;
+}
+
+void fused_grid(fused_args* f, const pp_dims& d, int occupancy) {
+  f->d = d;
+  f->zchunk = fused_zchunk(d, 256 * occupancy);
+  f->gx = (d.nx + TX - 1) / TX;
+  f->gy = (d.ny + TY - 1) / TY;
+  f->gz = (d.nz + f->zchunk - 1) / f->zchunk;
+  f->per_xcd = (int)(((size_t)f->gx * f->gy * f->gz + 7) / 8);
 }
 
 int check_demons_args(pp_ctx* ctx, const pp_geom* g, const pp_demons_params* p) {
@@ -872,26 +890,27 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   }
 
   // ---- fused schedule ----
-  const int R = rmax < 1 ? 1 : rmax;
-  fused_args fu, fd;
-  fu.d = d;
+  int ra = 1, rb = 1;
+  for (int a = 0; a < 3; ++a) {
+    if (tu[a].r > ra) ra = tu[a].r;
+    if (td[a].r > rb) rb = td[a].r;
+  }
   int opt = PP_FUSED_DEFAULT_OPT;
   if (const char* e = getenv("PP_FUSED_OPT")) opt = atoi(e) == 2 ? 2 : 4;
-  int occ;
-  if (opt == 4) occ = R == 1 ? fused_occupancy<1, 4>() : (R == 2 ? fused_occupancy<2, 4>() : fused_occupancy<3, 4>());
-  else occ = R == 1 ? fused_occupancy<1, 2>() : (R == 2 ? fused_occupancy<2, 2>() : fused_occupancy<3, 2>());
-  fu.zchunk = fused_zchunk(d, 256 * occ);
-  fu.gx = (d.nx + TX - 1) / TX;
-  fu.gy = (d.ny + TY - 1) / TY;
-  fu.gz = (d.nz + fu.zchunk - 1) / fu.zchunk;
-  fu.per_xcd = (int)(((size_t)fu.gx * fu.gy * fu.gz + 7) / 8);
-  fd = fu;
-  small_taps(tu[0], R, &fu.wx);
-  small_taps(tu[1], R, &fu.wy);
-  small_taps(tu[2], R, &fu.wz);
-  small_taps(td[0], R, &fd.wx);
-  small_taps(td[1], R, &fd.wy);
-  small_taps(td[2], R, &fd.wz);
+  const int opt_a = ra > 3 ? 2 : opt, opt_b = rb > 3 ? 2 : opt;   // radii 4 and 5 exist in the 512-thread layout only
+  fused_args fu, fd;
+#define PP_OCC_A(RR, OO) occ_force<RR, OO>()
+#define PP_OCC_B(RR, OO) occ_warp<RR, OO>()
+  fused_grid(&fu, d, PP_BY_RADIUS(ra, opt_a, PP_OCC_A));
+  fused_grid(&fd, d, PP_BY_RADIUS(rb, opt_b, PP_OCC_B));
+#undef PP_OCC_A
+#undef PP_OCC_B
+  small_taps(tu[0], ra, &fu.wx);
+  small_taps(tu[1], ra, &fu.wy);
+  small_taps(tu[2], ra, &fu.wz);
+  small_taps(td[0], rb, &fd.wx);
+  small_taps(td[1], rb, &fd.wy);
+  small_taps(td[2], rb, &fd.wz);
   const size_t nblk = (size_t)fu.gx * fu.gy * fu.gz;
   const size_t need = 2 * pp_align_up(N * 4, 256) + 2 * pp_align_up(3 * N * 4, 256) + pp_align_up(3 * nblk * 8, 256) + 256;
   rc = pp_reserve(ctx, need);
@@ -912,11 +931,14 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     float* mw_out = (it & 1) ? MwB : MwA;
     const float* Dcur = (it & 1) ? D2 : field;
     float* Dnext = (it & 1) ? field : D2;
-#define PP_FUSED_CALL(RR, OO) \
-  launch_fused_iteration<RR, OO>(ctx, fixed, moving, mw_in, mw_out, Dcur, Dnext, Us, fu, fd, K, sc, partials, halt)
-    if (opt == 4) rc = R == 1 ? PP_FUSED_CALL(1, 4) : (R == 2 ? PP_FUSED_CALL(2, 4) : PP_FUSED_CALL(3, 4));
-    else rc = R == 1 ? PP_FUSED_CALL(1, 2) : (R == 2 ? PP_FUSED_CALL(2, 2) : PP_FUSED_CALL(3, 2));
-#undef PP_FUSED_CALL
+#define PP_CALL_A(RR, OO) launch_force<RR, OO>(ctx, fixed, mw_in, Us, fu, K, partials, halt)
+#define PP_CALL_B(RR, OO) launch_warp<RR, OO>(ctx, Dcur, (const float*)Us, moving, Dnext, mw_out, fd, sc, halt)
+    rc = PP_BY_RADIUS(ra, opt_a, PP_CALL_A);
+    PP_LAUNCH_CHECK(ctx, "k_fused_force_smooth");
+    rc = PP_BY_RADIUS(rb, opt_b, PP_CALL_B);
+    PP_LAUNCH_CHECK(ctx, "k_fused_add_smooth_warp");
+#undef PP_CALL_A
+#undef PP_CALL_B
     if (rc) return rc;
     hipLaunchKernelGGL(k_demons_finalize, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nblk, dst, max_rms);
     PP_LAUNCH_CHECK(ctx, "k_demons_finalize");

@@ -103,7 +103,7 @@ struct pp_taps {
 int pp_make_taps(pp_ctx* ctx, double variance, double max_error, int max_kernel_width, pp_taps* t);
 
 // Small-radius taps passed by value to the fused kernels.
-#define PP_FUSED_MAX_R 3
+#define PP_FUSED_MAX_R 5
 struct pp_taps_small {
   float w[2 * PP_FUSED_MAX_R + 1];
 };

@@ -244,8 +244,11 @@ def _oracle_execute(fix, mov, spacing, origin, iterations, max_rms):
     return d.arr, f.stats
 
 
+HIRES = ((14, 30, 70), (0.55, 0.62, 1.0), (1.0, 2.0, 3.0))   # sigma_d = 1.5 mm -> kernel radii 5, 4, 2
+
+
 @pytest.mark.parametrize("variant", [_lib.DEMONS_STAGED, _lib.DEMONS_FUSED])
-@pytest.mark.parametrize("grid", GRIDS)
+@pytest.mark.parametrize("grid", GRIDS + [HIRES])
 def test_demons_execute(backend, grid, variant):
     """registration_algorithm.Execute (deformable.py:149): 4 iterations, field vs the fp64 oracle.
 
