@@ -414,3 +414,57 @@ def test_distance_map_and_contour(backend, grid):
     c = backend.empty(shape, np.uint8)
     backend.ctx.label_contour(backend.dev(mask), size_of(shape), c)
     np.testing.assert_array_equal(backend.host(c), O.label_contour(O.Vol(mask, spacing, origin)).arr)
+
+
+@pytest.mark.parametrize("variant", [_lib.DEMONS_STAGED, _lib.DEMONS_FUSED])
+def test_demons_edge_cases(backend, variant):
+    """Degenerate inputs the reference's filter accepts: tiny volumes (smaller than one tile, shorter than the kernel
+    radius), zero iterations, identical images (halts after the first iteration), a one-voxel-thick axis."""
+    ctx = backend.ctx
+    for shape in [(5, 6, 7), (1, 9, 11), (3, 1, 70)]:
+        spacing, origin = (1.0, 1.3, 2.0), (0.0, 0.0, 0.0)
+        rng = np.random.default_rng(sum(shape))
+        fix = (rng.normal(size=shape) * 50).astype(np.float32)
+        mov = (fix + rng.normal(size=shape) * 10).astype(np.float32)
+        want, wst = _oracle_execute(fix, mov, spacing, origin, 3, 0.0)
+        p = _demons_params(ctx, 3, spacing, variant, max_rms=0.0)
+        field = backend.empty((3,) + shape)
+        st = ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, field)
+        assert st.elapsed_iterations == 3 and st.n_pixels == wst.n_pixels
+        np.testing.assert_allclose(backend.host(field), want, rtol=0, atol=1e-4)
+    shape, spacing, origin = (6, 10, 20), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)
+    img = phantom(shape, seed=9)
+    g = geom_of(shape, spacing, origin)
+    # zero iterations: the field is zero and nothing was counted
+    p = _demons_params(ctx, 0, spacing, variant)
+    field = backend.dev(np.ones((3,) + shape, np.float32))
+    st = ctx.demons_execute(backend.dev(img), backend.dev(img), g, p, field)
+    assert st.elapsed_iterations == 0 and not backend.host(field).any()
+    # identical images: zero update, metric 0, RMS change 0 < MaximumRMSError -> Halt() after one iteration
+    p = _demons_params(ctx, 5, spacing, variant, max_rms=0.02)
+    st = ctx.demons_execute(backend.dev(img), backend.dev(img), g, p, field)
+    assert st.elapsed_iterations == 1 and st.halted == 1 and st.metric == 0.0 and st.rms_change == 0.0
+    assert not backend.host(field).any()
+
+
+def test_argument_errors(backend):
+    ctx = backend.ctx
+    shape = (4, 6, 8)
+    a = backend.dev(np.zeros(shape, np.float32))
+    g = geom_of(shape, (1, 1, 1), (0, 0, 0))
+    p = ctx.default_demons_params()
+    with pytest.raises(_lib.PlatipyAmdError):          # NULL volume
+        ctx.demons_execute(a, None, g, p, backend.empty((3,) + shape))
+    bad = _lib.make_geom((8, 6, 4), (1.0, 0.0, 1.0))   # zero spacing
+    with pytest.raises(_lib.PlatipyAmdError):
+        ctx.warp(a, backend.empty((3,) + shape), bad, 0.0, backend.empty(shape))
+    with pytest.raises(_lib.PlatipyAmdError):          # in-place resample
+        ctx.resample(a, g, g, a)
+    p.variant = _lib.DEMONS_FUSED
+    p.smooth_update = 0                                # the fused schedule needs both smoothers
+    with pytest.raises(_lib.PlatipyAmdError):
+        ctx.demons_execute(a, a, g, p, backend.empty((3,) + shape))
+    rot = _lib.make_geom((8, 6, 4), (1, 1, 1), (0, 0, 0), (0, 1, 0, -1, 0, 0, 0, 0, 1))
+    p = ctx.default_demons_params()
+    with pytest.raises(_lib.PlatipyAmdError):          # direction cosines are handled above the ABI
+        ctx.demons_execute(a, a, rot, p, backend.empty((3,) + shape))
