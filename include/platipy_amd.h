@@ -217,6 +217,15 @@ int pp_meansq_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], co
                          const double Am[9], const double bm[3], const int vsize[3], int stride,
                          const uint8_t* fixed_mask, const uint8_t* moving_mask, double* result);
 
+/* The same sampling for the correlation metric (itk::CorrelationImageToImageMetricv4, linear.py:142-143): raw
+ * moments from which value and gradient of -corr^2 follow on the host.  result (host, 42 doubles):
+ * [0] count [1] sum f [2] sum m [3] sum f^2 [4] sum m^2 [5] sum f m, then three blocks of 12 (d/dAm row-major 9,
+ * d/dbm 3): [6..17] sum g, [18..29] sum f g, [30..41] sum m g, with g the interpolant-gradient terms g_r v_q / g_r. */
+int pp_corr_moments_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], const float* moving,
+                               const int msize[3], const double Af[9], const double bf[3],
+                               const double Am[9], const double bm[3], const int vsize[3], int stride,
+                               const uint8_t* fixed_mask, const uint8_t* moving_mask, double* result);
+
 #ifdef __cplusplus
 }
 #endif

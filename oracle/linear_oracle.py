@@ -67,3 +67,28 @@ def meansq_affine(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask=None,
     out[2:11] = (s[:, :, None] * v[:, None, :]).sum(0).ravel()
     out[11:14] = s.sum(0)
     return out
+
+
+def corr_moments_affine(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None):
+    """-> the 42 raw moments pp_corr_moments_affine_f32 accumulates (layout in include/platipy_amd.h)."""
+    Af, Am = np.asarray(Af, dtype=np.float64).reshape(3, 3), np.asarray(Am, dtype=np.float64).reshape(3, 3)
+    bf, bm = np.asarray(bf, dtype=np.float64), np.asarray(bm, dtype=np.float64)
+    nv = int(vsize[0]) * int(vsize[1]) * int(vsize[2])
+    lin = np.arange(0, nv, int(stride), dtype=np.int64)
+    v = np.stack([lin % vsize[0], (lin // vsize[0]) % vsize[1], lin // (vsize[0] * vsize[1])], axis=1).astype(np.float64)
+    cf, cm = v @ Af.T + bf, v @ Am.T + bm
+    inf_, fval, _ = _sample(np.asarray(fixed), cf)
+    inm, mval, g = _sample(np.asarray(moving), cm)
+    ok = inf_ & inm
+    if fixed_mask is not None:
+        ok &= np.where(inf_, _nn_mask(np.asarray(fixed_mask), np.where(inf_[:, None], cf, 0.0)), False)
+    if moving_mask is not None:
+        ok &= np.where(inm, _nn_mask(np.asarray(moving_mask), np.where(inm[:, None], cm, 0.0)), False)
+    f, m, g, v = fval[ok], mval[ok], g[ok], v[ok]
+    terms = np.concatenate([(g[:, :, None] * v[:, None, :]).reshape(len(f), 9), g], axis=1)     # [n, 12]
+    out = np.zeros(42)
+    out[0:6] = [len(f), f.sum(), m.sum(), (f * f).sum(), (m * m).sum(), (f * m).sum()]
+    out[6:18] = terms.sum(0)
+    out[18:30] = (f[:, None] * terms).sum(0)
+    out[30:42] = (m[:, None] * terms).sum(0)
+    return out

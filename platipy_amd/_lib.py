@@ -100,6 +100,9 @@ _SIGNATURES = {
     "pp_meansq_affine_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                        C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(C.c_double)]),
+    "pp_corr_moments_affine_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                             C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(C.c_double)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -330,3 +333,11 @@ class Context:
                                                 _dn(Am, 9), _dn(bm, 3), _i3(vsize), int(stride), ptr(fixed_mask),
                                                 ptr(moving_mask), res), "pp_meansq_affine_f32")
         return [res[i] for i in range(14)]
+
+    def corr_moments_affine(self, fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None):
+        """-> the 42 raw moments of pp_corr_moments_affine_f32."""
+        res = (C.c_double * 42)()
+        self._chk(self.lib.pp_corr_moments_affine_f32(self.h, ptr(fixed), _i3(fsize), ptr(moving), _i3(msize), _dn(Af, 9), _dn(bf, 3),
+                                                      _dn(Am, 9), _dn(bm, 3), _i3(vsize), int(stride), ptr(fixed_mask),
+                                                      ptr(moving_mask), res), "pp_corr_moments_affine_f32")
+        return [res[i] for i in range(42)]

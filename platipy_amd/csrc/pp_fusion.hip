@@ -166,13 +166,19 @@ __device__ __forceinline__ bool msq_locate(const double c[3], const pp_dims& n, 
   return true;
 }
 
-__global__ void __launch_bounds__(NT) k_meansq_affine(const float* __restrict__ F, pp_dims df, const float* __restrict__ M,
+// MODE 0: mean squares, NACC = 14 (layout above).
+// MODE 1: raw moments for the correlation metric, NACC = 42:
+//   [0] count [1] sum f [2] sum m [3] sum f^2 [4] sum m^2 [5] sum f m
+//   [6..17] sum g (d/dAm row-major 9, d/dbm 3)   [18..29] sum f g   [30..41] sum m g      (g = interpolant gradient terms)
+template <int MODE>
+__global__ void __launch_bounds__(NT) k_metric_affine(const float* __restrict__ F, pp_dims df, const float* __restrict__ M,
                                                       pp_dims dm, const uint8_t* __restrict__ fmask,
                                                       const uint8_t* __restrict__ mmask, msq_args a,
-                                                      double* __restrict__ partials /* [grid][14] */) {
+                                                      double* __restrict__ partials /* [grid][NACC] */) {
+  constexpr int NACC = MODE == 0 ? 14 : 42;
   __shared__ double red[3 * NT];
-  double acc[14];
-  for (int k = 0; k < 14; ++k) acc[k] = 0.0;
+  double acc[NACC];
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
   const size_t nvirt = (size_t)a.vsize[0] * a.vsize[1] * a.vsize[2];
   const size_t nsamp = (nvirt + a.stride - 1) / a.stride;
   for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nsamp; e += (size_t)gridDim.x * NT) {
@@ -216,37 +222,59 @@ __global__ void __launch_bounds__(NT) k_meansq_affine(const float* __restrict__ 
     const float gx = gx0 + (gx1 - gx0) * wz;
     const float gy = (v10 - v00) + ((v11 - v01) - (v10 - v00)) * wz;
     const float gz = v1 - v0;
-    const double diff = (double)fval - (double)m;
-    acc[0] += diff * diff;
-    acc[1] += 1.0;
-    const double s = -2.0 * diff;
-    const double g[3] = {s * gx, s * gy, s * gz};
-    for (int r = 0; r < 3; ++r) {
-      acc[2 + r * 3 + 0] += g[r] * v[0];
-      acc[2 + r * 3 + 1] += g[r] * v[1];
-      acc[2 + r * 3 + 2] += g[r] * v[2];
-      acc[11 + r] += g[r];
+    if (MODE == 0) {
+      const double diff = (double)fval - (double)m;
+      acc[0] += diff * diff;
+      acc[1] += 1.0;
+      const double s = -2.0 * diff;
+      const double g[3] = {s * gx, s * gy, s * gz};
+      for (int r = 0; r < 3; ++r) {
+        acc[2 + r * 3 + 0] += g[r] * v[0];
+        acc[2 + r * 3 + 1] += g[r] * v[1];
+        acc[2 + r * 3 + 2] += g[r] * v[2];
+        acc[11 + r] += g[r];
+      }
+    } else {
+      const double fd = fval, md = m;
+      acc[0] += 1.0;
+      acc[1] += fd;
+      acc[2] += md;
+      acc[3] += fd * fd;
+      acc[4] += md * md;
+      acc[5] += fd * md;
+      const double g[3] = {gx, gy, gz};
+      for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 4; ++q) {
+          const double t = g[r] * (q < 3 ? v[q] : 1.0);
+          const int slot = q < 3 ? r * 3 + q : 9 + r;
+          acc[6 + slot] += t;
+          acc[18 + slot] += fd * t;
+          acc[30 + slot] += md * t;
+        }
     }
   }
-  for (int k = 0; k < 14; k += 3) {
-    double p = acc[k], q = k + 1 < 14 ? acc[k + 1] : 0.0, r = k + 2 < 14 ? acc[k + 2] : 0.0;
+  for (int k = 0; k < NACC; k += 3) {
+    double p = acc[k], q = k + 1 < NACC ? acc[k + 1] : 0.0, r = k + 2 < NACC ? acc[k + 2] : 0.0;
     pp_block_sum3<NT>(p, q, r, red);
     if (threadIdx.x == 0) {
-      partials[(size_t)blockIdx.x * 14 + k] = p;
-      if (k + 1 < 14) partials[(size_t)blockIdx.x * 14 + k + 1] = q;
-      if (k + 2 < 14) partials[(size_t)blockIdx.x * 14 + k + 2] = r;
+      partials[(size_t)blockIdx.x * NACC + k] = p;
+      if (k + 1 < NACC) partials[(size_t)blockIdx.x * NACC + k + 1] = q;
+      if (k + 2 < NACC) partials[(size_t)blockIdx.x * NACC + k + 2] = r;
     }
     __syncthreads();
   }
 }
 
-// Fold [count][14] partial rows into 14 sums with one tree (8 barrier steps for all fields at once).
-__global__ void __launch_bounds__(NT) k_sum14_final(const double* __restrict__ partials, int count, double* __restrict__ result) {
+// Fold [count][14] partial rows into 14 sums with one tree (8 barrier steps for all fields at once); launched
+// with one block per group of 14 fields (blockIdx.x selects the group of a wider row).
+__global__ void __launch_bounds__(NT) k_sum14_final(const double* __restrict__ partials, int count, int row, double* __restrict__ result) {
   __shared__ double red[NT * 14];
+  const int f0 = blockIdx.x * 14;
+  const int nf = row - f0 < 14 ? row - f0 : 14;
   double acc[14];
   for (int f = 0; f < 14; ++f) acc[f] = 0.0;
   for (int i = threadIdx.x; i < count; i += NT)
-    for (int f = 0; f < 14; ++f) acc[f] += partials[(size_t)i * 14 + f];
+    for (int f = 0; f < nf; ++f) acc[f] += partials[(size_t)i * row + f0 + f];
   for (int f = 0; f < 14; ++f) red[f * NT + threadIdx.x] = acc[f];
   __syncthreads();
   for (int s = NT / 2; s > 0; s >>= 1) {
@@ -254,7 +282,7 @@ __global__ void __launch_bounds__(NT) k_sum14_final(const double* __restrict__ p
       for (int f = 0; f < 14; ++f) red[f * NT + threadIdx.x] += red[f * NT + threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x < 14) result[threadIdx.x] = red[threadIdx.x * NT];
+  if ((int)threadIdx.x < nf) result[f0 + threadIdx.x] = red[threadIdx.x * NT];
 }
 
 }  // namespace
@@ -351,13 +379,13 @@ int pp_binary_threshold_f32(pp_ctx* ctx, const float* prob, size_t n, double max
   return PP_OK;
 }
 
-int pp_meansq_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], const float* moving, const int msize[3],
-                         const double Af[9], const double bf[3], const double Am[9], const double bm[3],
-                         const int vsize[3], int stride, const uint8_t* fixed_mask, const uint8_t* moving_mask,
-                         double* result) {
+static int metric_affine(pp_ctx* ctx, int mode, const float* fixed, const int fsize[3], const float* moving, const int msize[3],
+                         const double Af[9], const double bf[3], const double Am[9], const double bm[3], const int vsize[3],
+                         int stride, const uint8_t* fixed_mask, const uint8_t* moving_mask, double* result) {
   if (!ctx) return PP_ERR_ARG;
-  PP_REQUIRE(ctx, fixed && fsize && moving && msize && Af && bf && Am && bm && vsize && result, "pp_meansq_affine_f32: NULL argument");
-  PP_REQUIRE(ctx, stride >= 1 && vsize[0] >= 1 && vsize[1] >= 1 && vsize[2] >= 1, "pp_meansq_affine_f32: bad sampling lattice");
+  PP_REQUIRE(ctx, fixed && fsize && moving && msize && Af && bf && Am && bm && vsize && result, "metric: NULL argument");
+  PP_REQUIRE(ctx, stride >= 1 && vsize[0] >= 1 && vsize[1] >= 1 && vsize[2] >= 1, "metric: bad sampling lattice");
+  const int nacc = mode == 0 ? 14 : 42;
   msq_args a;
   memcpy(a.Af, Af, sizeof(a.Af));
   memcpy(a.bf, bf, sizeof(a.bf));
@@ -368,16 +396,34 @@ int pp_meansq_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], co
   const size_t nsamp = ((size_t)vsize[0] * vsize[1] * vsize[2] + stride - 1) / stride;
   const pp_dims df{fsize[0], fsize[1], fsize[2]}, dm{msize[0], msize[1], msize[2]};
   const unsigned nb = grid_for(nsamp, 512u);
-  int rc = pp_reserve(ctx, pp_align_up(((size_t)nb * 14 + 14) * sizeof(double), 256));
+  int rc = pp_reserve(ctx, pp_align_up(((size_t)nb * nacc + nacc) * sizeof(double), 256));
   if (rc) return rc;
   double* partials = reinterpret_cast<double*>(ctx->ws);
-  hipLaunchKernelGGL(k_meansq_affine, dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, partials);
-  PP_LAUNCH_CHECK(ctx, "k_meansq_affine");
-  hipLaunchKernelGGL(k_sum14_final, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, partials + (size_t)nb * 14);
+  if (mode == 0)
+    hipLaunchKernelGGL((k_metric_affine<0>), dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, partials);
+  else
+    hipLaunchKernelGGL((k_metric_affine<1>), dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, partials);
+  PP_LAUNCH_CHECK(ctx, "k_metric_affine");
+  hipLaunchKernelGGL(k_sum14_final, dim3((nacc + 13) / 14), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, nacc,
+                     partials + (size_t)nb * nacc);
   PP_LAUNCH_CHECK(ctx, "k_sum14_final");
-  PP_HIP(ctx, hipMemcpyAsync(result, partials + (size_t)nb * 14, 14 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PP_HIP(ctx, hipMemcpyAsync(result, partials + (size_t)nb * nacc, nacc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PP_OK;
+}
+
+int pp_meansq_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], const float* moving, const int msize[3],
+                         const double Af[9], const double bf[3], const double Am[9], const double bm[3],
+                         const int vsize[3], int stride, const uint8_t* fixed_mask, const uint8_t* moving_mask,
+                         double* result) {
+  return metric_affine(ctx, 0, fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask, result);
+}
+
+int pp_corr_moments_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], const float* moving, const int msize[3],
+                               const double Af[9], const double bf[3], const double Am[9], const double bm[3],
+                               const int vsize[3], int stride, const uint8_t* fixed_mask, const uint8_t* moving_mask,
+                               double* result) {
+  return metric_affine(ctx, 1, fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask, result);
 }
 
 }  // extern "C"

@@ -18,7 +18,8 @@ trajectory is not a goal for this stage; it is judged by final metric / transfor
     default is False).  ITK re-estimates the learning rate at the start of every level so that the first step
     moves the volume corners by one voxel; when the previous level already converged that first step overshoots,
     and keeping the best visited point makes the result insensitive to it;
-  * metrics other than "mean_squares" and the "exhaustive" optimiser raise NotImplementedError.
+  * "mean_squares" and "correlation" are implemented; the mutual-information metrics and the "exhaustive"
+    optimiser raise NotImplementedError.
 """
 import numpy as np
 import torch
@@ -84,9 +85,13 @@ def _shrink_geometry(image, factor):
 
 
 class _MeanSquares:
-    """value / gradient of the mean-squares metric for one pyramid level."""
+    """value / gradient of the similarity metric for one pyramid level: "mean_squares"
+    (itk::MeanSquaresImageToImageMetricv4) or "correlation" (itk::CorrelationImageToImageMetricv4,
+    -corr^2), both from one GPU reduction over the sampled virtual domain."""
 
-    def __init__(self, ctx, fixed, moving, vsize, vspacing, vorigin, vdir, initial, sampling_rate, fixed_mask, moving_mask):
+    def __init__(self, ctx, fixed, moving, vsize, vspacing, vorigin, vdir, initial, sampling_rate, fixed_mask, moving_mask,
+                 metric="mean_squares"):
+        self.metric = metric
         self.ctx = ctx
         self.fixed, self.moving = fixed, moving
         self.ft = fixed.tensor.contiguous()
@@ -123,23 +128,36 @@ class _MeanSquares:
         return Am, bm
 
     def raw(self, model, params):
+        """-> (value, d value / d (Am row-major, bm)) in index space."""
         Am, bm = self.index_map(model, params)
         self.evaluations += 1
-        return self.ctx.meansq_affine(self.ft, self.fixed.GetSize(), self.mt, self.moving.GetSize(), self.Af.ravel(), self.bf,
-                                      Am.ravel(), bm, self.vsize, self.stride, self.fmask, self.mmask)
+        args = (self.ft, self.fixed.GetSize(), self.mt, self.moving.GetSize(), self.Af.ravel(), self.bf, Am.ravel(), bm, self.vsize,
+                self.stride, self.fmask, self.mmask)
+        if self.metric == "mean_squares":
+            r = self.ctx.meansq_affine(*args)
+            if r[1] <= 0:
+                raise RuntimeError("linear_registration: no valid sample points (images do not overlap)")
+            return r[0] / r[1], np.asarray(r[2:14]) / r[1]
+        r = np.asarray(self.ctx.corr_moments_affine(*args))
+        n = r[0]
+        if n <= 0:
+            raise RuntimeError("linear_registration: no valid sample points (images do not overlap)")
+        fbar, mbar = r[1] / n, r[2] / n
+        sff, smm, sfm = r[3] - n * fbar * fbar, r[4] - n * mbar * mbar, r[5] - n * fbar * mbar
+        if sff <= 1e-300 or smm <= 1e-300:
+            return 0.0, np.zeros(12)
+        G, FG, MG = r[6:18], r[18:30], r[30:42]
+        dsfm = FG - fbar * G                       # sum (f - fbar) dm
+        dsmm = 2.0 * (MG - mbar * G)               # d sum (m - mbar)^2
+        value = -(sfm * sfm) / (sff * smm)
+        grad = -(2.0 * sfm / (sff * smm) * dsfm - (sfm * sfm) / (sff * smm * smm) * dsmm)
+        return value, grad
 
     def value(self, model, params):
-        r = self.raw(model, params)
-        if r[1] <= 0:
-            raise RuntimeError("linear_registration: no valid sample points (images do not overlap)")
-        return r[0] / r[1]
+        return self.raw(model, params)[0]
 
     def value_and_gradient(self, model, params):
-        r = self.raw(model, params)
-        if r[1] <= 0:
-            raise RuntimeError("linear_registration: no valid sample points (images do not overlap)")
-        value = r[0] / r[1]
-        g_idx = np.asarray(r[2:14]) / r[1]              # d value / d (Am row-major, bm)
+        value, g_idx = self.raw(model, params)
         params = np.asarray(params, dtype=np.float64)
         grad = np.zeros(len(params))
         for i in range(len(params)):                     # chain rule through params -> (Am, bm), numerically
@@ -245,8 +263,9 @@ def linear_registration(
     moving_image = moving_image.astype(torch.float32)
     ctx = runtime.context(fixed_image.device)
 
-    if metric.lower() != "mean_squares":
-        raise NotImplementedError(f"metric {metric!r}: only 'mean_squares' runs on the HIP path")
+    metric = metric.lower()
+    if metric not in ("mean_squares", "correlation"):
+        raise NotImplementedError(f"metric {metric!r}: 'mean_squares' and 'correlation' run on the HIP path")
     initial_transform = centered_transform_initializer(fixed_image, moving_image)
 
     if isinstance(reg_method, str):
@@ -281,7 +300,8 @@ def linear_registration(
         f_l = discrete_gaussian(fixed_image, sigma * sigma) if sigma > 0 else fixed_image
         m_l = discrete_gaussian(moving_image, sigma * sigma) if sigma > 0 else moving_image
         vsize, vspacing, vorigin, vdir = _shrink_geometry(fixed_image, shrink)
-        ms = _MeanSquares(ctx, f_l, m_l, vsize, vspacing, vorigin, vdir, initial_transform, sampling_rate, fixed_mask, moving_mask)
+        ms = _MeanSquares(ctx, f_l, m_l, vsize, vspacing, vorigin, vdir, initial_transform, sampling_rate, fixed_mask, moving_mask,
+                          metric=metric)
 
         if opt == "lbfgsb":
             from scipy.optimize import fmin_l_bfgs_b

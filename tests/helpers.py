@@ -129,7 +129,13 @@ def install_emu_runtime(setattr_fn=None):
         return list(linear_oracle.meansq_affine(fixed.numpy(), moving.numpy(), Af, bf, Am, bm, vsize, stride, tn(fixed_mask),
                                                 tn(moving_mask)))
 
+    def fake_corr(fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None):
+        tn = lambda t: None if t is None else t.numpy()  # noqa: E731
+        return list(linear_oracle.corr_moments_affine(fixed.numpy(), moving.numpy(), Af, bf, Am, bm, vsize, stride, tn(fixed_mask),
+                                                      tn(moving_mask)))
+
     sa(be.ctx, "meansq_affine", fake_meansq)
+    sa(be.ctx, "corr_moments_affine", fake_corr)
     return be
 
 

@@ -49,6 +49,22 @@ def test_meansq_kernel_matches_numpy_and_finite_differences(backend):
     assert 0 < masked[1] < got[1]
 
 
+def test_corr_moments_kernel_matches_numpy(backend):
+    from oracle import linear_oracle
+
+    F = phantom((10, 14, 18), seed=300, noise=0)
+    M = (0.5 * phantom((12, 13, 17), seed=301, noise=0) + 300).astype(np.float32)
+    Af, bf = np.eye(3) * 2.0, np.array([0.5, 0.5, 0.5])
+    Am = np.array([[1.9137, 0.1071, 0.0031], [-0.0813, 2.0519, 0.0207], [0.0109, 0.0043, 2.3011]])
+    bm = np.array([0.7123, -0.4057, 0.9131])
+    vsize, stride = (9, 7, 5), 2
+    got = np.array(backend.ctx.corr_moments_affine(backend.dev(F), (18, 14, 10), backend.dev(M), (17, 13, 12), Af.ravel(), bf,
+                                                   Am.ravel(), bm, vsize, stride))
+    want = linear_oracle.corr_moments_affine(F, M, Af, bf, Am, bm, vsize, stride)
+    assert got[0] == want[0] > 50
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-6 * np.abs(want).max())
+
+
 def _rigid_pair(pa, shape, spacing, origin, angle=0.06, shift=(3.0, -2.0, 1.5), scale=1.0):
     """moving = fixed seen through a known transform (fixed point p -> moving point A (p - c) + c + t)."""
     fix = phantom(shape, seed=400, noise=0)
@@ -92,6 +108,24 @@ def test_linear_registration_recovers_known_transform(host_api, method, optimise
     # 12-parameter gradient descent converges slowly along the shear/scale directions: the volume corners land
     # within 3 mm after 3 x 40 iterations; the 6/7-parameter models within 1 mm
     assert np.abs(got - want).max() < (3.0 if method == "affine" else 1.0), np.abs(got - want).max()
+
+
+def test_linear_registration_correlation_metric(host_api):
+    """metric="correlation" (linear.py:142-143) is blind to a linear intensity change that defeats mean squares."""
+    pa = host_api
+    shape, spacing, origin = (24, 40, 48), (1.5, 1.5, 2.5), (-30.0, -20.0, 10.0)
+    fix, mov, (R, t, c) = _rigid_pair(pa, shape, spacing, origin)
+    mov2 = (0.4 * mov + 250.0).astype(np.float32)          # different window/level
+    img, tfm = pa.registration.linear_registration(
+        pa.image_from_array(fix, spacing, origin), pa.image_from_array(mov2, spacing, origin), reg_method="rigid", metric="correlation",
+        optimiser="gradient_descent_line_search", shrink_factors=[4, 2, 1], smooth_sigmas=[2, 1, 0], sampling_rate=0.5,
+        number_of_iterations=40, default_value=float(mov2.min()))
+    A, off = tfm.matrix_offset()
+    n = np.array(shape[::-1], dtype=np.float64) - 1
+    corners = np.array([[i, j, k] for i in (0, n[0]) for j in (0, n[1]) for k in (0, n[2])]) * np.array(spacing) + np.array(origin)
+    assert np.abs((corners @ A.T + off) - ((corners - c) @ R.T + c + t)).max() < 1.5
+    cc = np.corrcoef(fix.ravel(), img.numpy().ravel())[0, 1]
+    assert cc > 0.97, cc
 
 
 def test_linear_registration_reference_fixture_dice(host_api):
