@@ -829,7 +829,9 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     if (tu[a].r > rmax) rmax = tu[a].r;
     if (td[a].r > rmax) rmax = td[a].r;
   }
-  const bool fusable = p->smooth_update && p->smooth_displacement && rmax <= PP_FUSED_MAX_R;
+  // the fused kernels address one z-plane with 32-bit byte offsets and store 8/16-B vectors
+  const bool plane_ok = (size_t)d.nx * d.ny * sizeof(float) < ((size_t)1 << 32) && (reinterpret_cast<uintptr_t>(field) % 16 == 0);
+  const bool fusable = p->smooth_update && p->smooth_displacement && rmax <= PP_FUSED_MAX_R && plane_ok;
   int variant = p->variant;
   if (variant == PP_DEMONS_AUTO) variant = fusable ? PP_DEMONS_FUSED : PP_DEMONS_STAGED;
   if (variant == PP_DEMONS_FUSED && !fusable)

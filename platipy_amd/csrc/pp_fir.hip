@@ -78,10 +78,75 @@ __global__ void __launch_bounds__(NT) k_conv_axis(const float* __restrict__ in, 
   }
 }
 
+// x pass, 4 consecutive outputs per thread: the row is read as aligned float4 chunks (each input value is
+// loaded once per thread instead of once per tap) and every chunk is scattered into the 4 running sums.
+// Needs nx % 4 == 0 and 16-B aligned rows; edge chunks clamp per element.
+template <bool ADD>
+__global__ void __launch_bounds__(NT) k_conv_x4(const float* __restrict__ in, const float* __restrict__ add,
+                                                float* __restrict__ out, pp_dims d, size_t cstride, pp_taps taps,
+                                                const int* __restrict__ halt) {
+  if (halt && *halt) return;
+  const size_t comp = (size_t)blockIdx.y * cstride;
+  in += comp;
+  out += comp;
+  if (ADD) add += comp;
+  const int nxv = d.nx / 4;
+  const size_t total = (size_t)nxv * d.ny * d.nz;
+  const int r = taps.r;
+  const int r4 = (r + 3) / 4 * 4;
+  for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
+    const int x0 = (int)(e % nxv) * 4;
+    const size_t row = (e / nxv) * (size_t)d.nx;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    for (int o = -r4; o < 4 + r4; o += 4) {           // chunk covers inputs x0 + o .. x0 + o + 3
+      float v[4];
+      const int xa = x0 + o;
+      if (xa >= 0 && xa + 3 < d.nx) {
+        float4 q = *reinterpret_cast<const float4*>(in + row + xa);
+        if (ADD) {
+          const float4 a = *reinterpret_cast<const float4*>(add + row + xa);
+          q.x += a.x; q.y += a.y; q.z += a.z; q.w += a.w;
+        }
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int xc = pp_clampi(xa + i, 0, d.nx - 1);
+          v[i] = in[row + xc];
+          if (ADD) v[i] += add[row + xc];
+        }
+      }
+      // input at relative position p = o + i feeds output j through tap k = p - j + r
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k0 = o + i + r;                     // tap index for output 0
+        const float w0 = (k0 >= 0 && k0 <= 2 * r) ? taps.w[k0] : 0.0f;
+        const float w1 = (k0 - 1 >= 0 && k0 - 1 <= 2 * r) ? taps.w[k0 - 1] : 0.0f;
+        const float w2 = (k0 - 2 >= 0 && k0 - 2 <= 2 * r) ? taps.w[k0 - 2] : 0.0f;
+        const float w3 = (k0 - 3 >= 0 && k0 - 3 <= 2 * r) ? taps.w[k0 - 3] : 0.0f;
+        s0 = fmaf(w0, v[i], s0);
+        s1 = fmaf(w1, v[i], s1);
+        s2 = fmaf(w2, v[i], s2);
+        s3 = fmaf(w3, v[i], s3);
+      }
+    }
+    *reinterpret_cast<float4*>(out + row + x0) = make_float4(s0, s1, s2, s3);
+  }
+}
+
 template <int AXIS, bool ADD>
 int launch_axis(pp_ctx* ctx, const float* in, const float* add, float* out, const pp_dims& d, int ncomp,
                 const pp_taps& taps, const int* halt) {
   const size_t cstride = (size_t)d.nx * d.ny * d.nz;
+  if (AXIS == 0 && (d.nx % 4 == 0) && taps.r >= 3 &&
+      ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | (ADD ? reinterpret_cast<uintptr_t>(add) : 0)) % 16 == 0)) {
+    size_t blocks = (cstride / 4 + NT - 1) / NT;
+    if (blocks > 65535u * 4u) blocks = 65535u * 4u;
+    hipLaunchKernelGGL((k_conv_x4<ADD>), dim3((unsigned)blocks, (unsigned)ncomp, 1), dim3(NT, 1, 1), 0, ctx->stream, in, add, out, d,
+                       cstride, taps, halt);
+    PP_LAUNCH_CHECK(ctx, "k_conv_x4");
+    return PP_OK;
+  }
   const bool vec4 = AXIS != 0 && (d.nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) |
                                                        (ADD ? reinterpret_cast<uintptr_t>(add) : 0)) % 16 == 0);
   const size_t work = cstride / (vec4 ? 4 : 1);
