@@ -297,7 +297,7 @@ static void conv_axis_f32(const float* in, float* out, const int* n, int axis,
   const long nx = n[0], ny = n[1], nz = n[2];
   const long stride = axis == 0 ? 1 : (axis == 1 ? nx : nx * ny);
   const long len = n[axis];
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for collapse(2) schedule(static)
   for (long z = 0; z < nz; ++z)
     for (long y = 0; y < ny; ++y)
       for (long x = 0; x < nx; ++x) {
@@ -319,7 +319,7 @@ static void conv_axis_f64(const double* in, double* out, const int* n, int axis,
   const long nx = n[0], ny = n[1], nz = n[2];
   const long stride = axis == 0 ? 1 : (axis == 1 ? nx : nx * ny);
   const long len = n[axis];
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for collapse(2) schedule(static)
   for (long z = 0; z < nz; ++z)
     for (long y = 0; y < ny; ++y)
       for (long x = 0; x < nx; ++x) {
@@ -407,7 +407,7 @@ int orc_warp_image_f32(const float* moving, const orc_geom* gm, const double* fi
   geom_expand(gout, &xo);
   const long nx = gout->size[0], ny = gout->size[1], nz = gout->size[2];
   const size_t N = (size_t)nx * ny * nz;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for collapse(2) schedule(static)
   for (long z = 0; z < nz; ++z)
     for (long y = 0; y < ny; ++y)
       for (long x = 0; x < nx; ++x) {
@@ -450,7 +450,7 @@ int orc_esm_update(const float* fixed, const float* warped, const orc_geom* g,
   const float SENT = FLT_MAX; /* NumericTraits<MovingPixelType>::max() */
   double ssd = 0.0, ssc = 0.0;
   long long npx = 0;
-#pragma omp parallel for schedule(static) reduction(+ : ssd, ssc, npx)
+#pragma omp parallel for collapse(2) schedule(static) reduction(+ : ssd, ssc, npx)
   for (long z = 0; z < n[2]; ++z)
     for (long y = 0; y < n[1]; ++y)
       for (long x = 0; x < n[0]; ++x) {
@@ -654,7 +654,7 @@ static inline void xform_point(const xform* T, const double* p, double* q) {
   T.field = field;                                                                 \
   if (field) geom_expand(gd, &T.gd);                                               \
   const long nx = gout->size[0], ny = gout->size[1], nz = gout->size[2];           \
-  _Pragma("omp parallel for schedule(static)") for (long z = 0; z < nz; ++z)      \
+  _Pragma("omp parallel for collapse(2) schedule(static)") for (long z = 0; z < nz; ++z) \
       for (long y = 0; y < ny; ++y) for (long x = 0; x < nx; ++x) {                \
     const size_t i = ((size_t)z * ny + y) * nx + x;                                \
     double p[3], q[3], c[3];                                                       \
