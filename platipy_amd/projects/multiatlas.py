@@ -125,44 +125,51 @@ class _Dist:
         return out
 
 
+_STREAM_POOL = {}   # device index -> long-lived worker streams (each owns one pp_ctx + workspace, see runtime.context)
+
+
+def _worker_streams(device, n):
+    pool = _STREAM_POOL.setdefault(device.index, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device))
+    return pool[:n]
+
+
 def _map_atlases(fn, ids, streams_per_gpu, device):
-    """Run fn(atlas_id) for this rank's atlases, `streams_per_gpu` at a time, each worker thread on its own
-    HIP stream (its own pp_ctx: runtime.context is keyed by thread and follows torch's current stream)."""
+    """Run fn(atlas_id) for this rank's atlases, `streams_per_gpu` at a time.  Each worker thread runs under its own
+    long-lived HIP stream, hence its own pp_ctx (runtime.context follows torch's current stream), so one atlas's
+    small coarse-level kernels overlap another's; ctypes calls release the GIL."""
     if streams_per_gpu <= 1 or len(ids) <= 1 or device.type != "cuda":
         return {i: fn(i) for i in ids}
+    import queue
+
     main = torch.cuda.current_stream(device)
     ready = torch.cuda.Event()
     ready.record(main)
+    free = queue.SimpleQueue()
+    for s in _worker_streams(device, min(streams_per_gpu, len(ids))):
+        free.put(s)
 
     def work(i):
         torch.cuda.set_device(device)
-        s = _thread_stream(device)
-        s.wait_event(ready)
-        with torch.cuda.stream(s):
-            out = fn(i)
-            done = torch.cuda.Event()
-            done.record(s)
-        return out, done
+        s = free.get()
+        try:
+            s.wait_event(ready)
+            with torch.cuda.stream(s):
+                out = fn(i)
+                done = torch.cuda.Event()
+                done.record(s)
+            return out, done
+        finally:
+            free.put(s)
 
-    with ThreadPoolExecutor(max_workers=streams_per_gpu) as ex:
+    with ThreadPoolExecutor(max_workers=min(streams_per_gpu, len(ids))) as ex:
         res = dict(zip(ids, ex.map(work, ids)))
     out = {}
     for i, (val, done) in res.items():
         main.wait_event(done)
         out[i] = val
     return out
-
-
-_TLS_STREAMS = {}
-
-
-def _thread_stream(device):
-    import threading
-
-    key = (threading.get_ident(), device.index)
-    if key not in _TLS_STREAMS:
-        _TLS_STREAMS[key] = torch.cuda.Stream(device)
-    return _TLS_STREAMS[key]
 
 
 def run_segmentation(img, settings=MUTLIATLAS_SETTINGS_DEFAULTS, atlases=None, streams_per_gpu=1, return_atlas_set=False):

@@ -16,8 +16,10 @@ def default_device():
 
 
 def context(device=None):
-    """The pp_ctx for `device` (default: current CUDA device), re-pointed at torch's current stream so
-    kernels order correctly with surrounding torch work.  One ctx per (thread, device)."""
+    """The pp_ctx bound to torch's CURRENT stream on `device` (default: current CUDA device).  One ctx -- and one
+    scratch workspace -- per (device, stream): kernels order with surrounding torch work on that stream, and worker
+    threads that each run under their own `torch.cuda.stream(...)` get independent contexts that persist across
+    calls (streams are long-lived; nothing is keyed by thread)."""
     if not torch.cuda.is_available():
         raise _lib.PlatipyAmdError("platipy_amd needs a ROCm GPU: there is no CPU fallback")
     if device is None:
@@ -26,17 +28,13 @@ def context(device=None):
         idx = torch.device(device).index
         if idx is None:
             idx = torch.cuda.current_device()
-    key = (threading.get_ident(), idx)
     stream = torch.cuda.current_stream(idx).cuda_stream
+    key = (idx, stream)
     with _LOCK:
         ctx = _CTX.get(key)
         if ctx is None:
             ctx = _lib.Context(idx, stream)
             _CTX[key] = ctx
-            ctx._stream = stream
-    if ctx._stream != stream:
-        ctx.set_stream(stream)
-        ctx._stream = stream
     return ctx
 
 
