@@ -34,20 +34,18 @@ struct pp_dev_stats {
 };
 
 struct pp_esm_consts {
-  float hx, hy, hz;   // 0.5 / spacing
-  float ix, iy, iz;   // 1 / spacing
-  float inv_norm;     // 1 / normalizer (unused when !has_norm)
+  float ix, iy, iz;     // 1 / spacing; the central-difference factor 0.5 / spacing is exactly half of it
+  float inv_norm;       // 1 / normalizer, or 0 when MaximumUpdateStepLength <= 0 (then denom = |J|^2)
   float denom_thr;
   float intensity_thr;  // smallest float >= the fp64 threshold: |s| < thr decides exactly as in fp64
-  int has_norm;
 };
 
 // One axis of the symmetric ESM gradient: itk::CentralDifferenceImageFunction on the fixed
 // image (zero on the first/last index) plus the sentinel-aware difference of the warped moving
 // image that ESMDemonsRegistrationFunction::ComputeUpdate builds "more or less by hand".
 // lo / hi: the voxel is the first / last one along this axis (both set: the axis has one voxel).
-__device__ __forceinline__ float pp_esm_axis(float fm, float fp, float mc, float mm, float mp, bool lo, bool hi, float h,
-                                             float inv_sp) {
+__device__ __forceinline__ float pp_esm_axis(float fm, float fp, float mc, float mm, float mp, bool lo, bool hi, float inv_sp) {
+  const float h = 0.5f * inv_sp;
   // Branch-free form of ITK's case analysis: a neighbour is usable when it exists and is not the sentinel;
   // both usable -> central difference, one usable -> one-sided, none -> 0.  Unused candidates may hold
   // inf (sentinel arithmetic) but are only ever selected away, never blended.
@@ -72,9 +70,9 @@ __device__ __forceinline__ pp_esm_out pp_esm_voxel(const pp_esm_consts& K, float
   const bool mapped = (mc != FLT_MAX);
   const float speed = fc - mc;
   const float g2 = gx * gx + gy * gy + gz * gz;
-  const float denom = K.has_norm ? g2 + speed * speed * K.inv_norm : g2;
+  const float denom = g2 + speed * speed * K.inv_norm;
   const bool live = mapped && !(fabsf(speed) < K.intensity_thr) && !(denom < K.denom_thr);
-  const float factor = live ? __fdividef(2.0f * speed, denom) : 0.0f;
+  const float factor = live ? 2.0f * speed * __builtin_amdgcn_rcpf(denom) : 0.0f;   // v_rcp_f32: 1 ulp
   pp_esm_out o;
   o.ux = live ? factor * gx : 0.0f;
   o.uy = live ? factor * gy : 0.0f;
@@ -104,9 +102,9 @@ __global__ void __launch_bounds__(NT) k_demons_force(const float* __restrict__ F
     const size_t ym = y > 0 ? i - sy : i, yp = y < d.ny - 1 ? i + sy : i;
     const size_t zm = z > 0 ? i - sz : i, zp = z < d.nz - 1 ? i + sz : i;
     const float fc = F[i], mc = Mw[i];
-    const float gx = pp_esm_axis(F[xm], F[xp], mc, Mw[xm], Mw[xp], x == 0, x == d.nx - 1, K.hx, K.ix);
-    const float gy = pp_esm_axis(F[ym], F[yp], mc, Mw[ym], Mw[yp], y == 0, y == d.ny - 1, K.hy, K.iy);
-    const float gz = pp_esm_axis(F[zm], F[zp], mc, Mw[zm], Mw[zp], z == 0, z == d.nz - 1, K.hz, K.iz);
+    const float gx = pp_esm_axis(F[xm], F[xp], mc, Mw[xm], Mw[xp], x == 0, x == d.nx - 1, K.ix);
+    const float gy = pp_esm_axis(F[ym], F[yp], mc, Mw[ym], Mw[yp], y == 0, y == d.ny - 1, K.iy);
+    const float gz = pp_esm_axis(F[zm], F[zp], mc, Mw[zm], Mw[zp], z == 0, z == d.nz - 1, K.iz);
     const pp_esm_out o = pp_esm_voxel(K, fc, mc, gx, gy, gz);
     U[i] = o.ux;
     U[N + i] = o.uy;
@@ -236,7 +234,7 @@ __device__ __forceinline__ void fused_xpass(const float* __restrict__ us /*[3][U
     for (int j = 0; j < 4; ++j) {
       float s = 0.0f;
 #pragma unroll
-      for (int k = 0; k < 2 * R + 1; ++k) s = fmaf(wx.w[k], in[j + k], s);
+      for (int k = 0; k < 2 * R + 1; ++k) s = fmaf(wx.h[k < R ? R - k : k - R], in[j + k], s);
       o[j] = s;
     }
     *reinterpret_cast<float4*>(xs + (c * G::UH + uy) * TX + 4 * cx) = make_float4(o[0], o[1], o[2], o[3]);
@@ -255,14 +253,16 @@ __device__ __forceinline__ void fused_ypass(const float* __restrict__ xs, int c,
     const float* p = xs + (c * G::UH + cy + k) * TX + OPT * cx;
     if (OPT == 4) {
       const float4 a = *reinterpret_cast<const float4*>(p);
-      v[0] = fmaf(wy.w[k], a.x, v[0]);
-      v[1] = fmaf(wy.w[k], a.y, v[1]);
-      v[2] = fmaf(wy.w[k], a.z, v[2]);
-      v[3] = fmaf(wy.w[k], a.w, v[3]);
+      const float w = wy.h[k < R ? R - k : k - R];
+      v[0] = fmaf(w, a.x, v[0]);
+      v[1] = fmaf(w, a.y, v[1]);
+      v[2] = fmaf(w, a.z, v[2]);
+      v[3] = fmaf(w, a.w, v[3]);
     } else {
       const float2 a = *reinterpret_cast<const float2*>(p);
-      v[0] = fmaf(wy.w[k], a.x, v[0]);
-      v[1] = fmaf(wy.w[k], a.y, v[1]);
+      const float w = wy.h[k < R ? R - k : k - R];
+      v[0] = fmaf(w, a.x, v[0]);
+      v[1] = fmaf(w, a.y, v[1]);
     }
   }
 }
@@ -283,7 +283,7 @@ struct zring {
   __device__ __forceinline__ float dot(int c, int j, const pp_taps_small& wz) const {
     float s = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 2 * R + 1; ++k) s = fmaf(wz.w[k], r[c][j][k], s);
+    for (int k = 0; k < 2 * R + 1; ++k) s = fmaf(wz.h[k < R ? R - k : k - R], r[c][j][k], s);
     return s;
   }
 };
@@ -455,10 +455,10 @@ __global__ void __launch_bounds__(TX * TY / OPT, PP_A_WAVES) k_fused_force_smoot
         if (fl & F_VALID) {
           const int l = (int)(slots[k] & 0xffffu);
           const float gx = pp_esm_axis(s_f[l - 1], s_f[l + 1], mcur[k], s_m[l - 1], s_m[l + 1], (fl & F_XLO) != 0,
-                                       (fl & F_XHI) != 0, K.hx, K.ix);
+                                       (fl & F_XHI) != 0, K.ix);
           const float gy = pp_esm_axis(s_f[l - G::MWP], s_f[l + G::MWP], mcur[k], s_m[l - G::MWP], s_m[l + G::MWP],
-                                       (fl & F_YLO) != 0, (fl & F_YHI) != 0, K.hy, K.iy);
-          const float gz = pp_esm_axis(fprev[k], fnext[k], mcur[k], mprev[k], mnext[k], zlo_b, zhi_b, K.hz, K.iz);
+                                       (fl & F_YLO) != 0, (fl & F_YHI) != 0, K.iy);
+          const float gz = pp_esm_axis(fprev[k], fnext[k], mcur[k], mprev[k], mnext[k], zlo_b, zhi_b, K.iz);
           const pp_esm_out o = pp_esm_voxel(K, fcur[k], mcur[k], gx, gy, gz);
           const int u = (int)(uflag[k] & 0xffffu);
           s_u[u] = o.ux;
@@ -656,9 +656,6 @@ __global__ void __launch_bounds__(TX * TY / OPT, PP_B_WAVES) k_fused_add_smooth_
 // host side
 
 void esm_consts(const pp_geom* g, const pp_demons_params* p, pp_esm_consts* K) {
-  K->hx = (float)(0.5 / g->spacing[0]);
-  K->hy = (float)(0.5 / g->spacing[1]);
-  K->hz = (float)(0.5 / g->spacing[2]);
   K->ix = (float)(1.0 / g->spacing[0]);
   K->iy = (float)(1.0 / g->spacing[1]);
   K->iz = (float)(1.0 / g->spacing[2]);
@@ -667,10 +664,8 @@ void esm_consts(const pp_geom* g, const pp_demons_params* p, pp_esm_consts* K) {
     for (int k = 0; k < 3; ++k) nrm += g->spacing[k] * g->spacing[k];
     nrm *= p->max_step_length * p->max_step_length / 3.0;
     K->inv_norm = (float)(1.0 / nrm);
-    K->has_norm = 1;
   } else {
     K->inv_norm = 0.0f;
-    K->has_norm = 0;
   }
   K->denom_thr = (float)p->denominator_threshold;
   float thr = (float)p->intensity_threshold;
@@ -679,8 +674,8 @@ void esm_consts(const pp_geom* g, const pp_demons_params* p, pp_esm_consts* K) {
 }
 
 void small_taps(const pp_taps& t, int R, pp_taps_small* s) {
-  for (int k = 0; k < 2 * PP_FUSED_MAX_R + 1; ++k) s->w[k] = 0.0f;
-  for (int k = -t.r; k <= t.r; ++k) s->w[k + R] = t.w[k + t.r];  // centred; outer taps stay 0
+  (void)R;
+  for (int k = 0; k <= PP_FUSED_MAX_R; ++k) s->h[k] = k <= t.r ? t.w[t.r + k] : 0.0f;  // taps beyond the axis radius stay 0
 }
 
 // z-chunk length: long chunks amortise the 2R (+3 image) halo planes, but the launch should fill the

@@ -105,7 +105,7 @@ int pp_make_taps(pp_ctx* ctx, double variance, double max_error, int max_kernel_
 // Small-radius taps passed by value to the fused kernels.
 #define PP_FUSED_MAX_R 5
 struct pp_taps_small {
-  float w[2 * PP_FUSED_MAX_R + 1];
+  float h[PP_FUSED_MAX_R + 1];  // symmetric kernel: h[0] = centre, h[k] = taps at distance k
 };
 
 // ---------------------------------------------------------------------------------------

@@ -127,3 +127,4 @@ static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline int __float2int_rd(float x) { return (int)floorf(x); }
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
 static inline float __fdividef(float a, float b) { return a / b; }
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))   // v_rcp_f32 (1 ulp) on the GPU
