@@ -44,6 +44,7 @@ typedef enum {
 } pp_status;
 
 enum { PP_INTERP_NEAREST = 1, PP_INTERP_LINEAR = 2 }; /* = sitk.sitkNearestNeighbor / sitkLinear */
+enum { PP_MORPH_DILATE = 0, PP_MORPH_ERODE = 1, PP_MORPH_CLOSE = 2 };
 
 enum { PP_DEMONS_AUTO = 0, PP_DEMONS_STAGED = 1, PP_DEMONS_FUSED = 2 };
 
@@ -192,6 +193,14 @@ int pp_binary_threshold_f32(pp_ctx* ctx, const float* prob, size_t n, double max
  * component_voxels (host, may be NULL) receives the size of the kept component; non-NULL synchronises. */
 int pp_fillhole_largest_component_u8(pp_ctx* ctx, const uint8_t* in, const int size[3], int fill_holes,
                                      uint8_t* out, int64_t* component_voxels);
+
+/* sitk.BinaryDilate / BinaryErode / BinaryMorphologicalClosing(mask, radius) with SimpleITK's defaults
+ * (registration/utils.py:328-329; projects/multiatlas/run.py:421-423, projects/cardiac/run.py:1127-1129):
+ * kernel = ITK ball, offset d in the element when sum_i (d_i / (radius_i + 0.5))^2 <= 1; dilation sees background
+ * and erosion foreground outside the buffer; PP_MORPH_CLOSE = dilate then erode with a safe border (as if padded
+ * by the radius).  Masks are 0 / non-zero in, 0 / 1 out; radius in voxels per axis (x, y, z), each <= 15. */
+int pp_binary_morph_ball_u8(pp_ctx* ctx, const uint8_t* in, const int size[3], const int radius[3], int op,
+                            uint8_t* out);
 
 /* ---- iterative atlas removal ------------------------------------------------------- */
 /* sitk.LabelContour(mask) with face connectivity (label/projection.py:85): object voxels that have a face

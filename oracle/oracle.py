@@ -501,6 +501,48 @@ def process_probability_image(prob, threshold=0.5):
 
 
 # --------------------------------------------------------------------------------------
+# binary morphology with ITK's ball (registration/utils.py:328-329; multiatlas/run.py:421-423)
+
+
+def ball_element(radius):
+    """[ITK-upstream FlatStructuringElement::Ball(radius), radiusIsParametric = False] as a [Z][Y][X] bool array:
+    voxel offset d is in the element when sum_i (d_i / (r_i + 0.5))^2 <= 1 (ellipsoid of axes 2 r_i + 1 around
+    the centre voxel, pixel-centre inclusion)."""
+    rx, ry, rz = (int(r) for r in radius)
+    z, y, x = np.mgrid[-rz:rz + 1, -ry:ry + 1, -rx:rx + 1].astype(np.float64)
+    s = (x / (rx + 0.5)) ** 2
+    s = s + (y / (ry + 0.5)) ** 2
+    s = s + (z / (rz + 0.5)) ** 2
+    return s <= 1.0
+
+
+def binary_dilate_ball(mask_vol, radius):
+    """sitk.BinaryDilate(mask, radius) with defaults: ball kernel, background outside the image."""
+    from scipy import ndimage
+
+    out = ndimage.binary_dilation(mask_vol.arr != 0, structure=ball_element(radius), border_value=0)
+    return mask_vol.like(out.astype(np.uint8))
+
+
+def binary_erode_ball(mask_vol, radius):
+    """sitk.BinaryErode(mask, radius) with defaults: ball kernel, boundaryToForeground = True."""
+    from scipy import ndimage
+
+    out = ndimage.binary_erosion(mask_vol.arr != 0, structure=ball_element(radius), border_value=1)
+    return mask_vol.like(out.astype(np.uint8))
+
+
+def binary_closing_ball(mask_vol, radius):
+    """sitk.BinaryMorphologicalClosing(mask, radius) with defaults (safeBorder = True): pad by the radius with
+    background, dilate, erode, crop."""
+    rx, ry, rz = (int(r) for r in radius)
+    padded = Vol(np.pad(mask_vol.arr != 0, [(rz, rz), (ry, ry), (rx, rx)]).astype(np.uint8), mask_vol.spacing, mask_vol.origin)
+    a = binary_erode_ball(binary_dilate_ball(padded, radius), radius).arr
+    a = a[rz:a.shape[0] - rz, ry:a.shape[1] - ry, rx:a.shape[2] - rx]
+    return mask_vol.like(np.ascontiguousarray(a))
+
+
+# --------------------------------------------------------------------------------------
 # platipy/imaging/label/projection.py:67-92 helpers
 
 

@@ -27,4 +27,5 @@ __version__ = "0.1.0"
 
 from . import registration  # noqa: E402,F401
 from . import label  # noqa: E402,F401
+from . import generation  # noqa: E402,F401
 from . import projects  # noqa: E402,F401

@@ -95,6 +95,7 @@ _SIGNATURES = {
     "pp_rescale_threshold_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, C.c_float]),
     "pp_binary_threshold_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_double, C.c_double, _P]),
     "pp_fillhole_largest_component_u8": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.c_int, _P, C.POINTER(C.c_int64)]),
+    "pp_binary_morph_ball_u8": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, _P]),
     "pp_label_contour_u8": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P]),
     "pp_distance_map_f32": (C.c_int, [_P, _P, C.POINTER(Geom), C.c_int, C.c_int, _P]),
     "pp_meansq_affine_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double),
@@ -318,6 +319,11 @@ class Context:
         self._chk(self.lib.pp_fillhole_largest_component_u8(self.h, ptr(mask), _i3(size), int(bool(fill_holes)), ptr(out),
                                                             C.byref(n) if want_count else None), "pp_fillhole_largest_component_u8")
         return n.value if want_count else None
+
+    def binary_morph_ball(self, mask, size, radius, op, out):
+        """op: 0 dilate, 1 erode, 2 closing (safe border); ITK ball of `radius` voxels (x, y, z)."""
+        self._chk(self.lib.pp_binary_morph_ball_u8(self.h, ptr(mask), _i3(size), _i3(radius), int(op), ptr(out)),
+                  "pp_binary_morph_ball_u8")
 
     def label_contour(self, mask, size, out):
         self._chk(self.lib.pp_label_contour_u8(self.h, ptr(mask), _i3(size), ptr(out)), "pp_label_contour_u8")

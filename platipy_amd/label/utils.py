@@ -1,9 +1,62 @@
 """Drop-in for the pieces of platipy/imaging/label/utils.py the pipelines use after fusion:
-correct_volume_overlap (:23-58).  Element-wise tensor arithmetic on the GPU."""
+correct_volume_overlap (:23-58, element-wise tensor arithmetic on the GPU), plus the binary-mask SimpleITK calls
+the pipelines make inline -- BinaryDilate / BinaryErode / BinaryMorphologicalClosing with the ball kernel and
+"RelabelComponent(ConnectedComponent(x)) == 1" -- as HIP kernels (pp_morph.hip, pp_cc.hip)."""
 import numpy as np
 import torch
 
+from .. import runtime
 from ..image import as_image
+
+_DILATE, _ERODE, _CLOSE = 0, 1, 2
+
+
+def _u8(image):
+    t = image.tensor
+    return (t if t.dtype == torch.uint8 else (t != 0).to(torch.uint8)).contiguous()
+
+
+def _radius3(image, radius):
+    if not hasattr(radius, "__iter__"):
+        radius = [radius] * 3
+    radius = [int(r) for r in radius]
+    if len(radius) != 3 or min(radius) < 0:
+        raise ValueError(f"kernel radius must be three non-negative voxel counts, got {radius}")
+    return radius
+
+
+def _morph(mask, radius, op):
+    mask = as_image(mask)
+    radius = _radius3(mask, radius)
+    src = _u8(mask)
+    out = torch.empty_like(src)
+    runtime.context(mask.device).binary_morph_ball(src, mask.GetSize(), radius, op, out)
+    return mask.like(out)
+
+
+def binary_dilate(mask, radius):
+    """sitk.BinaryDilate(mask, radius): ball kernel, radius in voxels (x, y, z) (registration/utils.py:328-329)."""
+    return _morph(mask, radius, _DILATE)
+
+
+def binary_erode(mask, radius):
+    """sitk.BinaryErode(mask, radius): ball kernel, the image boundary counts as foreground."""
+    return _morph(mask, radius, _ERODE)
+
+
+def binary_morphological_closing(mask, radius):
+    """sitk.BinaryMorphologicalClosing(mask, radius), safe border (multiatlas/run.py:422, cardiac/run.py:1128)."""
+    return _morph(mask, radius, _CLOSE)
+
+
+def largest_component(mask):
+    """sitk.RelabelComponent(sitk.ConnectedComponent(mask)) == 1 (multiatlas/run.py:421): the largest
+    face-connected component, the first in raster order on ties; an empty mask stays empty."""
+    mask = as_image(mask)
+    src = _u8(mask)
+    out = torch.empty_like(src)
+    runtime.context(mask.device).fillhole_largest_component(src, mask.GetSize(), out, fill_holes=False)
+    return mask.like(out)
 
 
 def correct_volume_overlap(binary_label_dict, assign_overlap_to_largest=True):

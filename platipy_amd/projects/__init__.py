@@ -1,1 +1,2 @@
 from . import multiatlas  # noqa: F401
+from . import cardiac  # noqa: F401

@@ -29,7 +29,8 @@ from ..image import Image, as_image
 from ..label.fusion import compute_weight_map, finalize_probability, process_probability_image
 from ..registration.deformable import fast_symmetric_forces_demons_registration
 from ..registration.linear import linear_registration
-from ..registration.utils import apply_transform
+from ..generation.mask import extend_mask
+from ..registration.utils import apply_transform, convert_mask_to_reg_structure
 from ..transform import sitkLinear, sitkNearestNeighbor
 from ..utils.crop import crop_to_roi, label_to_roi, paste
 
@@ -172,6 +173,12 @@ def _map_atlases(fn, ids, streams_per_gpu, device):
     return out
 
 
+def _mask_outside(image, mask, outside_value):
+    """sitk.Mask(image, mask, outsideValue): image where mask != 0, outsideValue elsewhere."""
+    t = image.tensor
+    return image.like(torch.where(mask != 0, t, torch.full((), outside_value, dtype=t.dtype, device=t.device)))
+
+
 def run_segmentation(img, settings=MUTLIATLAS_SETTINGS_DEFAULTS, atlases=None, streams_per_gpu=1, return_atlas_set=False):
     """Runs the atlas-based segmentation (reference multiatlas/run.py:106-441).
 
@@ -179,22 +186,42 @@ def run_segmentation(img, settings=MUTLIATLAS_SETTINGS_DEFAULTS, atlases=None, s
     holding at least this rank's share (atlas_id_list[rank::world_size]); a rank may hold them all.
     Returns (results, results_prob): {structure: uint8 Image}, {structure: fp32 probability Image}, on every rank.
     """
+    out = atlas_pipeline(img, settings, None, atlases, streams_per_gpu, cardiac=False)
+    run_segmentation.last_iar_removed = out["iar_removed"]
+    if return_atlas_set:
+        return out["results"], out["results_prob"], out["atlas_set"]
+    return out["results"], out["results_prob"]
+
+
+def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_per_gpu=1, cardiac=False):
+    """The skeleton shared by run_segmentation (multiatlas/run.py:106-441) and run_cardiac_segmentation
+    (cardiac/run.py:507-1147): read atlases -> crop the target -> per atlas [linear -> (structure-guided demons)
+    -> demons -> propagate] -> (iterative atlas removal) -> weight maps -> fuse -> threshold -> paste back ->
+    post-process.  `cardiac` selects the cardiac pipeline's result conventions (only structures with an
+    optimal_threshold are voted, the guide structure is handed back, return_as_cropped).
+    Returns a dict: results, results_prob, atlas_set, iar_removed, img_crop."""
     img = as_image(img)
     settings = copy.deepcopy(settings)
     dd = _Dist()
     device = img.device
-    atlas_id_list = list(settings["atlas_settings"]["atlas_id_list"])
-    atlas_structure_list = list(settings["atlas_settings"]["atlas_structure_list"])
+    a_set = settings["atlas_settings"]
+    atlas_id_list = list(a_set["atlas_id_list"])
+    atlas_structure_list = list(a_set["atlas_structure_list"])
+    guided = guide_structure is not None     # the reference tests `if guide_structure:` on a sitk.Image (always true)
+    guide_structure_name = a_set.get("guide_structure_name") if guided else None
+    if guided:
+        guide_structure = as_image(guide_structure)
+        if not guide_structure_name:
+            raise KeyError("atlas_settings['guide_structure_name'] is needed with a guide structure")
     my_ids = atlas_id_list[dd.rank::dd.world]
-    if atlases is None:     # multiatlas/run.py:155-170: read this rank's atlases from disk
+    if atlases is None:     # multiatlas/run.py:155-170, cardiac/run.py:560-568: read this rank's atlases from disk
         from ..io import read_image
 
-        a = settings["atlas_settings"]
         atlases = {}
         for atlas_id in my_ids:
-            entry = {"CT Image": read_image(f"{a['atlas_path']}/{a['atlas_image_format'].format(atlas_id)}", device)}
+            entry = {"CT Image": read_image(f"{a_set['atlas_path']}/{a_set['atlas_image_format'].format(atlas_id)}", device)}
             for struct in atlas_structure_list:
-                entry[struct] = read_image(f"{a['atlas_path']}/{a['atlas_label_format'].format(atlas_id, struct)}", device)
+                entry[struct] = read_image(f"{a_set['atlas_path']}/{a_set['atlas_label_format'].format(atlas_id, struct)}", device)
             atlases[atlas_id] = entry
 
     # ---- initialisation: optional crop of each atlas to its structures (:172-190) ----
@@ -203,64 +230,99 @@ def run_segmentation(img, settings=MUTLIATLAS_SETTINGS_DEFAULTS, atlases=None, s
         src = atlases[atlas_id]
         image = as_image(src["CT Image"])
         structures = {s: as_image(src[s]) for s in atlas_structure_list if s in src}
-        if settings["atlas_settings"].get("crop_atlas_to_structures", False):
-            size, index = label_to_roi(list(structures.values()), expansion_mm=settings["atlas_settings"]["crop_atlas_expansion_mm"])
+        if a_set.get("crop_atlas_to_structures", False):
+            size, index = label_to_roi(list(structures.values()), expansion_mm=a_set["crop_atlas_expansion_mm"])
             image = crop_to_roi(image, size, index)
             structures = {s: crop_to_roi(v, size, index) for s, v in structures.items()}
         atlas_set[atlas_id] = {"Original": {"CT Image": image, **structures}}
 
-    # ---- step 1: automatic cropping of the target (:203-249) ----
+    # ---- step 1: automatic cropping of the target (multiatlas :203-249; cardiac :603-659) ----
     expansion_mm = settings["auto_crop_target_image_settings"]["expansion_mm"]
-    crop_ids = atlas_id_list[: min(8, len(atlas_id_list))]
-    mine = [a for a in crop_ids if a in atlas_set]
+    if guided:
+        crop_box_size, crop_box_index = label_to_roi(guide_structure, expansion_mm=expansion_mm)
+        img_crop = crop_to_roi(img, crop_box_size, crop_box_index)
+        guide_structure = crop_to_roi(guide_structure, crop_box_size, crop_box_index)
+        target_reg_structure = convert_mask_to_reg_structure(guide_structure, expansion=2)
+        superior_extension = a_set["superior_extension"]
+        expanded_target_mask = extend_mask(guide_structure, direction=("ax", "sup"), extension_mm=superior_extension,
+                                           interior_mm_shape=superior_extension / 2)
+    else:
+        crop_ids = atlas_id_list[: min(8, len(atlas_id_list))]
+        mine = [a for a in crop_ids if a in atlas_set]
 
-    def quick(atlas_id):
-        reg_image, _ = linear_registration(img, atlas_set[atlas_id]["Original"]["CT Image"], **QUICK_REG_SETTINGS)
-        return reg_image.tensor.float()
+        def quick(atlas_id):
+            reg_image, _ = linear_registration(img, atlas_set[atlas_id]["Original"]["CT Image"], **QUICK_REG_SETTINGS)
+            return reg_image.tensor.float()
 
-    acc = torch.zeros(img.shape, dtype=torch.float32, device=device)
-    for t in _map_atlases(quick, mine, streams_per_gpu, device).values():
-        acc += t
-    dd.all_reduce_sum(acc)
-    combined = img.like(((acc / float(len(crop_ids))) > -1000).to(torch.uint8))
-    crop_box_size, crop_box_index = label_to_roi(combined, expansion_mm=expansion_mm)
-    img_crop = crop_to_roi(img, crop_box_size, crop_box_index)
-    del acc, combined
+        acc = torch.zeros(img.shape, dtype=torch.float32, device=device)
+        for t in _map_atlases(quick, mine, streams_per_gpu, device).values():
+            acc += t
+        dd.all_reduce_sum(acc)
+        combined = img.like(((acc / float(len(crop_ids))) > -1000).to(torch.uint8))
+        crop_box_size, crop_box_index = label_to_roi(combined, expansion_mm=expansion_mm)
+        img_crop = crop_to_roi(img, crop_box_size, crop_box_index)
+        del acc, combined
 
-    # ---- steps 2-4a, per atlas: linear -> propagate -> demons -> propagate -> weight map (:261-362) ----
+    # ---- steps 2-3, per atlas: linear -> propagate -> [guided demons -> propagate] -> demons -> propagate ----
     lin_set = settings["linear_registration_settings"]
     dir_set = settings["deformable_registration_settings"]
-    vote_type = settings["label_fusion_settings"]["vote_type"]
-    vote_params = settings["label_fusion_settings"]["vote_params"]
+    sg_set = settings.get("structure_guided_registration_settings") if guided else None
 
     def chain(atlas_id):
         orig = atlas_set[atlas_id]["Original"]
-        _, initial_tfm = linear_registration(img_crop, orig["CT Image"], **lin_set)
-        rir = {"Transform": initial_tfm,
+        if guided:      # cardiac :682-688: register the guide structures' distance-map images, not the CTs
+            target_reg_image = target_reg_structure
+            atlas_reg_image = convert_mask_to_reg_structure(orig[guide_structure_name], expansion=2)
+        else:
+            target_reg_image, atlas_reg_image = img_crop, orig["CT Image"]
+        _, initial_tfm = linear_registration(target_reg_image, atlas_reg_image, **lin_set)
+        cur = {"Transform": initial_tfm,
                "CT Image": apply_transform(orig["CT Image"], img_crop, initial_tfm, -1000, sitkLinear)}
         for s in atlas_structure_list:
             if s in orig:
-                rir[s] = apply_transform(orig[s], img_crop, initial_tfm, 0, sitkNearestNeighbor)
-        _, dir_tfm, _ = fast_symmetric_forces_demons_registration(img_crop, rir["CT Image"], **dir_set)
+                cur[s] = apply_transform(orig[s], img_crop, initial_tfm, 0, sitkNearestNeighbor)
+        if guided:      # cardiac :700-722, :766-816
+            reg_mask = apply_transform(atlas_reg_image, img_crop, initial_tfm, 0, sitkLinear)
+            expanded = extend_mask(orig[guide_structure_name], direction=("ax", "sup"), extension_mm=superior_extension,
+                                   interior_mm_shape=superior_extension / 2)
+            expanded = apply_transform(expanded, img_crop, initial_tfm, 0, sitkNearestNeighbor)
+            _, sg_tfm, _ = fast_symmetric_forces_demons_registration(target_reg_structure, reg_mask, **sg_set)
+            nxt = {"Transform": sg_tfm,
+                   "CT Image": apply_transform(cur["CT Image"], transform=sg_tfm, default_value=-1000, interpolator=sitkLinear)}
+            expanded = apply_transform(expanded, img_crop, sg_tfm, 0, sitkNearestNeighbor)
+            for s in atlas_structure_list:
+                if s in cur:
+                    nxt[s] = apply_transform(cur[s], transform=sg_tfm, default_value=0, interpolator=sitkNearestNeighbor)
+            cur = nxt
+            # cardiac :834-849: both images are masked to the union of the extended guide structures and to the
+            # atlas image's soft tissue before the intensity-driven demons
+            combined_mask = torch.maximum(expanded.tensor, expanded_target_mask.tensor.to(expanded.tensor.dtype))
+            atlas_reg_image = _mask_outside(cur["CT Image"], combined_mask, -1000)
+            atlas_reg_image = _mask_outside(atlas_reg_image, atlas_reg_image.tensor > -400, -1000)
+            target_reg_image = _mask_outside(img_crop, combined_mask, -1000)
+            target_reg_image = _mask_outside(target_reg_image, atlas_reg_image.tensor > -400, -1000)
+        else:
+            target_reg_image, atlas_reg_image = img_crop, cur["CT Image"]
+        _, dir_tfm, _ = fast_symmetric_forces_demons_registration(target_reg_image, atlas_reg_image, **dir_set)
         out = {"Transform": dir_tfm,
-               "CT Image": apply_transform(rir["CT Image"], transform=dir_tfm, default_value=-1000, interpolator=sitkLinear)}
+               "CT Image": apply_transform(cur["CT Image"], transform=dir_tfm, default_value=-1000, interpolator=sitkLinear)}
         for s in atlas_structure_list:
-            if s in rir:
-                out[s] = apply_transform(rir[s], transform=dir_tfm, default_value=0, interpolator=sitkNearestNeighbor)
-        out["Weight Map"] = compute_weight_map(img_crop, out["CT Image"], vote_type=vote_type, vote_params=vote_params)
+            if s in cur:
+                out[s] = apply_transform(cur[s], transform=dir_tfm, default_value=0, interpolator=sitkNearestNeighbor)
         return out
 
     for atlas_id, out in _map_atlases(chain, my_ids, streams_per_gpu, device).items():
         atlas_set[atlas_id]["Original"] = None
         atlas_set[atlas_id]["DIR"] = out
 
-    # ---- optional: iterative atlas removal (cardiac/run.py:879-891 -> label/iar.py) ----
+    # ---- step 4: iterative atlas removal on global-vote weights (cardiac/run.py:879-891 -> label/iar.py) ----
     iar = dict(settings.get("iar_settings") or {})
     ref_struct = iar.pop("reference_structure", False)
+    removed = []
     if ref_struct:
         from ..label.iar import run_iar
 
-        # every rank needs every atlas's propagated reference structure + weight map: all_gather them slot by slot
+        # every rank needs every atlas's propagated reference structure + weight: all_gather them slot by slot
         # (slot k of rank r is atlas_id_list[r + k * world]); all ranks then run the same, deterministic selection.
         slots = (len(atlas_id_list) + dd.world - 1) // dd.world
         full_set = {}
@@ -269,7 +331,7 @@ def run_segmentation(img, settings=MUTLIATLAS_SETTINGS_DEFAULTS, atlases=None, s
             if have:
                 d = atlas_set[my_ids[k]]["DIR"]
                 m = (d[ref_struct].tensor != 0).to(torch.uint8).contiguous()
-                w = d["Weight Map"].tensor.float().contiguous()
+                w = compute_weight_map(img_crop, d["CT Image"], vote_type="global").tensor.float().contiguous()
             else:
                 m = torch.zeros(img_crop.shape, dtype=torch.uint8, device=device)
                 w = torch.zeros(img_crop.shape, dtype=torch.float32, device=device)
@@ -284,15 +346,19 @@ def run_segmentation(img, settings=MUTLIATLAS_SETTINGS_DEFAULTS, atlases=None, s
         if removed:
             logger.info("IAR removed atlases: %s", removed)
         my_ids = [i for i in my_ids if i in kept]
-        run_segmentation.last_iar_removed = removed
         del full_set, kept
+    else:
+        logger.info("IAR: No reference structure, skipping iterative atlas removal.")
 
-    # ---- step 4b: label fusion, the one cross-atlas exchange (fusion.py:263-288) ----
+    # ---- step 5: weight maps + label fusion, the one cross-atlas exchange (fusion.py:263-288) ----
+    vote_type = settings["label_fusion_settings"]["vote_type"]
+    vote_params = settings["label_fusion_settings"]["vote_params"]
     ctx = runtime.context(device)
     S, n = len(atlas_structure_list), img_crop.tensor.numel()
     buf = torch.zeros((2 * S,) + img_crop.shape, dtype=torch.float32, device=device)   # [wsum_s, wlsum_s] per structure
     for atlas_id in my_ids:
         d = atlas_set[atlas_id]["DIR"]
+        d["Weight Map"] = compute_weight_map(img_crop, d["CT Image"], vote_type=vote_type, vote_params=vote_params)
         w = d["Weight Map"].tensor.contiguous()
         for k, s in enumerate(atlas_structure_list):
             if s in d:
@@ -303,45 +369,44 @@ def run_segmentation(img, settings=MUTLIATLAS_SETTINGS_DEFAULTS, atlases=None, s
     combined_label_dict = {s: finalize_probability(ctx, img_crop, buf[2 * k], buf[2 * k + 1]) for k, s in enumerate(atlas_structure_list)}
     del buf
 
-    # ---- step 6: threshold, largest component, paste back into the target's space (:373-404) ----
+    # ---- step 6: threshold, largest component, paste back into the target's space (:373-404; cardiac :928-1004) ----
     results, results_prob = {}, {}
+    thresholds = settings["label_fusion_settings"]["optimal_threshold"]
+    as_cropped = bool(cardiac and settings.get("return_as_cropped", False))
     template_binary = img.like(torch.zeros(img.shape, dtype=torch.uint8, device=device))
     template_prob = img.like(torch.zeros(img.shape, dtype=torch.float32, device=device))
-    for s in atlas_structure_list:
+    # the cardiac pipeline votes only the structures it has a threshold for (:931-932)
+    vote_structures = [s for s in thresholds if s in atlas_structure_list] if cardiac else atlas_structure_list
+    for s in vote_structures:
         prob = combined_label_dict[s]
-        thr = settings["label_fusion_settings"]["optimal_threshold"].get(s, 0.5)
-        binary = process_probability_image(prob, thr)
-        results[s] = paste(template_binary, binary, crop_box_index)
-        results_prob[s] = paste(template_prob, prob, crop_box_index)
+        binary = process_probability_image(prob, thresholds.get(s, 0.5))
+        if as_cropped:
+            results[s], results_prob[s] = binary, prob
+        else:
+            results[s] = paste(template_binary, binary, crop_box_index)
+            results_prob[s] = paste(template_prob, prob, crop_box_index)
+        if cardiac and guided and not settings.get("return_atlas_guide_structure", False):   # :955-960, :994-1004
+            g = guide_structure.like(guide_structure.tensor.to(torch.uint8))
+            g = g if as_cropped else paste(template_binary, g, crop_box_index)
+            results[guide_structure_name] = g
+            results_prob[guide_structure_name] = g
 
-    # ---- step 8: post-processing (:409-437) ----
+    # ---- step 8: post-processing (:409-437; cardiac :1113-1141), on the device ----
     pp = settings["postprocessing_settings"]
     if pp["run_postprocessing"]:
-        if pp["structures_for_binaryfillhole"]:
-            from scipy import ndimage
-            import numpy as np
+        from ..label.utils import binary_morphological_closing, correct_volume_overlap, largest_component
 
-            radius = [int(pp["binaryfillhole_mm"] / sp) for sp in img.GetSpacing()]
-            for s in pp["structures_for_binaryfillhole"]:
-                if s not in results:
-                    continue
-                a = results[s].numpy() > 0
-                lab, ncomp = ndimage.label(a)
-                if ncomp:
-                    counts = np.bincount(lab.ravel())[1:]
-                    a = lab == 1 + int(np.argmax(counts))           # RelabelComponent(...) == 1: the largest
-                zz, yy, xx = np.ogrid[-radius[2]:radius[2] + 1, -radius[1]:radius[1] + 1, -radius[0]:radius[0] + 1]
-                ball = ((xx / max(radius[0], 0.5)) ** 2 + (yy / max(radius[1], 0.5)) ** 2 + (zz / max(radius[2], 0.5)) ** 2) <= 1.0
-                a = ndimage.binary_closing(np.pad(a, [(r, r) for r in radius[::-1]]), structure=ball)
-                a = a[radius[2]:a.shape[0] - radius[2], radius[1]:a.shape[1] - radius[1], radius[0]:a.shape[2] - radius[0]]
-                results[s] = img.like(torch.from_numpy(a.astype(np.uint8)).to(device))
-        if len(pp["structures_for_overlap_correction"]) >= 2:      # :425-434
-            from ..label.utils import correct_volume_overlap
-
-            fixed = correct_volume_overlap({s: results[s] for s in pp["structures_for_overlap_correction"]})
-            for s in pp["structures_for_overlap_correction"]:
+        radius = [int(pp["binaryfillhole_mm"] / sp) for sp in img.GetSpacing()]
+        for s in pp["structures_for_binaryfillhole"]:
+            if s not in results:
+                continue
+            results[s] = binary_morphological_closing(largest_component(results[s]), radius)
+        overlap = pp["structures_for_overlap_correction"]
+        if cardiac or len(overlap) >= 2:      # the multi-atlas pipeline skips fewer than two (:425); cardiac does not
+            fixed = correct_volume_overlap({s: results[s] for s in overlap})
+            for s in overlap:
                 results[s] = fixed[s]
 
-    if return_atlas_set:
-        return results, results_prob, atlas_set
-    return results, results_prob
+    if as_cropped:
+        results["CROP_IMAGE"] = img_crop
+    return {"results": results, "results_prob": results_prob, "atlas_set": atlas_set, "iar_removed": removed, "img_crop": img_crop}

@@ -181,13 +181,21 @@ def convert_mask_to_distance_map(mask, squared_distance=False, normalise=False):
 
 
 def convert_mask_to_reg_structure(mask, expansion=(0, 0, 0), scale=lambda x: x):
-    """Mask-like image for structure-guided registration (reference registration/utils.py:302-344): the inside
-    distance map, zero outside, scaled to [0, 1].  Binary dilation (`expansion`) is not implemented."""
+    """Mask-like image for structure-guided registration (reference registration/utils.py:302-344): optional
+    ball dilation (`expansion`: mm when scalar, voxels per axis when a sequence, as the reference has it), then
+    the inside distance map, zero outside, scaled to [0, 1], float64."""
+    from ..label.utils import binary_dilate
+
     mask = as_image(mask)
+    t = mask.tensor
+    vals = torch.unique(t[t > 0])
+    if len(vals) > 2:   # more than one value: threshold at the median (:320-324)
+        cutoff = float(np.median(vals.cpu().numpy()))
+        mask = mask.like(((t >= cutoff) & (t <= float(vals.max()))).to(torch.uint8))
     if not hasattr(expansion, "__iter__"):
         expansion = [int(expansion / i) for i in mask.GetSpacing()]
     if any(expansion):
-        raise NotImplementedError("convert_mask_to_reg_structure: expansion (binary dilation) is not implemented")
+        mask = binary_dilate(mask, expansion)
     dm = convert_mask_to_distance_map(mask, squared_distance=False)
-    inside = dm.tensor * (mask.tensor != 0).to(dm.tensor.dtype)
+    inside = dm.tensor.double() * (mask.tensor != 0).to(torch.float64)
     return scale(dm.like(inside / inside.max()))

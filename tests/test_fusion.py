@@ -2,6 +2,7 @@
 platipy/imaging/label/fusion.py."""
 import numpy as np
 import pytest
+import torch
 
 from oracle import oracle as O
 from tests.helpers import dice, phantom, smooth_noise
@@ -113,5 +114,15 @@ def test_overlap_correction_and_distance_map_helpers(host_api):
     assert dm[6, 10, 15] > 0 > dm[0, 0, 0]
     rs = pa.registration.convert_mask_to_reg_structure(imgs["A"]).numpy()
     assert rs.max() == 1.0 and rs[0, 0, 0] == 0.0
-    with pytest.raises(NotImplementedError):
-        pa.registration.convert_mask_to_reg_structure(imgs["A"], expansion=2)
+    # expansion in mm -> ball dilation by int(mm / spacing) voxels per axis before the distance map (utils.py:326-329)
+    rs2 = pa.registration.convert_mask_to_reg_structure(imgs["A"], expansion=2)
+    radius = [int(2 / sp) for sp in SPACING]
+    grown = O.binary_dilate_ball(O.Vol(a.astype(np.uint8), SPACING, ORIGIN), radius)
+    want2 = O.maurer_distance_map(grown, signed=True, inside_positive=True).arr.astype(np.float64) * (grown.arr != 0)
+    assert rs2.tensor.dtype == torch.float64
+    np.testing.assert_allclose(rs2.numpy(), want2 / want2.max(), rtol=1e-5, atol=1e-6)
+    # the pipelines' inline mask calls: closing after "largest component" (multiatlas/run.py:421-423)
+    lc = pa.label.utils.largest_component(imgs["C"]).numpy()
+    assert lc.max() == 1 and (lc <= c).all()
+    closed = pa.label.utils.binary_morphological_closing(imgs["A"], [1, 1, 1]).numpy()
+    np.testing.assert_array_equal(closed, O.binary_closing_ball(O.Vol(a.astype(np.uint8), SPACING, ORIGIN), [1, 1, 1]).arr)

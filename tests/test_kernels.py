@@ -416,6 +416,28 @@ def test_distance_map_and_contour(backend, grid):
     np.testing.assert_array_equal(backend.host(c), O.label_contour(O.Vol(mask, spacing, origin)).arr)
 
 
+@pytest.mark.parametrize("radius", [(1, 1, 1), (2, 2, 0), (3, 2, 1), (0, 0, 0), (5, 4, 2)])
+def test_binary_morphology_ball(backend, radius):
+    """BinaryDilate / BinaryErode / BinaryMorphologicalClosing with ITK's ball (registration/utils.py:328-329,
+    multiatlas/run.py:421-423): bit-exact vs the oracle, objects touching the buffer edge included."""
+    shape = (12, 20, 26)
+    mask = (smooth_noise(shape, 311, cells=4) > 0.35).astype(np.uint8)
+    mask[:3, :4, :5] = 1          # touches three faces
+    mask[6, 10, 13] = 0
+    vol = O.Vol(mask, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0))
+    for op, ref in ((0, O.binary_dilate_ball), (1, O.binary_erode_ball), (2, O.binary_closing_ball)):
+        out = backend.empty(shape, np.uint8)
+        backend.ctx.binary_morph_ball(backend.dev(mask), size_of(shape), radius, op, out)
+        np.testing.assert_array_equal(backend.host(out), ref(vol, radius).arr, err_msg=f"op {op}")
+
+
+def test_ball_element_known_shapes():
+    """ITK's radius-1 ball in 3-D is the 18-neighbourhood + centre (19 voxels); (2, 2, 0) is the 21-pixel disc."""
+    assert int(O.ball_element((1, 1, 1)).sum()) == 19
+    b = O.ball_element((2, 2, 0))
+    assert b.shape == (1, 5, 5) and int(b.sum()) == 21 and not b[0, 0, 0]
+
+
 @pytest.mark.parametrize("variant", [_lib.DEMONS_STAGED, _lib.DEMONS_FUSED])
 def test_demons_edge_cases(backend, variant):
     """Degenerate inputs the reference's filter accepts: tiny volumes (smaller than one tile, shorter than the kernel
