@@ -40,7 +40,8 @@ typedef enum {
   PP_ERR_HIP = -2,         /* a HIP runtime call or kernel launch failed          */
   PP_ERR_ALLOC = -3,       /* workspace allocation failed                         */
   PP_ERR_UNSUPPORTED = -4, /* valid request this build does not implement         */
-  PP_ERR_SIZE = -5         /* volume too small / too large for the operation      */
+  PP_ERR_SIZE = -5,        /* volume too small / too large for the operation      */
+  PP_ERR_NO_OVERLAP = -6   /* linear registration: no valid sample point at start */
 } pp_status;
 
 enum { PP_INTERP_NEAREST = 1, PP_INTERP_LINEAR = 2 }; /* = sitk.sitkNearestNeighbor / sitkLinear */
@@ -234,6 +235,58 @@ int pp_corr_moments_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[
                                const int msize[3], const double Af[9], const double bf[3],
                                const double Am[9], const double bm[3], const int vsize[3], int stride,
                                const uint8_t* fixed_mask, const uint8_t* moving_mask, double* result);
+
+/* Line-search evaluations (ITK GradientDescentLineSearchOptimizerv4::GoldenSectionSearch inside
+ * registration.Execute, registration/linear.py:238): metric VALUES only, for `ncand` (1..16) candidate moving
+ * maps Am[c][9], bm[c][3] in one launch -- the host speculates the next levels of the search tree.  Sampling,
+ * validity and interpolation exactly as pp_meansq_affine_f32 / pp_corr_moments_affine_f32.  result (host,
+ * ncand x 6 doubles): metric 0 -> [sum (f-m)^2, count, -, -, -, -]; metric 1 -> [count, sum f, sum m, sum f^2,
+ * sum m^2, sum f m].  A candidate's numbers do not depend on the others in the call.  Synchronises. */
+int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, const int fsize[3],
+                                const float* moving, const int msize[3], const double Af[9],
+                                const double bf[3], int ncand, const double* Am, const double* bm,
+                                const int vsize[3], int stride, const uint8_t* fixed_mask,
+                                const uint8_t* moving_mask, double* result);
+
+/* One resolution level of linear_registration's optimisation (what registration.Execute does inside a level,
+ * registration/linear.py:129-238): ITK v4 gradient descent (optionally with the golden-section line search) on
+ * the mean-squares or correlation metric above, parameter scales from physical shift, learning rate estimated
+ * once, convergence window 10 / 1e-6, best point kept.  Host logic in the library, metric on the GPU. */
+enum { PP_MODEL_TRANSLATION = 0, PP_MODEL_VERSOR_RIGID = 1, PP_MODEL_SIMILARITY = 2, PP_MODEL_SCALE = 3,
+       PP_MODEL_AFFINE = 4, PP_MODEL_EULER = 5 };       /* sitk parameter layouts; 3/6/7/3/12/6 parameters */
+enum { PP_OPT_GD = 0, PP_OPT_GD_LINE_SEARCH = 1 };
+enum { PP_LINREG_STOP_ITERATIONS = 0, PP_LINREG_STOP_CONVERGED = 1, PP_LINREG_STOP_NO_OVERLAP = 2 };
+typedef struct pp_linreg_level {
+  int model;              /* PP_MODEL_*: q = A(params) (p - center) + center + t(params)            */
+  int metric;             /* 0 mean squares, 1 correlation                                            */
+  int optimizer;          /* PP_OPT_*                                                                 */
+  int iterations;         /* numberOfIterations                                                       */
+  int vsize[3];           /* virtual (shrunk fixed) domain                                            */
+  int stride;             /* REGULAR sampling: every stride-th voxel of it                            */
+  int speculation;        /* golden-section tree levels probed per launch, 1..4 (1 = sequential)      */
+  int reserved;
+  double v_i2p[9], v_origin[3]; /* virtual index -> physical: p = v_i2p idx + v_origin               */
+  double f_p2i[9], f_origin[3]; /* fixed  physical -> index:  idx = f_p2i (p - f_origin)             */
+  double m_p2i[9], m_origin[3]; /* moving physical -> index                                           */
+  double init_matrix[9], init_offset[3]; /* the centring transform composed in front: q = M p + o    */
+  double center[3];       /* fixed centre of rotation of the optimised transform                      */
+  double v_min_spacing;   /* smallest virtual spacing (learning-rate estimate)                        */
+} pp_linreg_level;
+typedef struct pp_linreg_stats {
+  int iterations;         /* optimiser iterations taken            */
+  int evaluations;        /* metric evaluations (probes included)  */
+  int stop;               /* PP_LINREG_STOP_*                      */
+  int reserved;
+  double value;           /* metric at the returned parameters     */
+  double learning_rate;   /* last learning rate                    */
+} pp_linreg_stats;
+int pp_linear_num_parameters(int model);
+/* params (host, in/out): pp_linear_num_parameters(model) doubles.  history (host, may be NULL): metric value
+ * per iteration, up to history_capacity.  PP_ERR_NO_OVERLAP when no sample point is valid at the start. */
+int pp_linear_optimize_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], const float* moving,
+                           const int msize[3], const uint8_t* fixed_mask, const uint8_t* moving_mask,
+                           const pp_linreg_level* level, double* params, pp_linreg_stats* stats,
+                           double* history, int history_capacity);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,24 @@ class Geom(C.Structure):
                 ("direction", C.c_double * 9)]
 
 
+class LinregLevel(C.Structure):     # pp_linreg_level
+    _fields_ = [("model", C.c_int), ("metric", C.c_int), ("optimizer", C.c_int), ("iterations", C.c_int), ("vsize", C.c_int * 3),
+                ("stride", C.c_int), ("speculation", C.c_int), ("reserved", C.c_int),
+                ("v_i2p", C.c_double * 9), ("v_origin", C.c_double * 3), ("f_p2i", C.c_double * 9), ("f_origin", C.c_double * 3),
+                ("m_p2i", C.c_double * 9), ("m_origin", C.c_double * 3), ("init_matrix", C.c_double * 9),
+                ("init_offset", C.c_double * 3), ("center", C.c_double * 3), ("v_min_spacing", C.c_double)]
+
+
+class LinregStats(C.Structure):     # pp_linreg_stats
+    _fields_ = [("iterations", C.c_int), ("evaluations", C.c_int), ("stop", C.c_int), ("reserved", C.c_int), ("value", C.c_double),
+                ("learning_rate", C.c_double)]
+
+
+ERR_NO_OVERLAP = -6
+MODEL_TRANSLATION, MODEL_VERSOR_RIGID, MODEL_SIMILARITY, MODEL_SCALE, MODEL_AFFINE, MODEL_EULER = range(6)
+OPT_GD, OPT_GD_LINE_SEARCH = 0, 1
+
+
 class DemonsParams(C.Structure):
     _fields_ = [
         ("iterations", C.c_int),
@@ -104,6 +122,12 @@ _SIGNATURES = {
     "pp_corr_moments_affine_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                              C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                              C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(C.c_double)]),
+    "pp_metric_values_affine_f32": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                              C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                              C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(C.c_double)]),
+    "pp_linear_num_parameters": (C.c_int, [C.c_int]),
+    "pp_linear_optimize_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), _P, _P, C.POINTER(LinregLevel),
+                                         C.POINTER(C.c_double), C.POINTER(LinregStats), C.POINTER(C.c_double), C.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -339,6 +363,39 @@ class Context:
                                                 _dn(Am, 9), _dn(bm, 3), _i3(vsize), int(stride), ptr(fixed_mask),
                                                 ptr(moving_mask), res), "pp_meansq_affine_f32")
         return [res[i] for i in range(14)]
+
+    def metric_values_affine(self, metric, fixed, fsize, moving, msize, Af, bf, Ams, bms, vsize, stride, fixed_mask=None,
+                             moving_mask=None):
+        """Values only for len(Ams) <= 16 candidate maps in one launch -> array [ncand, 6] (pp_metric_values_affine_f32)."""
+        import numpy as np
+
+        k = len(Ams)
+        am = np.ascontiguousarray(np.asarray(Ams, dtype=np.float64).reshape(k, 9))
+        bm = np.ascontiguousarray(np.asarray(bms, dtype=np.float64).reshape(k, 3))
+        res = np.zeros((k, 6), dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        self._chk(self.lib.pp_metric_values_affine_f32(self.h, int(metric), ptr(fixed), _i3(fsize), ptr(moving), _i3(msize), _dn(Af, 9),
+                                                       _dn(bf, 3), k, am.ctypes.data_as(dp), bm.ctypes.data_as(dp), _i3(vsize),
+                                                       int(stride), ptr(fixed_mask), ptr(moving_mask), res.ctypes.data_as(dp)),
+                  "pp_metric_values_affine_f32")
+        return res
+
+    def linear_optimize(self, fixed, fsize, moving, msize, level, params, fixed_mask=None, moving_mask=None, history=0):
+        """One level of linear_registration's optimisation in the library (pp_linear_optimize_f32).
+        -> (params list, LinregStats, history list).  Raises PlatipyAmdError; .code == ERR_NO_OVERLAP when the images
+        do not overlap at the start."""
+        n = self.lib.pp_linear_num_parameters(int(level.model))
+        p = (C.c_double * n)(*[float(v) for v in params])
+        st = LinregStats()
+        hist = (C.c_double * max(1, int(history)))()
+        rc = self.lib.pp_linear_optimize_f32(self.h, ptr(fixed), _i3(fsize), ptr(moving), _i3(msize), ptr(fixed_mask), ptr(moving_mask),
+                                             C.byref(level), p, C.byref(st), hist, int(history))
+        if rc:
+            msg = self.lib.pp_last_error(self.h)
+            err = PlatipyAmdError(f"pp_linear_optimize_f32 failed ({rc}): {msg.decode(errors='replace') if msg else ''}")
+            err.code = rc
+            raise err
+        return [p[i] for i in range(n)], st, [hist[i] for i in range(min(int(history), st.iterations))]
 
     def corr_moments_affine(self, fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None):
         """-> the 42 raw moments of pp_corr_moments_affine_f32."""

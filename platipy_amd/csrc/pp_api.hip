@@ -87,6 +87,36 @@ int pp_reserve(pp_ctx* ctx, size_t bytes) {
   return PP_OK;
 }
 
+int pp_read_back(pp_ctx* ctx, const void* dev, void* host, size_t bytes) {
+  if (bytes > 4096) return pp_fail(ctx, PP_ERR_ARG, "pp_read_back: %zu bytes exceed the staging buffer", bytes);
+  if (!ctx->pinned) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 4096, 0) != hipSuccess || !p) {
+      (void)hipGetLastError();
+      return pp_fail(ctx, PP_ERR_ALLOC, "page-locked staging buffer allocation failed");
+    }
+    ctx->pinned = static_cast<char*>(p);
+  }
+  PP_HIP(ctx, hipMemcpyAsync(ctx->pinned, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(host, ctx->pinned, bytes);
+  return PP_OK;
+}
+
+int pp_ticket(pp_ctx* ctx, unsigned** out) {
+  if (!ctx->ticket) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess || !p) {
+      (void)hipGetLastError();
+      return pp_fail(ctx, PP_ERR_ALLOC, "ticket counter allocation failed");
+    }
+    ctx->ticket = static_cast<unsigned*>(p);
+    PP_HIP(ctx, hipMemsetAsync(ctx->ticket, 0, 256, ctx->stream));
+  }
+  *out = ctx->ticket;
+  return PP_OK;
+}
+
 extern "C" {
 
 int pp_abi_version(void) { return PP_ABI_VERSION; }
@@ -110,6 +140,8 @@ void pp_destroy(pp_ctx* ctx) {
   if (!ctx) return;
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->ticket) (void)hipFree(ctx->ticket);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->prof) {
     for (auto& s : ctx->prof->spans) {
       (void)hipEventDestroy(s.a);

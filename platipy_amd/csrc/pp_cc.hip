@@ -233,8 +233,8 @@ extern "C" int pp_fillhole_largest_component_u8(pp_ctx* ctx, const uint8_t* in, 
   PP_LAUNCH_CHECK(ctx, "k_cc_select");
   if (component_voxels) {
     int h[2];
-    PP_HIP(ctx, hipMemcpyAsync(h, result, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rc = pp_read_back(ctx, result, h, sizeof(h));
+    if (rc) return rc;
     *component_voxels = h[0];
   }
   return PP_OK;

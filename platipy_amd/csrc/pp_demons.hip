@@ -762,8 +762,8 @@ int check_demons_args(pp_ctx* ctx, const pp_geom* g, const pp_demons_params* p) 
 
 int read_stats(pp_ctx* ctx, const pp_dev_stats* dst, pp_demons_stats* out) {
   pp_dev_stats h;
-  PP_HIP(ctx, hipMemcpyAsync(&h, dst, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int rc = pp_read_back(ctx, dst, &h, sizeof(h));
+  if (rc) return rc;
   out->metric = h.metric;
   out->rms_change = h.rms;
   out->sum_sq_diff = h.ssd;

@@ -285,6 +285,123 @@ __global__ void __launch_bounds__(NT) k_sum14_final(const double* __restrict__ p
   if ((int)threadIdx.x < nf) result[f0 + threadIdx.x] = red[threadIdx.x * NT];
 }
 
+// ---- line-search evaluations: K candidate moving maps in ONE launch, values only --------------------------
+// The golden-section line search of ITK's GradientDescentLineSearchOptimizerv4 needs ~13 metric VALUES per
+// optimiser iteration, each depending on the previous comparison; one launch + one read-back per value is pure
+// latency (the sample lattice is 16 K .. 1 M points).  The host speculates the next few levels of the search
+// tree and evaluates all of their learning rates at once: blockIdx.y = candidate.  The last block of a candidate to
+// finish (device ticket per candidate) folds that candidate's per-block partial sums with a fixed tree, so a candidate's value does not depend on
+// which other candidates ride in the launch.  (ctx->ticket holds 64 counters; PP_MAX_CAND of them are used.)
+constexpr int PP_MAX_CAND = 16;
+struct mval_args {
+  double Af[9], bf[3];
+  double Am[PP_MAX_CAND][9], bm[PP_MAX_CAND][3];
+  int vsize[3];
+  int stride;
+};
+
+// MODE 0: [sum (f-m)^2, count].  MODE 1: [count, sum f, sum m, sum f^2, sum m^2, sum f m].
+// One thread walks its samples and, per sample, ALL candidates of its chunk (CH per blockIdx.y): the lattice is
+// sparse in the full-resolution images (every gather is its own cache line, so an evaluation is HBM traffic, not
+// arithmetic), the candidates of a line search land within a voxel or two of each other, and probing them
+// back-to-back turns 15 of 16 candidates' gathers into L1/L2 hits; the fixed sample is fetched once.
+template <int MODE, int CH>
+__global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ F, pp_dims df, const float* __restrict__ M, pp_dims dm,
+                                                      const uint8_t* __restrict__ fmask, const uint8_t* __restrict__ mmask, mval_args a,
+                                                      int ncand, double* partials /* [chunk][grid.x][CH*NV] */,
+                                                      unsigned* __restrict__ ticket, double* __restrict__ result /* [cand][6] */) {
+  constexpr int NV = MODE == 0 ? 2 : 6;
+  constexpr int ROW = CH * NV;
+  __shared__ double red[3 * NT];
+  __shared__ int is_last;
+  const int c0 = blockIdx.y * CH;
+  const int nc = ncand - c0 < CH ? ncand - c0 : CH;
+  double acc[ROW];
+  for (int k = 0; k < ROW; ++k) acc[k] = 0.0;
+  const size_t nvirt = (size_t)a.vsize[0] * a.vsize[1] * a.vsize[2];
+  const size_t nsamp = (nvirt + a.stride - 1) / a.stride;
+  for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nsamp; e += (size_t)gridDim.x * NT) {
+    const size_t lin = e * (size_t)a.stride;
+    const double v[3] = {(double)(lin % a.vsize[0]), (double)((lin / a.vsize[0]) % a.vsize[1]),
+                         (double)(lin / ((size_t)a.vsize[0] * a.vsize[1]))};
+    double cf[3];
+    for (int r = 0; r < 3; ++r) cf[r] = a.Af[r * 3 + 0] * v[0] + a.Af[r * 3 + 1] * v[1] + a.Af[r * 3 + 2] * v[2] + a.bf[r];
+    int bf_[3];
+    float ff[3];
+    if (!msq_locate(cf, df, bf_, ff)) continue;
+    if (fmask) {
+      const int qx = (int)floor(cf[0] + 0.5), qy = (int)floor(cf[1] + 0.5), qz = (int)floor(cf[2] + 0.5);
+      if (!fmask[((size_t)qz * df.ny + qy) * df.nx + qx]) continue;
+    }
+    const double fd = pp_trilinear(F, df.nx, df.ny, df.nz, bf_[0], ff[0], bf_[1], ff[1], bf_[2], ff[2]);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      double cm[3];
+      for (int r = 0; r < 3; ++r)
+        cm[r] = a.Am[c0 + j][r * 3 + 0] * v[0] + a.Am[c0 + j][r * 3 + 1] * v[1] + a.Am[c0 + j][r * 3 + 2] * v[2] + a.bm[c0 + j][r];
+      int bm_[3] = {0, 0, 0};
+      float fm[3] = {0.0f, 0.0f, 0.0f};
+      bool ok = j < nc && msq_locate(cm, dm, bm_, fm);
+      if (ok && mmask) {
+        const int qx = (int)floor(cm[0] + 0.5), qy = (int)floor(cm[1] + 0.5), qz = (int)floor(cm[2] + 0.5);
+        ok = mmask[((size_t)qz * dm.ny + qy) * dm.nx + qx] != 0;
+      }
+      if (ok) {
+        const double md = pp_trilinear(M, dm.nx, dm.ny, dm.nz, bm_[0], fm[0], bm_[1], fm[1], bm_[2], fm[2]);
+        if (MODE == 0) {
+          const double diff = fd - md;
+          acc[j * NV + 0] += diff * diff;
+          acc[j * NV + 1] += 1.0;
+        } else {
+          acc[j * NV + 0] += 1.0;
+          acc[j * NV + 1] += fd;
+          acc[j * NV + 2] += md;
+          acc[j * NV + 3] += fd * fd;
+          acc[j * NV + 4] += md * md;
+          acc[j * NV + 5] += fd * md;
+        }
+      }
+    }
+  }
+  double* mine = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ROW;
+#pragma unroll
+  for (int k = 0; k < ROW; k += 3) {
+    double p = acc[k], q = k + 1 < ROW ? acc[k + 1] : 0.0, r = k + 2 < ROW ? acc[k + 2] : 0.0;
+    pp_block_sum3<NT>(p, q, r, red);
+    if (threadIdx.x == 0) {
+      mine[k] = p;
+      if (k + 1 < ROW) mine[k + 1] = q;
+      if (k + 2 < ROW) mine[k + 2] = r;
+    }
+    __syncthreads();
+  }
+  // the last block of this chunk to arrive folds the chunk's rows (fixed tree, independent of arrival order)
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned t = atomicAdd(ticket + blockIdx.y, 1u);
+    is_last = t == gridDim.x - 1u;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  const double* rows = partials + (size_t)blockIdx.y * gridDim.x * ROW;
+  for (int k = 0; k < nc * NV; k += 3) {
+    double p = 0.0, q = 0.0, r = 0.0;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += NT) {
+      p += rows[(size_t)i * ROW + k];
+      if (k + 1 < ROW) q += rows[(size_t)i * ROW + k + 1];
+      if (k + 2 < ROW) r += rows[(size_t)i * ROW + k + 2];
+    }
+    pp_block_sum3<NT>(p, q, r, red);
+    if (threadIdx.x == 0) {
+      const double out[3] = {p, q, r};
+      for (int u = 0; u < 3 && k + u < nc * NV; ++u) result[(c0 + (k + u) / NV) * 6 + (k + u) % NV] = out[u];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ticket[blockIdx.y] = 0u;
+}
+
 }  // namespace
 
 extern "C" {
@@ -317,9 +434,7 @@ int pp_sum_sq_diff_f32(pp_ctx* ctx, const float* a, const float* b, size_t n, do
   PP_LAUNCH_CHECK(ctx, "k_ssd_partial");
   hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, 1, 1, partials + nb);
   PP_LAUNCH_CHECK(ctx, "k_sum_final");
-  PP_HIP(ctx, hipMemcpyAsync(result, partials + nb, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return PP_OK;
+  return pp_read_back(ctx, partials + nb, result, sizeof(double));
 }
 
 int pp_fuse_accumulate_u8(pp_ctx* ctx, const float* weight, const uint8_t* label, float* wsum, float* wlsum, size_t n) {
@@ -350,8 +465,8 @@ int pp_minmax_f32(pp_ctx* ctx, const float* in, size_t n, float* min_out, float*
   hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(NT), 0, ctx->stream, (const float*)partials, (int)nb, partials + 2 * nb);
   PP_LAUNCH_CHECK(ctx, "k_minmax_final");
   float h[2];
-  PP_HIP(ctx, hipMemcpyAsync(h, partials + 2 * nb, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  rc = pp_read_back(ctx, partials + 2 * nb, h, sizeof(h));
+  if (rc) return rc;
   *min_out = h[0];
   *max_out = h[1];
   return PP_OK;
@@ -407,9 +522,7 @@ static int metric_affine(pp_ctx* ctx, int mode, const float* fixed, const int fs
   hipLaunchKernelGGL(k_sum14_final, dim3((nacc + 13) / 14), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, nacc,
                      partials + (size_t)nb * nacc);
   PP_LAUNCH_CHECK(ctx, "k_sum14_final");
-  PP_HIP(ctx, hipMemcpyAsync(result, partials + (size_t)nb * nacc, nacc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return PP_OK;
+  return pp_read_back(ctx, partials + (size_t)nb * nacc, result, nacc * sizeof(double));
 }
 
 int pp_meansq_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], const float* moving, const int msize[3],
@@ -424,6 +537,46 @@ int pp_corr_moments_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[
                                const int vsize[3], int stride, const uint8_t* fixed_mask, const uint8_t* moving_mask,
                                double* result) {
   return metric_affine(ctx, 1, fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask, result);
+}
+
+int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, const int fsize[3], const float* moving, const int msize[3],
+                                const double Af[9], const double bf[3], int ncand, const double* Am, const double* bm,
+                                const int vsize[3], int stride, const uint8_t* fixed_mask, const uint8_t* moving_mask, double* result) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, fixed && fsize && moving && msize && Af && bf && Am && bm && vsize && result, "metric values: NULL argument");
+  PP_REQUIRE(ctx, metric == 0 || metric == 1, "metric values: metric must be 0 (mean squares) or 1 (correlation moments)");
+  PP_REQUIRE(ctx, ncand >= 1 && ncand <= PP_MAX_CAND, "metric values: 1..16 candidates per call");
+  PP_REQUIRE(ctx, stride >= 1 && vsize[0] >= 1 && vsize[1] >= 1 && vsize[2] >= 1, "metric values: bad sampling lattice");
+  mval_args a;
+  memset(&a, 0, sizeof(a));
+  memcpy(a.Af, Af, sizeof(a.Af));
+  memcpy(a.bf, bf, sizeof(a.bf));
+  memcpy(a.Am, Am, (size_t)ncand * 9 * sizeof(double));
+  memcpy(a.bm, bm, (size_t)ncand * 3 * sizeof(double));
+  for (int k = 0; k < 3; ++k) a.vsize[k] = vsize[k];
+  a.stride = stride;
+  const size_t nsamp = ((size_t)vsize[0] * vsize[1] * vsize[2] + stride - 1) / stride;
+  const pp_dims df{fsize[0], fsize[1], fsize[2]}, dm{msize[0], msize[1], msize[2]};
+  constexpr int CH0 = 16, CH1 = 4;   // candidates per thread: 32 / 24 fp64 accumulators
+  const int ch = metric == 0 ? CH0 : CH1, nv = metric == 0 ? 2 : 6;
+  const int nchunk = (ncand + ch - 1) / ch;
+  const unsigned nb = grid_for(nsamp, 1024u);
+  const size_t row = (size_t)ch * nv;
+  int rc = pp_reserve(ctx, pp_align_up(((size_t)nb * nchunk * row + (size_t)PP_MAX_CAND * 6) * sizeof(double), 256));
+  if (rc) return rc;
+  unsigned* ticket = nullptr;
+  rc = pp_ticket(ctx, &ticket);
+  if (rc) return rc;
+  double* partials = reinterpret_cast<double*>(ctx->ws);
+  double* dres = partials + (size_t)nb * nchunk * row;
+  if (metric == 0)
+    hipLaunchKernelGGL((k_metric_values<0, CH0>), dim3(nb, nchunk), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask,
+                       moving_mask, a, ncand, partials, ticket, dres);
+  else
+    hipLaunchKernelGGL((k_metric_values<1, CH1>), dim3(nb, nchunk), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask,
+                       moving_mask, a, ncand, partials, ticket, dres);
+  PP_LAUNCH_CHECK(ctx, "k_metric_values");
+  return pp_read_back(ctx, dres, result, (size_t)ncand * 6 * sizeof(double));
 }
 
 }  // extern "C"

@@ -23,6 +23,8 @@ struct pp_ctx {
   char* ws;          // device scratch, grown on demand
   size_t ws_bytes;
   pp_profiler* prof;  // NULL unless pp_profile_enable(ctx, 1)
+  char* pinned;       // 4 KB of page-locked host memory for small read-backs (lazy)
+  unsigned* ticket;   // device counter for last-block-finishes reductions (lazy, kept at 0 between launches)
   char err[512];
 };
 
@@ -38,6 +40,11 @@ struct pp_prof_scope {
 int pp_fail(pp_ctx* ctx, int code, const char* fmt, ...);
 // Reserve `bytes` of device scratch (256-B aligned slices are carved by the callers).
 int pp_reserve(pp_ctx* ctx, size_t bytes);
+// Copy `bytes` (<= 4096) from device memory to `host` through the context's page-locked staging buffer and wait
+// for the stream: a pageable destination would make the runtime stage and block on its own, several times slower.
+int pp_read_back(pp_ctx* ctx, const void* dev, void* host, size_t bytes);
+// Device counter (zero between launches) for kernels whose last block folds the partial sums.
+int pp_ticket(pp_ctx* ctx, unsigned** out);
 
 #define PP_HIP(ctx, call)                                                              \
   do {                                                                                 \

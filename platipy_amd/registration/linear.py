@@ -156,6 +156,28 @@ class _MeanSquares:
     def value(self, model, params):
         return self.raw(model, params)[0]
 
+    def values(self, model, params_list):
+        """Metric values only for up to 16 parameter vectors in one launch (line search); a candidate without any
+        valid sample point is +inf."""
+        maps = [self.index_map(model, p) for p in params_list]
+        self.evaluations += len(maps)
+        r = self.ctx.metric_values_affine(0 if self.metric == "mean_squares" else 1, self.ft, self.fixed.GetSize(), self.mt,
+                                          self.moving.GetSize(), self.Af.ravel(), self.bf, [m[0] for m in maps], [m[1] for m in maps],
+                                          self.vsize, self.stride, self.fmask, self.mmask)
+        out = []
+        for row in np.asarray(r):
+            if self.metric == "mean_squares":
+                out.append(row[0] / row[1] if row[1] > 0 else float("inf"))
+                continue
+            n = row[0]
+            if n <= 0:
+                out.append(float("inf"))
+                continue
+            fbar, mbar = row[1] / n, row[2] / n
+            sff, smm, sfm = row[3] - n * fbar * fbar, row[4] - n * mbar * mbar, row[5] - n * fbar * mbar
+            out.append(0.0 if sff <= 1e-300 or smm <= 1e-300 else -(sfm * sfm) / (sff * smm))
+        return out
+
     def value_and_gradient(self, model, params):
         value, g_idx = self.raw(model, params)
         params = np.asarray(params, dtype=np.float64)
@@ -213,27 +235,108 @@ def _window_convergence(values, window):
     return -float(slope)
 
 
-def _golden_section(f, a, b, c, eps=0.01, max_iter=20):
-    """itk::GradientDescentLineSearchOptimizerv4::GoldenSectionSearch on the learning rate (a < b < c)."""
+# The gradient-descent optimisers run inside the library (pp_linear.hip: one call per level, no interpreter between
+# the ~1000 launches) for the built-in transform models; the Python loop below is the same algorithm and serves
+# user-defined _Parametrised models and scipy's L-BFGS-B.
+NATIVE_OPTIMISER = True
+_NATIVE_MODEL = {TranslationTransform: 0, VersorRigid3DTransform: 1, Similarity3DTransform: 2, ScaleTransform: 3,
+                 FullAffineTransform: 4, Euler3DTransform: 5}
+
+
+def _optimise_level_native(ctx, ms, model, params, opt, number_of_iterations, verbose):
+    """pp_linear_optimize_f32 on the level described by `ms`."""
+    from .._lib import ERR_NO_OVERLAP, LinregLevel, PlatipyAmdError
+
+    lv = LinregLevel()
+    lv.model = _NATIVE_MODEL[type(model)]
+    lv.metric = 0 if ms.metric == "mean_squares" else 1
+    lv.optimizer = 1 if opt == "gradient_descent_line_search" else 0
+    lv.iterations = int(number_of_iterations)
+    lv.vsize[:] = [int(v) for v in ms.vsize]
+    lv.stride = int(ms.stride)
+    lv.speculation = int(LINE_SEARCH_SPECULATION)
+    lv.v_i2p[:] = ms.i2p_v.ravel().tolist()
+    lv.v_origin[:] = np.asarray(ms.o_v, dtype=np.float64).tolist()
+    lv.f_p2i[:] = _p2i(ms.fixed).ravel().tolist()
+    lv.f_origin[:] = np.asarray(ms.fixed.origin, dtype=np.float64).tolist()
+    lv.m_p2i[:] = ms.p2i_m.ravel().tolist()
+    lv.m_origin[:] = ms.o_m.tolist()
+    lv.init_matrix[:] = np.asarray(ms.Ai, dtype=np.float64).ravel().tolist()
+    lv.init_offset[:] = np.asarray(ms.oi, dtype=np.float64).tolist()
+    lv.center[:] = np.asarray(model.center, dtype=np.float64).tolist()
+    lv.v_min_spacing = ms.min_spacing
+    try:
+        out, stats, history = ctx.linear_optimize(ms.ft, ms.fixed.GetSize(), ms.mt, ms.moving.GetSize(), lv, params, ms.fmask, ms.mmask,
+                                                  history=number_of_iterations if verbose else 0)
+    except PlatipyAmdError as e:
+        if getattr(e, "code", 0) == ERR_NO_OVERLAP:
+            raise RuntimeError("linear_registration: no valid sample points (images do not overlap)") from e
+        raise
+    ms.evaluations += stats.evaluations
+    if verbose:
+        for it, value in enumerate(history):
+            print("{0:3} = {1:10.5f}".format(it, value))
+    return np.asarray(out, dtype=np.float64)
+
+
+# How many levels of the golden-section decision tree are evaluated per launch (2^depth - 1 learning rates, + the
+# bracket's middle point on the first round: 16 at depth 4 = one pp_metric_values_affine_f32 call).
+LINE_SEARCH_SPECULATION = 4
+
+
+def _golden_section(fbatch, a, b, c, eps=0.01, max_iter=20, depth=None):
+    """itk::GradientDescentLineSearchOptimizerv4::GoldenSectionSearch on the learning rate (a < b < c).
+
+    The search is sequential -- each probe depends on the previous comparison -- and every probe is a GPU launch
+    plus a read-back whose cost is all latency.  So the next `depth` levels of its decision tree are probed
+    speculatively in ONE batched launch (`fbatch(list of learning rates) -> list of values`), then the search
+    walks the tree with the values in hand.  The probes taken, their order and the result are exactly those of
+    the sequential search (depth = 1)."""
+    depth = LINE_SEARCH_SPECULATION if depth is None else depth
     resphi = 2.0 - (1.0 + np.sqrt(5.0)) / 2.0
+    known = {}
+
+    def probe(a, b, c):
+        return b + resphi * (c - b) if (c - b) > (b - a) else b - resphi * (b - a)
+
+    def children(a, b, c, x):
+        """-> (state if f(x) < f(b), state otherwise)"""
+        if (c - b) > (b - a):
+            return (b, x, c), (a, b, x)
+        return (a, x, b), (x, b, c)
+
+    def speculate(a, b, c, levels, left, want):
+        if levels == 0 or left == 0:
+            return
+        x = probe(a, b, c)
+        if abs(c - a) < eps * (abs(b) + abs(x)):
+            return
+        if x not in known and x not in want:
+            want.append(x)
+        lo, hi = children(a, b, c, x)
+        speculate(*lo, levels - 1, left - 1, want)
+        speculate(*hi, levels - 1, left - 1, want)
+
     fb = None
-    for _ in range(max_iter):
-        x = b + resphi * (c - b) if (c - b) > (b - a) else b - resphi * (b - a)
+    for it in range(max_iter):
+        x = probe(a, b, c)
         if abs(c - a) < eps * (abs(b) + abs(x)):
             return (c + a) / 2.0
-        fx = f(x)
+        if x not in known or (fb is None and b not in known):
+            want = []
+            speculate(a, b, c, depth, max_iter - it, want)
+            if fb is None and b not in known and b not in want:
+                want.append(b)
+            for key, val in zip(want, fbatch(want)):
+                known[key] = val
+        fx = known[x]
         if fb is None:
-            fb = f(b)
+            fb = known[b]
+        lo, hi = children(a, b, c, x)
         if fx < fb:
-            if (c - b) > (b - a):
-                a, b, fb = b, x, fx
-            else:
-                c, b, fb = b, x, fx
+            (a, b, c), fb = lo, fx
         else:
-            if (c - b) > (b - a):
-                c = x
-            else:
-                a = x
+            a, b, c = hi
     return (c + a) / 2.0
 
 
@@ -322,6 +425,10 @@ def linear_registration(
                 params = x / root
             continue
 
+        if NATIVE_OPTIMISER and type(model) in _NATIVE_MODEL:
+            params = _optimise_level_native(ctx, ms, model, params, opt, number_of_iterations, verbose)
+            continue
+
         scales = ms.scales(model, params)
         learning_rate = 1.0
         history = []
@@ -348,11 +455,8 @@ def linear_registration(
             if opt == "gradient_descent_line_search":
                 base = params.copy()
 
-                def trial(e):
-                    try:
-                        return ms.value(model, base - e * g)
-                    except RuntimeError:
-                        return float("inf")
+                def trial(es):
+                    return ms.values(model, [base - e * g for e in es])
 
                 lr = _golden_section(trial, 0.0, learning_rate, 5.0 * learning_rate)
                 learning_rate = lr if lr > 0 else learning_rate

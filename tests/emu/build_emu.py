@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "platipy_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libplatipy_emu.so")
-SOURCES = ["pp_api.hip", "pp_fir.hip", "pp_resample.hip", "pp_demons.hip", "pp_iir.hip", "pp_fusion.hip", "pp_cc.hip", "pp_dist.hip", "pp_morph.hip"]
+SOURCES = ["pp_api.hip", "pp_fir.hip", "pp_resample.hip", "pp_demons.hip", "pp_iir.hip", "pp_fusion.hip", "pp_cc.hip", "pp_dist.hip", "pp_morph.hip", "pp_linear.hip"]
 FLAGS = ["-O2", "-std=c++17", "-fPIC", "-pthread", "-ffp-contract=off", "-Wno-unknown-pragmas", "-Wno-attributes",
          "-I", os.path.join(HERE, "include")]
 

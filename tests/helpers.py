@@ -134,6 +134,19 @@ def install_emu_runtime(setattr_fn=None):
         return list(linear_oracle.corr_moments_affine(fixed.numpy(), moving.numpy(), Af, bf, Am, bm, vsize, stride, tn(fixed_mask),
                                                       tn(moving_mask)))
 
+    def fake_values(metric, fixed, fsize, moving, msize, Af, bf, Ams, bms, vsize, stride, fixed_mask=None, moving_mask=None):
+        out = np.zeros((len(Ams), 6))
+        for c, (Am, bm) in enumerate(zip(Ams, bms)):
+            r = (fake_meansq if metric == 0 else fake_corr)(fixed, fsize, moving, msize, Af, bf, np.asarray(Am).ravel(), bm, vsize, stride,
+                                                            fixed_mask, moving_mask)
+            out[c, :2 if metric == 0 else 6] = r[:2 if metric == 0 else 6]
+        return out
+
+    from platipy_amd.registration import linear as _linear
+
+    sa(_linear, "NATIVE_OPTIMISER", False)        # the native loop would run every probe through the emulated kernels
+    sa(_linear, "LINE_SEARCH_SPECULATION", 1)     # sequential probes: the numpy stand-in gains nothing from batching
+    sa(be.ctx, "metric_values_affine", fake_values)
     sa(be.ctx, "meansq_affine", fake_meansq)
     sa(be.ctx, "corr_moments_affine", fake_corr)
     return be

@@ -49,6 +49,66 @@ def test_meansq_kernel_matches_numpy_and_finite_differences(backend):
     assert 0 < masked[1] < got[1]
 
 
+def test_metric_values_batch_matches_single_evaluations(backend):
+    """pp_metric_values_affine_f32: K candidate maps in one launch give each candidate the numbers a one-by-one
+    evaluation gives (same samples, fp64 sums), independent of the other candidates riding along."""
+    F = phantom((10, 14, 18), seed=300, noise=0)
+    M = (0.5 * phantom((12, 13, 17), seed=301, noise=0) + 300).astype(np.float32)
+    Af, bf = np.eye(3) * 2.0, np.array([0.5, 0.5, 0.5])
+    Am0 = np.array([[1.9137, 0.1071, 0.0031], [-0.0813, 2.0519, 0.0207], [0.0109, 0.0043, 2.3011]])
+    bm0 = np.array([0.7123, -0.4057, 0.9131])
+    vsize, stride = (9, 7, 5), 2
+    rng = np.random.default_rng(5)
+    Ams = [Am0 + 0.05 * rng.standard_normal((3, 3)) for _ in range(16)]
+    bms = [bm0 + 0.5 * rng.standard_normal(3) for _ in range(16)]
+    bms[3] = bm0 + 500.0                                         # no overlap at all: count 0, no NaN
+    fm = np.zeros((10, 14, 18), np.uint8)
+    fm[:, :, :12] = 1
+    dF, dM, dfm = backend.dev(F), backend.dev(M), backend.dev(fm)
+    fs, ms_ = (18, 14, 10), (17, 13, 12)
+    for mask in (None, dfm):
+        sq = backend.ctx.metric_values_affine(0, dF, fs, dM, ms_, Af.ravel(), bf, Ams, bms, vsize, stride, fixed_mask=mask)
+        co = backend.ctx.metric_values_affine(1, dF, fs, dM, ms_, Af.ravel(), bf, Ams, bms, vsize, stride, fixed_mask=mask)
+        for c in range(16):
+            one = backend.ctx.meansq_affine(dF, fs, dM, ms_, Af.ravel(), bf, Ams[c].ravel(), bms[c], vsize, stride, fixed_mask=mask)
+            assert sq[c, 1] == one[1]
+            np.testing.assert_allclose(sq[c, 0], one[0], rtol=1e-12, atol=0)
+            mom = backend.ctx.corr_moments_affine(dF, fs, dM, ms_, Af.ravel(), bf, Ams[c].ravel(), bms[c], vsize, stride, fixed_mask=mask)
+            np.testing.assert_allclose(co[c], mom[:6], rtol=1e-12, atol=0)
+        assert sq[3, 1] == 0 and sq[3, 0] == 0
+    # a candidate's value does not depend on its companions
+    alone = backend.ctx.metric_values_affine(0, dF, fs, dM, ms_, Af.ravel(), bf, Ams[5:6], bms[5:6], vsize, stride)
+    both = backend.ctx.metric_values_affine(0, dF, fs, dM, ms_, Af.ravel(), bf, Ams[2:9], bms[2:9], vsize, stride)
+    assert alone[0, 0] == both[3, 0] and alone[0, 1] == both[3, 1]
+
+
+def test_speculative_golden_section_is_the_sequential_search():
+    """Batched probing of the search tree takes the same probes in the same order and returns the same learning
+    rate as itk's sequential golden-section search (depth 1), for well- and ill-behaved objectives."""
+    from platipy_amd.registration.linear import _golden_section
+
+    objectives = [lambda e: (e - 0.37) ** 2, lambda e: (e - 3.9) ** 2 + 0.1 * np.sin(40 * e), lambda e: -e, lambda e: e,
+                  lambda e: float("inf") if e > 1.2 else (e - 2.0) ** 2, lambda e: 1.0]
+    for f in objectives:
+        results, used = [], []
+        for depth in (1, 2, 3, 4):
+            asked = []
+
+            def fbatch(es, asked=asked):
+                asked.append(list(es))
+                return [f(e) for e in es]
+
+            results.append(_golden_section(fbatch, 0.0, 1.0, 5.0, depth=depth))
+            used.append(asked)
+        assert results[0] == results[1] == results[2] == results[3]
+        sequential = [e for batch in used[0] for e in batch]
+        assert all(len(b) <= 2 for b in used[0])                     # depth 1: one probe (+ f(b) once) per launch
+        for depth, asked in zip((2, 3, 4), used[1:]):
+            assert max(len(b) for b in asked) <= 2 ** depth           # 2^depth - 1 probes + f(b)
+            assert len(asked) <= -(-len(used[0]) // depth) + 1        # ~depth times fewer launches
+            assert set(sequential) <= {e for b in asked for e in b}   # every sequential probe was among the speculated
+
+
 def test_corr_moments_kernel_matches_numpy(backend):
     from oracle import linear_oracle
 
@@ -78,6 +138,36 @@ def _rigid_pair(pa, shape, spacing, origin, angle=0.06, shift=(3.0, -2.0, 1.5), 
     mov = O.resample(O.Vol(fix, spacing, origin), O.Vol(fix, spacing, origin), affine=(Ainv, off_inv), interp=O.INTERP_LINEAR,
                      default_value=-1000.0).arr
     return fix, mov, (R, t, c)
+
+
+@pytest.mark.parametrize("method,optimiser,metric", [("rigid", "gradient_descent_line_search", "mean_squares"),
+                                                     ("affine", "gradient_descent_line_search", "mean_squares"),
+                                                     ("similarity", "gradient_descent", "mean_squares"),
+                                                     ("translation", "gradient_descent_line_search", "correlation")])
+def test_native_optimiser_follows_the_python_loop(backend, monkeypatch, method, optimiser, metric):
+    """pp_linear_optimize_f32 (the optimiser inside the library) and the Python loop are the same algorithm: driven
+    by the same kernels on the same small pair they end at the same parameters (differences: rounding in the
+    parameter -> matrix map and in the window-convergence slope)."""
+    import torch
+
+    import platipy_amd as pa
+    from platipy_amd import runtime
+    from platipy_amd.registration import linear
+
+    if backend.name == "emu":
+        monkeypatch.setattr(runtime, "context", lambda device=None: backend.ctx)
+        monkeypatch.setattr(runtime, "default_device", lambda: torch.device("cpu"))
+    shape, spacing, origin = (16, 20, 24), (1.5, 1.5, 2.5), (-30.0, -20.0, 10.0)
+    fix, mov, _ = _rigid_pair(pa, shape, spacing, origin, angle=0.06, shift=(2.0, -1.5, 1.0))
+    out = {}
+    for native in (True, False):
+        monkeypatch.setattr(linear, "NATIVE_OPTIMISER", native)
+        _, tfm = pa.registration.linear_registration(
+            pa.image_from_array(fix, spacing, origin), pa.image_from_array(mov, spacing, origin), reg_method=method, optimiser=optimiser,
+            metric=metric, shrink_factors=[2, 1], smooth_sigmas=[1, 0], sampling_rate=0.5, number_of_iterations=6)
+        out[native] = np.asarray(tfm.transforms[1].GetParameters())
+    assert np.abs(out[True]).max() > 1e-3                      # it moved
+    np.testing.assert_allclose(out[True], out[False], rtol=1e-6, atol=1e-8)
 
 
 @pytest.mark.parametrize("method,optimiser", [("rigid", "gradient_descent_line_search"),
