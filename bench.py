@@ -41,9 +41,12 @@ ALGO_BYTES_ITER = 196
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def synth_pair(ctx, shape, spacing, seed, device):
+def synth_pair(ctx, shape, spacing, seed, device, warp_seed=None, label=None):
     """SURVEY 8d synthetic CT pair, generated on the GPU: ellipsoid body, ellipsoidal organs,
-    sigma-1.5-voxel blur, N(0,5^2) noise; moving = fixed warped by a smooth <= 6 mm field + noise."""
+    sigma-1.5-voxel blur, N(0,5^2) noise; moving = fixed warped by a smooth <= 6 mm field + noise.
+    warp_seed: draw the field (and the moving image's noise) from its own stream, so that several atlases are
+    independent warps of one template (seeds 2000 + i).  label: a uint8 template label; the return
+    value then gains the label seen through the same field (nearest neighbour), i.e. the atlas's own contour."""
     nz, ny, nx = shape
     g = torch.Generator(device="cpu").manual_seed(seed)
     x = torch.arange(nx, device=device, dtype=torch.float32).view(1, 1, nx)
@@ -68,6 +71,8 @@ def synth_pair(ctx, shape, spacing, seed, device):
     del vol
     gd = torch.Generator(device=device).manual_seed(seed + 1)
     fixed = clean + 5.0 * torch.randn(shape, device=device, generator=gd)
+    if warp_seed is not None:
+        gd = torch.Generator(device=device).manual_seed(warp_seed)
     coarse = torch.randn((1, 3, 8, 16, 16), device=device, generator=gd)
     dvf = torch.nn.functional.interpolate(coarse, size=shape, mode="trilinear", align_corners=True)[0].contiguous()
     dvf *= 6.0 / float(torch.sqrt((dvf ** 2).sum(0)).max())
@@ -76,11 +81,19 @@ def synth_pair(ctx, shape, spacing, seed, device):
     ctx.warp(clean, dvf, geom, -1000.0, moving)
     ctx.sync()
     moving += 5.0 * torch.randn(shape, device=device, generator=gd)
+    if label is not None:
+        import platipy_amd as pa
+
+        field = pa.Image(dvf, spacing)
+        warped = pa.registration.apply_transform(pa.Image(label, spacing), transform=pa.DisplacementFieldTransform(field),
+                                                 default_value=0, interpolator=pa.sitkNearestNeighbor).tensor
+        del clean, dvf
+        return fixed.contiguous(), moving.contiguous(), geom, warped.contiguous()
     del clean, dvf
     return fixed.contiguous(), moving.contiguous(), geom
 
 
-def multi_atlas_leg(ctx, fixed, moving, spacing, rank, world, device):
+def multi_atlas_leg(ctx, fixed, moving, spacing, rank, world, device, seed=1234):
     """Config 4 shape: one atlas per GPU, whole chain (quick crop registration, affine, demons, propagation of
     the CT and one structure, local weight map, fusion all-reduce, post-processing) with the reference pipeline's
     default settings (multiatlas/run.py:47-103) except that atlases are already in HBM.  Returns seconds."""
@@ -95,8 +108,11 @@ def multi_atlas_leg(ctx, fixed, moving, spacing, rank, world, device):
     z = torch.arange(nz, device=device, dtype=torch.float32).view(nz, 1, 1)
     label = (((x - 0.5 * nx) / (0.2 * nx)) ** 2 + ((y - 0.5 * ny) / (0.18 * ny)) ** 2 + ((z - 0.5 * nz) / (0.25 * nz)) ** 2 < 1).to(torch.uint8)
     ids = [f"{i:03d}" for i in range(world)]
-    # this rank's atlas = the bench's moving image (the template seen through a smooth field) + the template's label
-    atlases = {ids[rank]: {"CT Image": pa.Image(moving, spacing), "HEART": pa.Image(label, spacing)}}
+    # this rank's atlas = the template seen through its own smooth field (seed 2000 + rank) + the template's label seen
+    # through the same field
+    # (the target is the seed-1234 template on EVERY rank: the pipeline replicates the target, only atlases are sharded)
+    fixed, atlas_ct, _, atlas_label = synth_pair(ctx, tuple(fixed.shape), spacing, seed, device, warp_seed=2000 + rank, label=label)
+    atlases = {ids[rank]: {"CT Image": pa.Image(atlas_ct, spacing), "HEART": pa.Image(atlas_label, spacing)}}
     st = copy.deepcopy(MUTLIATLAS_SETTINGS_DEFAULTS)
     st["atlas_settings"]["atlas_id_list"] = ids
     st["atlas_settings"]["atlas_structure_list"] = ["HEART"]
@@ -112,7 +128,41 @@ def multi_atlas_leg(ctx, fixed, moving, spacing, rank, world, device):
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    return dt, int(res["HEART"].tensor.sum())
+    fused = res["HEART"].tensor > 0
+    dice = float(2 * (fused & (label > 0)).sum() / (fused.sum() + (label > 0).sum()))
+    return dt, int(fused.sum()), dice
+
+
+def multi_atlas_streams_leg(ctx, shape, spacing, device, n_atlases=4, streams=4, seed=1234):
+    """Config 5's per-GPU shape: `n_atlases` atlases on ONE GPU, their chains overlapped on `streams` HIP streams
+    (one worker thread + pp_ctx per stream), then fusion.  Returns (seconds, Dice of the fused label)."""
+    import copy
+
+    import platipy_amd as pa
+    from platipy_amd.projects.multiatlas import MUTLIATLAS_SETTINGS_DEFAULTS, run_segmentation
+
+    nz, ny, nx = shape
+    x = torch.arange(nx, device=device, dtype=torch.float32).view(1, 1, nx)
+    y = torch.arange(ny, device=device, dtype=torch.float32).view(1, ny, 1)
+    z = torch.arange(nz, device=device, dtype=torch.float32).view(nz, 1, 1)
+    label = (((x - 0.5 * nx) / (0.2 * nx)) ** 2 + ((y - 0.5 * ny) / (0.18 * ny)) ** 2 + ((z - 0.5 * nz) / (0.25 * nz)) ** 2 < 1).to(torch.uint8)
+    atlases, ids, target = {}, [f"{i:03d}" for i in range(n_atlases)], None
+    for i, cid in enumerate(ids):
+        target, ct, _, lab = synth_pair(ctx, shape, spacing, seed, device, warp_seed=2000 + i, label=label)
+        atlases[cid] = {"CT Image": pa.Image(ct, spacing), "HEART": pa.Image(lab, spacing)}
+    st = copy.deepcopy(MUTLIATLAS_SETTINGS_DEFAULTS)
+    st["atlas_settings"]["atlas_id_list"] = ids
+    st["atlas_settings"]["atlas_structure_list"] = ["HEART"]
+    st["label_fusion_settings"]["vote_type"] = "local"
+    target = pa.Image(target, spacing)
+    run_segmentation(target, st, atlases=atlases, streams_per_gpu=streams)      # warm-up: per-stream workspaces
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res, _ = run_segmentation(target, st, atlases=atlases, streams_per_gpu=streams)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fused = res["HEART"].tensor > 0
+    return dt, float(2 * (fused & (label > 0)).sum() / (fused.sum() + (label > 0).sum()))
 
 
 def cpu_baseline(fixed, moving, spacing, budget_s=12.0):
@@ -312,17 +362,26 @@ def main():
 
     if not args.no_atlas and (nx, ny, nz) == (512, 512, 256):
         try:
-            dt_a, nvox_label = multi_atlas_leg(ctx, fixed, moving, spacing, rank, world, device)
+            dt_a, nvox_label, dice_a = multi_atlas_leg(ctx, fixed, moving, spacing, rank, world, device)
             if world > 1:
                 dt_a = max_over_ranks(dt_a)
             if rank == 0:
                 out["multi_atlas"] = {"atlases": world, "atlases_per_gpu": 1, "structures": 1, "seconds": dt_a,
                                       "atlases_per_min": 60.0 * world / dt_a, "fused_label_voxels": nvox_label,
+                                      "dice_vs_template_label": dice_a,
                                       "settings": "multiatlas/run.py defaults (affine GD-line-search 16/8/4 x50; demons isotropic "
                                                   "6/3/1.5 mm x150/125/100; local vote), atlases resident in HBM"}
         except Exception as e:
             if rank == 0:
                 out["multi_atlas"] = f"failed: {e!r}"
+        if world == 1:
+            try:
+                dt_s, dice_s = multi_atlas_streams_leg(ctx, (nz, ny, nx), spacing, device)
+                out["multi_atlas_streams"] = {"atlases": 4, "hip_streams": 4, "seconds": dt_s, "atlases_per_min": 60.0 * 4 / dt_s,
+                                              "dice_vs_template_label": dice_s,
+                                              "settings": "as multi_atlas; 4 independent atlas warps on one GPU, chains overlapped"}
+            except Exception as e:
+                out["multi_atlas_streams"] = f"failed: {e!r}"
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

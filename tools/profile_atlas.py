@@ -16,7 +16,7 @@ ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
 fixed, moving, geom = synth_pair(ctx, (256, 512, 512), (1.0, 1.0, 1.0), 1234, dev)
 pr = cProfile.Profile()
 pr.enable()
-dt, n = multi_atlas_leg(ctx, fixed, moving, (1.0, 1.0, 1.0), 0, 1, dev)
+dt, n, dice = multi_atlas_leg(ctx, fixed, moving, (1.0, 1.0, 1.0), 0, 1, dev)
 pr.disable()
-print("timed run", dt)
+print("timed run", dt, "dice", dice)
 pstats.Stats(pr).sort_stats("cumulative").print_stats(45)

@@ -83,11 +83,11 @@ if "5" in which:
     label = (((x - 0.5 * nx) / (0.2 * nx)) ** 2 + ((y - 0.5 * ny) / (0.18 * ny)) ** 2 + ((z - 0.5 * nz) / (0.25 * nz)) ** 2 < 1).to(torch.uint8)
     atlases, ids = {}, []
     for i in range(4):
-        # an atlas = the same anatomy seen through its own smooth field (synth_pair's "moving" with another seed) + the label
-        _, mov, _ = synth_pair(ctx, shape, (1.0, 1.0, 1.0), 1234, dev) if i == 0 else synth_pair(ctx, shape, (1.0, 1.0, 1.0), 1234, dev)
+        # an atlas = the same anatomy seen through its own smooth field (seed 2000 + i) + the label seen through that field
+        _, mov, _, lab = synth_pair(ctx, shape, (1.0, 1.0, 1.0), 1234, dev, warp_seed=2000 + i, label=label)
         cid = f"{i:03d}"
         ids.append(cid)
-        atlases[cid] = {"CT Image": pa.Image(mov + 2.0 * i, (1.0, 1.0, 1.0)), "HEART": pa.Image(label, (1.0, 1.0, 1.0))}
+        atlases[cid] = {"CT Image": pa.Image(mov, (1.0, 1.0, 1.0)), "HEART": pa.Image(lab, (1.0, 1.0, 1.0))}
     st = copy.deepcopy(MUTLIATLAS_SETTINGS_DEFAULTS)
     st["atlas_settings"]["atlas_id_list"] = ids
     st["atlas_settings"]["atlas_structure_list"] = ["HEART"]
