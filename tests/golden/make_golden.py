@@ -14,7 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from oracle import oracle as O  # noqa: E402
+from oracle import linear_oracle, oracle as O  # noqa: E402
 
 SHAPE, SPACING, ORIGIN = (10, 14, 18), (0.9, 1.1, 2.5), (320.0, -52.0, 60.0)
 
@@ -31,6 +31,19 @@ def inputs():
     field = (field * 1.5).astype(np.float32)
     mask = ((xx - 9) ** 2 / 30.0 + (yy - 7) ** 2 / 20.0 + (zz - 5) ** 2 / 8.0 < 1).astype(np.uint8)
     return fixed, moving, field, mask
+
+
+def NOTCHED(mask):
+    """the mask with a slot cut into it, so that closing has something to close"""
+    m = mask.copy()
+    m[4:6, 6:8, 3:16] = 0
+    return m
+
+
+# (Af, bf, Am, bm, vsize, stride): virtual 9x7x5 lattice over the 18x14x10 images, a slightly sheared moving map
+METRIC_MAP = (np.eye(3) * 2.0, np.array([0.5, 0.5, 0.5]),
+              np.array([[1.9137, 0.1071, 0.0031], [-0.0813, 2.0519, 0.0207], [0.0109, 0.0043, 1.9011]]), np.array([0.7123, -0.4057, 0.4131]),
+              (9, 7, 5), 2)
 
 
 def main():
@@ -63,6 +76,10 @@ def main():
         "weight_local": O.compute_weight_map(vf, vm, "local").arr,
         "distance_map_signed": O.maurer_distance_map(O.Vol(mask, SPACING, ORIGIN), signed=True).arr,
         "label_contour": O.label_contour(O.Vol(mask, SPACING, ORIGIN)).arr,
+        "dilate_ball_221": O.binary_dilate_ball(O.Vol(mask, SPACING, ORIGIN), (2, 2, 1)).arr,
+        "erode_ball_111": O.binary_erode_ball(O.Vol(mask, SPACING, ORIGIN), (1, 1, 1)).arr,
+        "close_ball_210": O.binary_closing_ball(O.Vol(NOTCHED(mask), SPACING, ORIGIN), (2, 1, 0)).arr,
+        "meansq_affine": np.array(linear_oracle.meansq_affine(fixed, moving, *METRIC_MAP), dtype=np.float64),
     }
     np.savez_compressed(os.path.join(HERE, "hotpath_small.npz"), **out)
     print("wrote", os.path.join(HERE, "hotpath_small.npz"), {k: v.shape for k, v in out.items()})

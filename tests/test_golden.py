@@ -8,7 +8,7 @@ import pytest
 
 from oracle import oracle as O
 from platipy_amd import _lib
-from tests.golden.make_golden import ORIGIN, SHAPE, SPACING, inputs
+from tests.golden.make_golden import METRIC_MAP, NOTCHED, ORIGIN, SHAPE, SPACING, inputs
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "hotpath_small.npz"))
 SIZE = (SHAPE[2], SHAPE[1], SHAPE[0])
@@ -35,6 +35,33 @@ def test_oracle_reproduces_golden():
     np.testing.assert_array_equal(O.resample(O.Vol(G["mask"], SPACING, ORIGIN), O.Vol(G["mask"], SPACING, ORIGIN),
                                              field_vol=O.Vol(f64, SPACING, ORIGIN), interp=O.INTERP_NEAREST).arr, G["mask_nn_through_field"])
     np.testing.assert_array_equal(O.label_contour(O.Vol(G["mask"], SPACING, ORIGIN)).arr, G["label_contour"])
+    mv = O.Vol(G["mask"], SPACING, ORIGIN)
+    np.testing.assert_array_equal(O.binary_dilate_ball(mv, (2, 2, 1)).arr, G["dilate_ball_221"])
+    np.testing.assert_array_equal(O.binary_erode_ball(mv, (1, 1, 1)).arr, G["erode_ball_111"])
+    np.testing.assert_array_equal(O.binary_closing_ball(O.Vol(NOTCHED(G["mask"]), SPACING, ORIGIN), (2, 1, 0)).arr, G["close_ball_210"])
+    from oracle import linear_oracle
+
+    np.testing.assert_allclose(linear_oracle.meansq_affine(G["fixed"], G["moving"], *METRIC_MAP), G["meansq_affine"], rtol=1e-12)
+
+
+def test_product_morphology_and_metric_match_golden(backend):
+    ctx = backend.ctx
+    mask = backend.dev(G["mask"])
+    for key, radius, op, src in (("dilate_ball_221", (2, 2, 1), 0, mask), ("erode_ball_111", (1, 1, 1), 1, mask),
+                                 ("close_ball_210", (2, 1, 0), 2, backend.dev(NOTCHED(G["mask"])))):
+        out = backend.empty(SHAPE, np.uint8)
+        ctx.binary_morph_ball(src, SIZE, radius, op, out)
+        np.testing.assert_array_equal(backend.host(out), G[key])
+    assert (G["close_ball_210"] != NOTCHED(G["mask"])).any()            # the closing did close something
+    Af, bf, Am, bm, vsize, stride = METRIC_MAP
+    want = G["meansq_affine"]
+    got = np.array(ctx.meansq_affine(backend.dev(G["fixed"]), SIZE, backend.dev(G["moving"]), SIZE, Af.ravel(), bf, Am.ravel(), bm, vsize, stride))
+    assert got[1] == want[1] and want[1] > 50
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-5)
+    np.testing.assert_allclose(got[2:], want[2:], rtol=2e-4, atol=1e-3 * np.abs(want[2:]).max())
+    vals = ctx.metric_values_affine(0, backend.dev(G["fixed"]), SIZE, backend.dev(G["moving"]), SIZE, Af.ravel(), bf, [Am], [bm], vsize, stride)
+    assert vals[0, 1] == want[1]
+    np.testing.assert_allclose(vals[0, 0], want[0], rtol=1e-5)
 
 
 def test_product_matches_golden(backend):
