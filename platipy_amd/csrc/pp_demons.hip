@@ -686,9 +686,11 @@ int fused_zchunk(const pp_dims& d, int slots) {
     if (v >= 1) return v < d.nz ? v : d.nz;
   }
   const int tiles = ((d.nx + TX - 1) / TX) * ((d.ny + TY - 1) / TY);
+  // Small grids (the coarse pyramid levels) cannot fill the chip either way and are bound by the latency of one
+  // block's march instead, ~2.5 us per plane: short chunks (down to 2 planes + halo) cut that chain.
   int best = d.nz < 32 ? d.nz : 32;
   double best_cost = 1e30;
-  for (int zc = 12; zc <= 64 && zc <= d.nz; ++zc) {
+  for (int zc = 2; zc <= 64 && zc <= d.nz; ++zc) {
     const int chunks = (d.nz + zc - 1) / zc;
     if ((chunks - 1) * zc >= d.nz) continue;
     const long blocks = (long)tiles * chunks;

@@ -273,6 +273,26 @@ def test_demons_execute(backend, grid, variant):
     assert np.abs(want).max() > 0.2  # the registration did something
 
 
+@pytest.mark.parametrize("zchunk", [1, 2, 3, 5, 100])
+def test_fused_demons_is_independent_of_the_z_chunking(backend, zchunk, monkeypatch):
+    """The fused schedule splits z into chunks (halo planes recomputed at the seams); any chunk length, shorter
+    than the halo included, gives bit-identical fields."""
+    shape, spacing, origin = GRIDS[0]
+    fix = phantom(shape, seed=40)
+    dv = random_dvf(shape, spacing, seed=41, max_mm=2.5)
+    mov = O.warp_image(O.Vol(fix, spacing, origin), dv.astype(np.float64), edge_value=-1000.0).arr.astype(np.float32)
+    p = _demons_params(backend.ctx, 3, spacing, _lib.DEMONS_FUSED, max_rms=0.0)
+    monkeypatch.delenv("PP_FUSED_ZCHUNK", raising=False)
+    ref = backend.empty((3,) + shape)
+    st0 = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, ref)
+    monkeypatch.setenv("PP_FUSED_ZCHUNK", str(zchunk))
+    out = backend.empty((3,) + shape)
+    st1 = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, out)
+    np.testing.assert_array_equal(backend.host(out), backend.host(ref))
+    # the statistics are sums of per-block partial sums: their grouping follows the chunking
+    np.testing.assert_allclose([st1.metric, st1.rms_change], [st0.metric, st0.rms_change], rtol=1e-6)
+
+
 @pytest.mark.parametrize("variant", [_lib.DEMONS_STAGED, _lib.DEMONS_FUSED])
 def test_demons_early_halt(backend, variant):
     """MaximumRMSError stops the loop on device exactly where FiniteDifferenceImageFilter::Halt does."""
