@@ -229,6 +229,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-registration", action="store_true")
     ap.add_argument("--no-atlas", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="time the region without the per-launch HIP events (no roofline block)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -278,7 +279,7 @@ def main():
         p.iterations = args.warmup
         ctx.demons_execute(fixed, moving, geom, p, field, want_stats=False)
     torch.cuda.synchronize()
-    ctx.profile_enable(True)
+    ctx.profile_enable(not args.no_kernel_events)
     p.iterations = args.steps
     barrier()
     torch.cuda.synchronize()
