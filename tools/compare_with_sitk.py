@@ -90,6 +90,52 @@ def main():
     got = O.compute_weight_map(vf, vm, "local").arr
     print(f"{'compute_weight_map(local), relative':42s} max {np.abs(got / want - 1).max():.3e}")
 
+    # 7. binary morphology with the ball kernel (registration/utils.py:328-329; multiatlas/run.py:421-423)
+    mask = (phantom(shape, seed=5, noise=0) > -300).astype(np.uint8)
+    mask[:, :3, :] = 0
+    Mk = to_sitk(mask, spacing, origin)
+    mv = O.Vol(mask, spacing, origin)
+    for radius in ((1, 1, 1), (2, 2, 0), (3, 2, 1)):
+        report(f"BinaryDilate ball {radius}", O.binary_dilate_ball(mv, radius).arr, sitk.GetArrayFromImage(sitk.BinaryDilate(Mk, radius)))
+        report(f"BinaryErode ball {radius}", O.binary_erode_ball(mv, radius).arr, sitk.GetArrayFromImage(sitk.BinaryErode(Mk, radius)))
+        report(f"BinaryMorphologicalClosing ball {radius}", O.binary_closing_ball(mv, radius).arr,
+               sitk.GetArrayFromImage(sitk.BinaryMorphologicalClosing(Mk, radius)))
+    # 8. distance map, contour, fill-hole + largest component (label/projection.py:80-90, label/fusion.py:305-328)
+    want = sitk.GetArrayFromImage(sitk.SignedMaurerDistanceMap(Mk, insideIsPositive=True, squaredDistance=False, useImageSpacing=True))
+    report("SignedMaurerDistanceMap (inside positive)", O.maurer_distance_map(mv, signed=True, inside_positive=True).arr, want)
+    report("LabelContour", O.label_contour(mv).arr, sitk.GetArrayFromImage(sitk.LabelContour(Mk)))
+    prob = sitk.Cast(sitk.DiscreteGaussian(sitk.Cast(Mk, sitk.sitkFloat32), 2.0), sitk.sitkFloat32)
+    pm = prob / float(sitk.GetArrayViewFromImage(prob).max())
+    b = sitk.BinaryFillhole(sitk.BinaryThreshold(pm, lowerThreshold=0.5, upperThreshold=1.0))
+    cc = sitk.ConnectedComponent(b)
+    st = sitk.LabelShapeStatisticsImageFilter()
+    st.Execute(cc)
+    best = max(st.GetLabels(), key=st.GetNumberOfPixels) if st.GetLabels() else 0
+    want = sitk.GetArrayFromImage(sitk.Cast(cc == best, sitk.sitkUInt8)) if best else sitk.GetArrayFromImage(b)
+    report("process_probability_image(0.5)", O.process_probability_image(O.Vol(sitk.GetArrayFromImage(prob), spacing, origin), 0.5).arr, want)
+    # 9. the mean-squares metric at a given affine map, and a whole linear_registration (registration/linear.py:129-238)
+    reg = sitk.ImageRegistrationMethod()
+    reg.SetMetricAsMeanSquares()
+    reg.SetMetricSamplingStrategy(reg.NONE)
+    reg.SetInterpolator(sitk.sitkLinear)
+    tfm0 = sitk.AffineTransform(3)
+    tfm0.SetMatrix([1.01, 0.02, 0.0, -0.015, 0.99, 0.01, 0.0, 0.005, 1.0])
+    tfm0.SetTranslation((1.5, -2.0, 0.7))
+    reg.SetInitialTransform(tfm0, inPlace=False)
+    from oracle import linear_oracle
+
+    A = np.array(tfm0.GetMatrix()).reshape(3, 3)
+    t = np.array(tfm0.GetTranslation())
+    i2p = np.diag(spacing)
+    p2i = np.linalg.inv(i2p)
+    o = np.array(origin)
+    Am, bm = p2i @ A @ i2p, p2i @ (A @ o + t - o)
+    r = linear_oracle.meansq_affine(fix, mov, np.eye(3), np.zeros(3), Am, bm, shape[::-1], 1)
+    print(f"{'MeanSquares metric at a fixed affine map':42s} oracle {r[0] / r[1]:.6f}  sitk {reg.MetricEvaluate(F, M):.6f}")
+    print("linear_registration end-to-end: run platipy.imaging.registration.linear.linear_registration and "
+          "platipy_amd.registration.linear_registration on the same pair on a GPU box and compare the corner displacements "
+          "(tests/test_linear.py::test_linear_registration_recovers_known_transform holds the build to < 1 mm of the known map)")
+
     try:
         import torch
 
