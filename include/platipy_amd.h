@@ -46,6 +46,7 @@ typedef enum {
 
 enum { PP_INTERP_NEAREST = 1, PP_INTERP_LINEAR = 2 }; /* = sitk.sitkNearestNeighbor / sitkLinear */
 enum { PP_MORPH_DILATE = 0, PP_MORPH_ERODE = 1, PP_MORPH_CLOSE = 2 };
+enum { PP_DTYPE_U8 = 0, PP_DTYPE_F32 = 1 };
 
 enum { PP_DEMONS_AUTO = 0, PP_DEMONS_STAGED = 1, PP_DEMONS_FUSED = 2 };
 
@@ -202,6 +203,10 @@ int pp_fillhole_largest_component_u8(pp_ctx* ctx, const uint8_t* in, const int s
  * by the radius).  Masks are 0 / non-zero in, 0 / 1 out; radius in voxels per axis (x, y, z), each <= 15. */
 int pp_binary_morph_ball_u8(pp_ctx* ctx, const uint8_t* in, const int size[3], const int radius[3], int op,
                             uint8_t* out);
+
+/* Bounding box of the voxels > 0 (label_to_roi, utils/crop.py:24-60): box (host) = {xmin, xmax, ymin, ymax, zmin,
+ * zmax}; an empty volume gives xmin > xmax.  dtype = PP_DTYPE_U8 or PP_DTYPE_F32.  Synchronises. */
+int pp_bounding_box(pp_ctx* ctx, const void* data, int dtype, const int size[3], int box[6]);
 
 /* ---- iterative atlas removal ------------------------------------------------------- */
 /* sitk.LabelContour(mask) with face connectivity (label/projection.py:85): object voxels that have a face

@@ -114,6 +114,7 @@ _SIGNATURES = {
     "pp_binary_threshold_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_double, C.c_double, _P]),
     "pp_fillhole_largest_component_u8": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.c_int, _P, C.POINTER(C.c_int64)]),
     "pp_binary_morph_ball_u8": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, _P]),
+    "pp_bounding_box": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pp_label_contour_u8": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P]),
     "pp_distance_map_f32": (C.c_int, [_P, _P, C.POINTER(Geom), C.c_int, C.c_int, _P]),
     "pp_meansq_affine_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double),
@@ -348,6 +349,12 @@ class Context:
         """op: 0 dilate, 1 erode, 2 closing (safe border); ITK ball of `radius` voxels (x, y, z)."""
         self._chk(self.lib.pp_binary_morph_ball_u8(self.h, ptr(mask), _i3(size), _i3(radius), int(op), ptr(out)),
                   "pp_binary_morph_ball_u8")
+
+    def bounding_box(self, data, size, is_float):
+        """-> [xmin, xmax, ymin, ymax, zmin, zmax] of the voxels > 0 (xmin > xmax when there are none)."""
+        box = (C.c_int * 6)()
+        self._chk(self.lib.pp_bounding_box(self.h, ptr(data), 1 if is_float else 0, _i3(size), box), "pp_bounding_box")
+        return [box[i] for i in range(6)]
 
     def label_contour(self, mask, size, out):
         self._chk(self.lib.pp_label_contour_u8(self.h, ptr(mask), _i3(size), ptr(out)), "pp_label_contour_u8")

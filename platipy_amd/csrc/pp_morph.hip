@@ -12,6 +12,8 @@
 // voxel, pixel-centre inclusion).  Each (dy, dz) row of it is one contiguous span |dx| <= ex, so the element
 // travels as a table of half-widths by value in the kernel arguments (<= 31 x 31 bytes) and a voxel's test is a
 // handful of short byte-row scans with early exit: HBM/L2-bound byte work, nothing to tile.
+#include <algorithm>
+
 #include "pp_internal.h"
 #include "pp_kernels.h"
 
@@ -62,6 +64,52 @@ __global__ void __launch_bounds__(NT) k_morph_ball(const uint8_t* __restrict__ i
     }
     out[i] = ERODE ? (hit ? 0 : 1) : (hit ? 1 : 0);
   }
+}
+
+// Bounding box of the voxels > 0 (label_to_roi, platipy/imaging/utils/crop.py:24-60): one streaming pass, a wave
+// per (z, y) row, per-block LDS min/max, six global atomics per block.  box = {xmin, xmax, ymin, ymax, zmin, zmax}.
+template <typename T>
+__global__ void __launch_bounds__(NT) k_bounding_box(const T* __restrict__ v, pp_dims d, int* __restrict__ box) {
+  __shared__ int sb[6];
+  if (threadIdx.x < 6) sb[threadIdx.x] = (threadIdx.x & 1) ? -1 : 0x7fffffff;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t rows = (size_t)d.ny * d.nz;
+  int xlo = 0x7fffffff, xhi = -1, ylo = 0x7fffffff, yhi = -1, zlo = 0x7fffffff, zhi = -1;
+  for (size_t r = (size_t)blockIdx.x * (NT / 64) + wave; r < rows; r += (size_t)gridDim.x * (NT / 64)) {
+    const T* row = v + r * d.nx;
+    const int y = (int)(r % d.ny), z = (int)(r / d.ny);
+    bool any = false;
+    for (int x = lane; x < d.nx; x += 64)
+      if (row[x] > (T)0) {
+        any = true;
+        xlo = x < xlo ? x : xlo;
+        xhi = x > xhi ? x : xhi;
+      }
+    if (any) {
+      ylo = y < ylo ? y : ylo;
+      yhi = y > yhi ? y : yhi;
+      zlo = z < zlo ? z : zlo;
+      zhi = z > zhi ? z : zhi;
+    }
+  }
+  if (xhi >= 0) {
+    atomicMin(&sb[0], xlo);
+    atomicMax(&sb[1], xhi);
+    atomicMin(&sb[2], ylo);
+    atomicMax(&sb[3], yhi);
+    atomicMin(&sb[4], zlo);
+    atomicMax(&sb[5], zhi);
+  }
+  __syncthreads();
+  if (threadIdx.x < 6 && sb[1] >= 0) {
+    if (threadIdx.x & 1) atomicMax(&box[threadIdx.x], sb[threadIdx.x]);
+    else atomicMin(&box[threadIdx.x], sb[threadIdx.x]);
+  }
+}
+
+__global__ void k_bounding_box_init(int* box) {
+  if (threadIdx.x < 6) box[threadIdx.x] = (threadIdx.x & 1) ? -1 : 0x7fffffff;
 }
 
 unsigned grid_for(size_t work) {
@@ -121,4 +169,25 @@ extern "C" int pp_binary_morph_ball_u8(pp_ctx* ctx, const uint8_t* in, const int
   rc = launch<0>(ctx, in, d, padded, dp, morph_off{-radius[0], -radius[1], -radius[2]}, se);
   if (rc) return rc;
   return launch<1>(ctx, padded, dp, out, d, morph_off{radius[0], radius[1], radius[2]}, se);
+}
+
+extern "C" int pp_bounding_box(pp_ctx* ctx, const void* data, int dtype, const int size[3], int box[6]) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, data && size && box, "pp_bounding_box: NULL argument");
+  PP_REQUIRE(ctx, size[0] > 0 && size[1] > 0 && size[2] > 0, "pp_bounding_box: empty volume");
+  PP_REQUIRE(ctx, dtype == PP_DTYPE_U8 || dtype == PP_DTYPE_F32, "pp_bounding_box: dtype must be PP_DTYPE_U8 or PP_DTYPE_F32");
+  const pp_dims d{size[0], size[1], size[2]};
+  int rc = pp_reserve(ctx, 256);
+  if (rc) return rc;
+  int* dbox = reinterpret_cast<int*>(ctx->ws);
+  hipLaunchKernelGGL(k_bounding_box_init, dim3(1), dim3(64), 0, ctx->stream, dbox);
+  PP_LAUNCH_CHECK(ctx, "k_bounding_box_init");
+  const size_t rows = (size_t)d.ny * d.nz;
+  const unsigned nb = (unsigned)std::min<size_t>((rows + NT / 64 - 1) / (NT / 64), 4096);
+  if (dtype == PP_DTYPE_U8)
+    hipLaunchKernelGGL(k_bounding_box<uint8_t>, dim3(nb), dim3(NT), 0, ctx->stream, static_cast<const uint8_t*>(data), d, dbox);
+  else
+    hipLaunchKernelGGL(k_bounding_box<float>, dim3(nb), dim3(NT), 0, ctx->stream, static_cast<const float*>(data), d, dbox);
+  PP_LAUNCH_CHECK(ctx, "k_bounding_box");
+  return pp_read_back(ctx, dbox, box, 6 * sizeof(int));
 }

@@ -1,5 +1,6 @@
 """Drop-in for platipy/imaging/utils/crop.py:24-77 (label_to_roi, crop_to_roi) plus the paste-back the
-pipelines do with sitk.Paste (multiatlas/run.py:386-404).  Bounding-box arithmetic only."""
+pipelines do with sitk.Paste (multiatlas/run.py:386-404).  The bounding box is one streaming HIP pass
+(pp_bounding_box); the rest is index arithmetic."""
 import numpy as np
 import torch
 
@@ -9,25 +10,27 @@ from ..image import Image, as_image
 def label_to_roi(label, expansion_mm=[0, 0, 0], return_as_list=False):
     """Bounding box of a binary label (or the union of several), expanded by `expansion_mm` and clipped
     to the image: returns (crop_box_size, crop_box_index), both (x, y, z)."""
+    from .. import runtime
+
     if isinstance(label, (list, tuple)) or (hasattr(label, "__iter__") and not isinstance(label, Image)):
         labels = [as_image(l) for l in label]
-        ref = labels[0]
-        mask = torch.zeros(ref.shape, dtype=torch.bool, device=ref.device)
-        for l in labels:
-            mask |= l.tensor > 0
     else:
-        ref = as_image(label)
-        mask = ref.tensor > 0
+        labels = [as_image(label)]
+    ref = labels[0]
     spacing = np.array(ref.GetSpacing())
-    if not bool(mask.any()):
+    ctx = runtime.context(ref.device)
+    lo, hi = [2 ** 31 - 1] * 3, [-1] * 3
+    for l in labels:     # one streaming pass per label on the device (pp_bounding_box); boxes merged here
+        t = l.tensor
+        if t.dtype not in (torch.uint8, torch.float32):
+            t = (t > 0).to(torch.uint8)
+        box = ctx.bounding_box(t.contiguous(), l.GetSize(), t.dtype == torch.float32)
+        if box[0] <= box[1]:
+            lo = [min(lo[k], box[2 * k]) for k in range(3)]
+            hi = [max(hi[k], box[2 * k + 1]) for k in range(3)]
+    if hi[0] < 0:
         raise ValueError("label_to_roi: empty label")
-    idx, size = [], []
-    for axis in (2, 1, 0):  # x, y, z
-        other = tuple(a for a in (0, 1, 2) if a != axis)
-        nz = torch.nonzero(mask.any(dim=other)).flatten()
-        lo, hi = int(nz[0]), int(nz[-1])
-        idx.append(lo)
-        size.append(hi - lo + 1)
+    idx, size = lo, [hi[k] - lo[k] + 1 for k in range(3)]
     index, size = np.array(idx), np.array(size)
     expansion = (np.array(expansion_mm) / spacing).astype(int)
     crop_box_index = np.max([index - expansion, np.array([0, 0, 0])], axis=0)

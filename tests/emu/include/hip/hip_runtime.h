@@ -125,6 +125,11 @@ static inline int atomicMin(int* p, int v) {
   while (v < o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
   return o;
 }
+static inline int atomicMax(int* p, int v) {
+  int o = *p;
+  while (v > o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+  return o;
+}
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline int __float2int_rd(float x) { return (int)floorf(x); }
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }

@@ -436,6 +436,24 @@ def test_distance_map_and_contour(backend, grid):
     np.testing.assert_array_equal(backend.host(c), O.label_contour(O.Vol(mask, spacing, origin)).arr)
 
 
+def test_bounding_box(backend):
+    """pp_bounding_box (label_to_roi, utils/crop.py:24-60): uint8 and float volumes, a single voxel, nothing at all."""
+    shape = (9, 13, 70)                     # rows longer than a wave
+    rng = np.random.default_rng(8)
+    for dtype in (np.uint8, np.float32):
+        a = np.zeros(shape, dtype)
+        assert backend.ctx.bounding_box(backend.dev(a), size_of(shape), dtype == np.float32)[0] > backend.ctx.bounding_box(
+            backend.dev(a), size_of(shape), dtype == np.float32)[1]
+        a[4, 7, 66] = 3
+        assert backend.ctx.bounding_box(backend.dev(a), size_of(shape), dtype == np.float32) == [66, 66, 7, 7, 4, 4]
+        a[2:8, 3:11, 5:69] = (rng.random((6, 8, 64)) > 0.7).astype(dtype)
+        if dtype == np.float32:
+            a[0, 0, 0] = -5.0               # not > 0
+        zz, yy, xx = np.nonzero(a > 0)
+        want = [xx.min(), xx.max(), yy.min(), yy.max(), zz.min(), zz.max()]
+        assert backend.ctx.bounding_box(backend.dev(a), size_of(shape), dtype == np.float32) == [int(v) for v in want]
+
+
 @pytest.mark.parametrize("radius", [(1, 1, 1), (2, 2, 0), (3, 2, 1), (0, 0, 0), (5, 4, 2)])
 def test_binary_morphology_ball(backend, radius):
     """BinaryDilate / BinaryErode / BinaryMorphologicalClosing with ITK's ball (registration/utils.py:328-329,

@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Per-level cost of the pipelines' two linear registrations (quick similarity at shrink 8; affine 16/8/4) at 512x512x256."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import platipy_amd as pa  # noqa: E402
+from bench import synth_pair  # noqa: E402
+from platipy_amd import _lib  # noqa: E402
+from platipy_amd.projects.multiatlas import MUTLIATLAS_SETTINGS_DEFAULTS, QUICK_REG_SETTINGS  # noqa: E402
+from platipy_amd.registration import linear  # noqa: E402
+
+ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
+fixed, moving, _ = synth_pair(ctx, (256, 512, 512), (1.0, 1.0, 1.0), 1234, torch.device("cuda", 0), warp_seed=2000)
+fi, mi = pa.Image(fixed, (1.0, 1.0, 1.0)), pa.Image(moving, (1.0, 1.0, 1.0))
+orig = linear._optimise_level_native
+log = []
+
+
+def timed(ctx_, ms, model, params, opt, n_it, verbose):
+    torch.cuda.synchronize()
+    e0 = ms.evaluations
+    t0 = time.perf_counter()
+    out = orig(ctx_, ms, model, params, opt, n_it, verbose)
+    log.append((tuple(ms.vsize), ms.stride, time.perf_counter() - t0, ms.evaluations - e0))
+    return out
+
+
+linear._optimise_level_native = timed
+for name, kw in (("quick", QUICK_REG_SETTINGS), ("affine", MUTLIATLAS_SETTINGS_DEFAULTS["linear_registration_settings"])):
+    pa.registration.linear_registration(fi, mi, **kw)
+    log.clear()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pa.registration.linear_registration(fi, mi, **kw)
+    torch.cuda.synchronize()
+    print(name, "total", round((time.perf_counter() - t0) * 1e3, 2), "ms")
+    for vsize, stride, dt, ev in log:
+        print(f"   level vsize {vsize} stride {stride}: {dt * 1e3:7.2f} ms, {ev} evaluations, {dt * 1e6 / max(ev, 1):.1f} us/evaluation")
