@@ -9,8 +9,9 @@
 // a component's root is its first voxel in raster order, which is also the order ITK numbers components
 // in, so "first largest" ties resolve identically).  One sweep labels foreground AND background
 // components (neighbours are united when their binary values agree); background components that own no
-// border voxel are holes.  Irregular, latency-bound integer work on 4 B labels: no LDS tiling pays until
-// the merge sweep is tiled, which is left for a later round.
+// border voxel are holes.  Two stages: x-runs first (an LDS scan per row, no atomics), then unions only where a
+// run starts against the rows above -- the background of a CT-sized mask is one 60-Mvoxel component, and uniting
+// it voxel by voxel serialises on its root (12 ms at 512x512x256; 10x less in stages).
 #include "pp_internal.h"
 #include "pp_kernels.h"
 
@@ -45,11 +46,41 @@ __device__ __forceinline__ void cc_unite(int* L, int a, int b) {
   }
 }
 
-__global__ void __launch_bounds__(NT) k_cc_init(int* __restrict__ L, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) L[i] = (int)i;
+// Stage 1, rows: every voxel points at the first voxel of its x-run of equal values (a max-scan of the run-start
+// positions through LDS, NT voxels at a time with a carry).  fg_only: background voxels keep their own index.
+__global__ void __launch_bounds__(NT) k_cc_rows(const uint8_t* __restrict__ mask, int* __restrict__ L, pp_dims d, int fg_only) {
+  __shared__ int s[NT];
+  __shared__ int carry_s;
+  const size_t rows = (size_t)d.ny * d.nz;
+  for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    const uint8_t* m = mask + row * d.nx;
+    int carry = 0;
+    for (int x0 = 0; x0 < d.nx; x0 += NT) {
+      const int x = x0 + (int)threadIdx.x;
+      const bool valid = x < d.nx;
+      const bool v = valid && m[x] != 0;
+      const bool start = valid && (x == 0 || (m[x - 1] != 0) != v);
+      s[threadIdx.x] = start ? x : -1;
+      __syncthreads();
+      for (int off = 1; off < NT; off <<= 1) {
+        const int t = (int)threadIdx.x >= off ? s[threadIdx.x - off] : -1;
+        __syncthreads();
+        if (t > s[threadIdx.x]) s[threadIdx.x] = t;
+        __syncthreads();
+      }
+      const int rs = s[threadIdx.x] >= 0 ? s[threadIdx.x] : carry;
+      if (valid) L[row * d.nx + x] = (fg_only && !v) ? (int)(row * d.nx + x) : (int)(row * d.nx + rs);
+      if (threadIdx.x == NT - 1) carry_s = rs;
+      __syncthreads();
+      carry = carry_s;
+      __syncthreads();
+    }
+  }
 }
 
-// fg_only: unite foreground voxels only (mask != 0); otherwise unite equal-valued neighbours.
+// Stage 2, across rows: two equal-valued runs in adjacent rows (y - 1 or z - 1) overlap somewhere, and the later
+// of their two starts lies inside the overlap -- one union there joins them, so only positions where either run
+// starts need to try.  That is a few unions per run instead of three per voxel, and finds are one or two hops.
 __global__ void __launch_bounds__(NT) k_cc_merge(const uint8_t* __restrict__ mask, int* __restrict__ L, pp_dims d, int fg_only) {
   const size_t n = (size_t)d.nx * d.ny * d.nz;
   const int sy = d.nx, sz = d.nx * d.ny;
@@ -57,9 +88,9 @@ __global__ void __launch_bounds__(NT) k_cc_merge(const uint8_t* __restrict__ mas
     const bool v = mask[i] != 0;
     if (fg_only && !v) continue;
     const int x = (int)(i % d.nx), y = (int)((i / d.nx) % d.ny), z = (int)(i / sz);
-    if (x > 0 && (mask[i - 1] != 0) == v) cc_unite(L, (int)i, (int)i - 1);
-    if (y > 0 && (mask[i - sy] != 0) == v) cc_unite(L, (int)i, (int)i - sy);
-    if (z > 0 && (mask[i - sz] != 0) == v) cc_unite(L, (int)i, (int)i - sz);
+    const bool start = x == 0 || (mask[i - 1] != 0) != v;
+    if (y > 0 && (mask[i - sy] != 0) == v && (start || (mask[i - sy - 1] != 0) != v)) cc_unite(L, (int)i, (int)i - sy);
+    if (z > 0 && (mask[i - sz] != 0) == v && (start || (mask[i - sz - 1] != 0) != v)) cc_unite(L, (int)i, (int)i - sz);
   }
 }
 
@@ -180,8 +211,9 @@ unsigned grid_for(size_t work, unsigned cap = 16384u) {
 
 int cc_label(pp_ctx* ctx, const uint8_t* mask, int* L, const pp_dims& d, size_t n, int fg_only) {
   const dim3 g(grid_for(n)), b(NT);
-  hipLaunchKernelGGL(k_cc_init, g, b, 0, ctx->stream, L, n);
-  PP_LAUNCH_CHECK(ctx, "k_cc_init");
+  const size_t rows = (size_t)d.ny * d.nz;
+  hipLaunchKernelGGL(k_cc_rows, dim3((unsigned)(rows < 65535 ? rows : 65535)), b, 0, ctx->stream, mask, L, d, fg_only);
+  PP_LAUNCH_CHECK(ctx, "k_cc_rows");
   hipLaunchKernelGGL(k_cc_merge, g, b, 0, ctx->stream, mask, L, d, fg_only);
   PP_LAUNCH_CHECK(ctx, "k_cc_merge");
   hipLaunchKernelGGL(k_cc_compress, g, b, 0, ctx->stream, L, n);
