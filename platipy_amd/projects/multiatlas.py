@@ -322,8 +322,9 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
     if ref_struct:
         from ..label.iar import run_iar
 
-        # every rank needs every atlas's propagated reference structure + weight: all_gather them slot by slot
-        # (slot k of rank r is atlas_id_list[r + k * world]); all ranks then run the same, deterministic selection.
+        # every rank needs every atlas's propagated reference structure (uint8 volume) and its global-vote weight --
+        # one number per atlas (fusion.py:154-161), so only that number travels: all_gather slot by slot (slot k of
+        # rank r is atlas_id_list[r + k * world]); all ranks then run the same, deterministic selection.
         slots = (len(atlas_id_list) + dd.world - 1) // dd.world
         full_set = {}
         for k in range(slots):
@@ -331,15 +332,16 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
             if have:
                 d = atlas_set[my_ids[k]]["DIR"]
                 m = (d[ref_struct].tensor != 0).to(torch.uint8).contiguous()
-                w = compute_weight_map(img_crop, d["CT Image"], vote_type="global").tensor.float().contiguous()
+                w = compute_weight_map(img_crop, d["CT Image"], vote_type="global").tensor.flatten()[:1].float().contiguous()
             else:
                 m = torch.zeros(img_crop.shape, dtype=torch.uint8, device=device)
-                w = torch.zeros(img_crop.shape, dtype=torch.float32, device=device)
+                w = torch.zeros(1, dtype=torch.float32, device=device)
             ms, ws = dd.all_gather(m), dd.all_gather(w)
             for r in range(dd.world):
                 idx = r + k * dd.world
                 if idx < len(atlas_id_list):
-                    full_set[atlas_id_list[idx]] = {"DIR": {"Weight Map": img_crop.like(ws[r]), ref_struct: img_crop.like(ms[r])}}
+                    weight = torch.zeros(img_crop.shape, dtype=torch.float32, device=device) + ws[r].to(device)
+                    full_set[atlas_id_list[idx]] = {"DIR": {"Weight Map": img_crop.like(weight), ref_struct: img_crop.like(ms[r])}}
         full_set = {i: full_set[i] for i in atlas_id_list}          # reference order
         kept = run_iar(atlas_set=full_set, reference_structure=ref_struct, **iar)
         removed = [i for i in atlas_id_list if i not in kept]
