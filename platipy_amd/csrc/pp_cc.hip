@@ -46,31 +46,52 @@ __device__ __forceinline__ void cc_unite(int* L, int a, int b) {
   }
 }
 
-// Stage 1, rows: every voxel points at the first voxel of its x-run of equal values (a max-scan of the run-start
-// positions through LDS, NT voxels at a time with a carry).  fg_only: background voxels keep their own index.
+// Stage 1, rows: every voxel points at the first voxel of its x-run of equal values.  A thread walks CC_E
+// consecutive voxels; the position of the last run start at or before each thread's span comes from a max-scan over
+// the threads' last starts through LDS (NT x CC_E voxels per pass, with a carry for longer rows).
+// fg_only: background voxels keep their own index.
+constexpr int CC_E = 8;
 __global__ void __launch_bounds__(NT) k_cc_rows(const uint8_t* __restrict__ mask, int* __restrict__ L, pp_dims d, int fg_only) {
   __shared__ int s[NT];
   __shared__ int carry_s;
   const size_t rows = (size_t)d.ny * d.nz;
+  const int span = NT * CC_E;
   for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
     const uint8_t* m = mask + row * d.nx;
     int carry = 0;
-    for (int x0 = 0; x0 < d.nx; x0 += NT) {
-      const int x = x0 + (int)threadIdx.x;
-      const bool valid = x < d.nx;
-      const bool v = valid && m[x] != 0;
-      const bool start = valid && (x == 0 || (m[x - 1] != 0) != v);
-      s[threadIdx.x] = start ? x : -1;
+    for (int x0 = 0; x0 < d.nx; x0 += span) {
+      const int left = d.nx - x0;
+      const int nact = left >= span ? NT : (left + CC_E - 1) / CC_E;   // threads with at least one voxel
+      const int xb = x0 + (int)threadIdx.x * CC_E;
+      bool v[CC_E];
+      int last = -1;                       // last run start inside my span
+      bool prev = xb > 0 && xb <= d.nx ? m[xb - 1] != 0 : false;
+      for (int e = 0; e < CC_E; ++e) {
+        const int x = xb + e;
+        v[e] = x < d.nx ? m[x] != 0 : false;
+        if (x < d.nx && (x == 0 || v[e] != prev)) last = x;
+        prev = v[e];
+      }
+      s[threadIdx.x] = last;
       __syncthreads();
-      for (int off = 1; off < NT; off <<= 1) {
+      for (int off = 1; off < nact; off <<= 1) {
         const int t = (int)threadIdx.x >= off ? s[threadIdx.x - off] : -1;
         __syncthreads();
         if (t > s[threadIdx.x]) s[threadIdx.x] = t;
         __syncthreads();
       }
-      const int rs = s[threadIdx.x] >= 0 ? s[threadIdx.x] : carry;
-      if (valid) L[row * d.nx + x] = (fg_only && !v) ? (int)(row * d.nx + x) : (int)(row * d.nx + rs);
-      if (threadIdx.x == NT - 1) carry_s = rs;
+      // run start in force when my span begins: the scan over the threads to my left, else the carry
+      int cur = threadIdx.x > 0 ? s[threadIdx.x - 1] : -1;
+      if (cur < 0) cur = carry;
+      prev = xb > 0 && xb <= d.nx ? m[xb - 1] != 0 : false;
+      for (int e = 0; e < CC_E; ++e) {
+        const int x = xb + e;
+        if (x >= d.nx) break;
+        if (x == 0 || v[e] != prev) cur = x;
+        prev = v[e];
+        L[row * d.nx + x] = (fg_only && !v[e]) ? (int)(row * d.nx + x) : (int)(row * d.nx + cur);
+      }
+      if ((int)threadIdx.x == nact - 1) carry_s = s[threadIdx.x] >= 0 ? s[threadIdx.x] : carry;
       __syncthreads();
       carry = carry_s;
       __syncthreads();
