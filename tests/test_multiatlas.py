@@ -130,6 +130,45 @@ def test_run_segmentation_two_ranks_gloo(tmp_path):
     assert dice(wh0, tmask) > 0.93
 
 
+def _exchange_worker(rank, world, port, out_dir):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world)})
+    import torch.distributed as dist
+
+    import platipy_amd as pa
+    from platipy_amd.projects import multiatlas
+    from tests.helpers import install_emu_runtime
+
+    install_emu_runtime()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ids, shape = ["a", "b", "c", "d", "e"], (5, 6, 7)           # 5 atlases on 2 ranks: the last slot is half empty
+        rng = np.random.default_rng(11)
+        target = pa.image_from_array(rng.normal(0, 50, shape).astype(np.float32), (1, 1, 2), (0, 0, 0))
+        everything = {i: {"DIR": {"CT Image": pa.image_from_array(rng.normal(0, 50, shape).astype(np.float32), (1, 1, 2), (0, 0, 0)),
+                                  "HEART": pa.image_from_array((rng.random(shape) > 0.5).astype(np.uint8), (1, 1, 2), (0, 0, 0))}}
+                      for i in ids}
+        my_ids = ids[rank::world]
+        full = multiatlas._iar_exchange(multiatlas._Dist(), {i: everything[i] for i in my_ids}, my_ids, ids, "HEART", target)
+        assert list(full) == ids
+        for i in ids:      # what came over the wire equals what the owner holds
+            np.testing.assert_array_equal(full[i]["DIR"]["HEART"].numpy(), everything[i]["DIR"]["HEART"].numpy())
+            w = pa.label.compute_weight_map(target, everything[i]["DIR"]["CT Image"], vote_type="global").numpy()
+            np.testing.assert_allclose(full[i]["DIR"]["Weight Map"].numpy(), w, rtol=1e-6)
+        np.save(os.path.join(out_dir, f"ok_{rank}.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_iar_exchange_two_ranks_gloo(tmp_path):
+    """The atlas-selection exchange at world_size 2 (gloo, CPU): every rank ends up with every atlas's reference
+    structure and global-vote weight, in the reference's atlas order, with an uneven atlas count."""
+    import torch.multiprocessing as mp
+
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_exchange_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok_0.npy").exists() and (tmp_path / "ok_1.npy").exists()
+
+
 def test_run_segmentation_with_iterative_atlas_removal(host_api):
     """Config 5's "iterative atlas selection": an atlas whose label is grossly wrong is dropped before fusion."""
     pa = host_api
