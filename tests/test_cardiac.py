@@ -154,3 +154,35 @@ def test_cardiac_refuses_out_of_scope_stages(monkeypatch):
     s["vessel_spline_settings"]["vessel_name_list"] = []
     with pytest.raises(NotImplementedError, match="geometric"):
         pa.projects.cardiac.run_cardiac_segmentation(img, settings=s)
+
+
+def test_cardiac_options_cropped_output_and_postprocessing(monkeypatch, tmp_path):
+    """return_as_cropped (cardiac/run.py:942-960, 1143-1144), crop_atlas_to_structures (:570-592) and the
+    post-processing stage (:1113-1141: largest component, ball closing, overlap correction) on the half-size data."""
+    import platipy_amd as pa
+    from tests.helpers import install_emu_runtime
+
+    install_emu_runtime(lambda obj, name, value: monkeypatch.setattr(obj, name, value, raising=False))
+    data = cardiac_data(pa, 2)
+    cases = list(data.keys())
+    structures = ["WHOLEHEART", "SUBSTRUCTURE"]
+    _write_atlases(data, tmp_path, structures)
+    s = _reference_test_settings(pa, cases[:3] + [cases[-1]], tmp_path, structures, False)     # two atlases are enough here
+    s["atlas_settings"]["crop_atlas_to_structures"] = True
+    s["atlas_settings"]["crop_atlas_expansion_mm"] = (10, 10, 15)
+    s["return_as_cropped"] = True
+    s["postprocessing_settings"].update({"run_postprocessing": True, "structures_for_binaryfillhole": ["WHOLEHEART", "NOT_THERE"],
+                                         "structures_for_overlap_correction": ["WHOLEHEART", "SUBSTRUCTURE"]})
+    infer = cases[-1]
+    output, prob = pa.projects.cardiac.run_cardiac_segmentation(data[infer]["CT"], settings=s)
+    crop = output["CROP_IMAGE"]
+    assert crop.GetSize() != data[infer]["CT"].GetSize()                        # the target was cropped ...
+    assert output["WHOLEHEART"].GetSize() == crop.GetSize() == prob["WHOLEHEART"].GetSize()   # ... and so are the results
+    # cropped results sit where the crop sits: compare with the ground truth cut out at the same place
+    off = np.round((np.array(crop.GetOrigin()) - np.array(ORIGIN)) / np.array(crop.GetSpacing())).astype(int)
+    sz = crop.GetSize()
+    gt = data[infer]["WHOLEHEART"].numpy()[off[2]:off[2] + sz[2], off[1]:off[1] + sz[1], off[0]:off[0] + sz[0]]
+    assert dice(output["WHOLEHEART"].numpy(), gt) > 0.9
+    # overlap correction made the two structures disjoint; the larger (whole heart) kept the shared voxels
+    wh, ss = output["WHOLEHEART"].numpy() > 0, output["SUBSTRUCTURE"].numpy() > 0
+    assert not (wh & ss).any() and wh.sum() > 0
