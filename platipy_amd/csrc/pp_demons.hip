@@ -177,12 +177,17 @@ unsigned grid_for(size_t work, unsigned cap = 65535u * 4u) {
 // any moment are x/y neighbours.  Their 2-voxel halos -- whose 272-B rows straddle four 128-B lines
 // instead of two -- then hit that XCD's L2 instead of being fetched once per XCD from the fabric.
 
-constexpr int TX = 64;
-constexpr int TY = 16;
+// Two tile shapes of 1024 outputs each: 64 x 16 (rows of two cache lines; the default) and 32 x 32 (smaller
+// halo, finer tiling of grids that 64-wide tiles overhang or whose tile count leaves block slots idle).
+constexpr int TILE_OUT = 1024;
+template <int SH> struct tile_shape;
+template <> struct tile_shape<0> { static constexpr int TX = 64, TY = 16; };
+template <> struct tile_shape<1> { static constexpr int TX = 32, TY = 32; };
 // OPT = outputs per thread along x (4: 256 threads, float4 rows; 2: 512 threads, float2 rows -- half the
 // registers per thread, twice the waves per CU for the same LDS tile).
-template <int R, int OPT>
+template <int R, int OPT, int SH>
 struct fused_geom {
+  static constexpr int TX = tile_shape<SH>::TX, TY = tile_shape<SH>::TY;
   static constexpr int NTH = TX * TY / OPT;       // threads per block
   static constexpr int LX = TX / OPT;             // threads along x
   static constexpr int UW = TX + 2 * R;           // smoothing-input tile width  (x from tx0 - R)
@@ -208,10 +213,11 @@ struct fused_geom {
 };
 
 // x pass: item (row uy, group cx) reads 4 + 2R inputs of `us` and writes 4 outputs to `xs`.
-template <int R, int OPT>
+template <int R, int OPT, int SH>
 __device__ __forceinline__ void fused_xpass(const float* __restrict__ us /*[3][UH][UWP]*/,
                                             float* __restrict__ xs /*[3][UH][TX]*/, const pp_taps_small& wx) {
-  using G = fused_geom<R, OPT>;
+  using G = fused_geom<R, OPT, SH>;
+  constexpr int TX = G::TX;
   for (int it = threadIdx.x; it < 3 * G::XI; it += G::NTH) {
     const int c = it / G::XI;
     const int rem = it - c * G::XI;
@@ -242,10 +248,11 @@ __device__ __forceinline__ void fused_xpass(const float* __restrict__ us /*[3][U
 }
 
 // y pass for this thread's OPT outputs of component c.
-template <int R, int OPT>
+template <int R, int OPT, int SH>
 __device__ __forceinline__ void fused_ypass(const float* __restrict__ xs, int c, int cx, int cy, const pp_taps_small& wy,
                                             float v[OPT]) {
-  using G = fused_geom<R, OPT>;
+  using G = fused_geom<R, OPT, SH>;
+  constexpr int TX = G::TX;
 #pragma unroll
   for (int j = 0; j < OPT; ++j) v[j] = 0.0f;
 #pragma unroll
@@ -297,7 +304,7 @@ struct fused_args {
 };
 
 // Tile of this block (see the grid note above); false for the few surplus blocks of the last XCD run.
-__device__ __forceinline__ bool fused_tile(const fused_args& a, int& tx0, int& ty0, int& z0, unsigned& rank) {
+__device__ __forceinline__ bool fused_tile(const fused_args& a, int TX, int TY, int& tx0, int& ty0, int& z0, unsigned& rank) {
   const unsigned b = blockIdx.x;
   const unsigned j = b >> 3;
   rank = (b & 7u) * (unsigned)a.per_xcd + j;
@@ -329,12 +336,12 @@ constexpr unsigned F_CNT = 1u, F_XLO = 2u, F_XHI = 4u, F_YLO = 8u, F_YHI = 16u, 
 #ifndef PP_B_WAVES
 #define PP_B_WAVES 1
 #endif
-template <int R, int OPT>
-__global__ void __launch_bounds__(TX * TY / OPT, PP_A_WAVES) k_fused_force_smooth(const float* __restrict__ F, const float* __restrict__ Mw,
+template <int R, int OPT, int SH>
+__global__ void __launch_bounds__(TILE_OUT / OPT, PP_A_WAVES) k_fused_force_smooth(const float* __restrict__ F, const float* __restrict__ Mw,
                                                            float* __restrict__ Us, fused_args a, pp_esm_consts K,
                                                            double* __restrict__ partials, const int* __restrict__ halt) {
-  using G = fused_geom<R, OPT>;
-  constexpr int NTH = G::NTH;
+  using G = fused_geom<R, OPT, SH>;
+  constexpr int NTH = G::NTH, TX = G::TX, TY = G::TY;
   __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
   float* const s_m = smem;                      // warped moving, current plane   (force phase)
   float* const s_f = smem + G::MH * G::MWP;     // fixed, current plane           (force phase)
@@ -343,7 +350,7 @@ __global__ void __launch_bounds__(TX * TY / OPT, PP_A_WAVES) k_fused_force_smoot
   if (halt && *halt) return;
   int tx0, ty0, z0;
   unsigned rank;
-  if (!fused_tile(a, tx0, ty0, z0, rank)) return;
+  if (!fused_tile(a, TX, TY, tx0, ty0, z0, rank)) return;
 
   const pp_dims d = a.d;
   const int t = threadIdx.x;
@@ -473,10 +480,10 @@ __global__ void __launch_bounds__(TX * TY / OPT, PP_A_WAVES) k_fused_force_smoot
       }
       __syncthreads();  // s_u complete; region 1 (image tiles) is dead from here
       // (3) x pass, (4) y pass
-      fused_xpass<R, OPT>(s_u, s_x, a.wx);
+      fused_xpass<R, OPT, SH>(s_u, s_x, a.wx);
       __syncthreads();
 #pragma unroll
-      for (int c = 0; c < 3; ++c) fused_ypass<R, OPT>(s_x, c, cx, cy, a.wy, v[c]);
+      for (int c = 0; c < 3; ++c) fused_ypass<R, OPT, SH>(s_x, c, cx, cy, a.wy, v[c]);
       // rotate the z window of the image values
 #pragma unroll
       for (int k = 0; k < G::KU; ++k) {
@@ -522,20 +529,20 @@ __global__ void __launch_bounds__(TX * TY / OPT, PP_A_WAVES) k_fused_force_smoot
 }
 
 // ---- kernel B: D' = G_d * (D + U), then the next iteration's warped moving image ------
-template <int R, int OPT>
-__global__ void __launch_bounds__(TX * TY / OPT, PP_B_WAVES) k_fused_add_smooth_warp(const float* __restrict__ D, const float* __restrict__ Us,
+template <int R, int OPT, int SH>
+__global__ void __launch_bounds__(TILE_OUT / OPT, PP_B_WAVES) k_fused_add_smooth_warp(const float* __restrict__ D, const float* __restrict__ Us,
                                                               const float* __restrict__ M, float* __restrict__ Dn,
                                                               float* __restrict__ Mw, fused_args a, pp_warp_scale sc,
                                                               const int* __restrict__ halt) {
-  using G = fused_geom<R, OPT>;
-  constexpr int NTH = G::NTH;
+  using G = fused_geom<R, OPT, SH>;
+  constexpr int NTH = G::NTH, TX = G::TX, TY = G::TY;
   __shared__ __attribute__((aligned(16))) float smem[G::SZ_X + G::SZ_U];
   float* const s_x = smem;
   float* const s_u = smem + G::SZ_X;
   if (halt && *halt) return;
   int tx0, ty0, z0;
   unsigned rank;
-  if (!fused_tile(a, tx0, ty0, z0, rank)) return;
+  if (!fused_tile(a, TX, TY, tx0, ty0, z0, rank)) return;
 
   const pp_dims d = a.d;
   const int t = threadIdx.x;
@@ -598,10 +605,10 @@ __global__ void __launch_bounds__(TX * TY / OPT, PP_B_WAVES) k_fused_add_smooth_
           }
       }
       __syncthreads();
-      fused_xpass<R, OPT>(s_u, s_x, a.wx);
+      fused_xpass<R, OPT, SH>(s_u, s_x, a.wx);
       __syncthreads();
 #pragma unroll
-      for (int c = 0; c < 3; ++c) fused_ypass<R, OPT>(s_x, c, cx, cy, a.wy, v[c]);
+      for (int c = 0; c < 3; ++c) fused_ypass<R, OPT, SH>(s_x, c, cx, cy, a.wy, v[c]);
       zc_done = zc;
     }
     ring.push(v);
@@ -680,10 +687,13 @@ void small_taps(const pp_taps& t, int R, pp_taps_small* s) {
 
 // z-chunk length: long chunks amortise the 2R (+3 image) halo planes, but the launch should fill the
 // chip a whole number of times.  `slots` = resident blocks of the slower kernel (256 CUs x blocks/CU).
-int fused_zchunk(const pp_dims& d, int slots) {
+int fused_zchunk(const pp_dims& d, int slots, int TX, int TY, double* cost_out = nullptr) {
   if (const char* e = getenv("PP_FUSED_ZCHUNK")) {
     const int v = atoi(e);
-    if (v >= 1) return v < d.nz ? v : d.nz;
+    if (v >= 1) {
+      if (cost_out) *cost_out = 0.0;
+      return v < d.nz ? v : d.nz;
+    }
   }
   const int tiles = ((d.nx + TX - 1) / TX) * ((d.ny + TY - 1) / TY);
   // Small grids (the coarse pyramid levels) cannot fill the chip either way and are bound by the latency of one
@@ -702,22 +712,39 @@ int fused_zchunk(const pp_dims& d, int slots) {
       best = zc;
     }
   }
+  if (cost_out) *cost_out = best_cost;
   return best;
+}
+
+// Tile shape for a grid.  64 x 16 is ~4 % faster per voxel (rows of two whole cache lines), so it stays unless
+// 32 x 32 needs clearly (>= 10 %) fewer plane-steps by the z-chunk model above -- grids whose 64 x 16 launch leaves
+// block slots idle (341 x 341 x 171: 396 blocks on 512 slots, 11 % faster with 32 x 32) -- or, on a model tie,
+// clearly fewer tiles (less overhang: 85 x 85 -> 9 tiles instead of 12, 18 % faster).
+int fused_shape(const pp_dims& d, int slots0, int slots1) {
+  if (const char* e = getenv("PP_FUSED_TILE")) return atoi(e) == 1 ? 1 : 0;
+  double c0 = 0.0, c1 = 0.0;
+  fused_zchunk(d, slots0, tile_shape<0>::TX, tile_shape<0>::TY, &c0);
+  fused_zchunk(d, slots1, tile_shape<1>::TX, tile_shape<1>::TY, &c1);
+  if (c1 < 0.9 * c0) return 1;
+  if (c0 < 0.9 * c1) return 0;
+  const long t0 = (long)((d.nx + tile_shape<0>::TX - 1) / tile_shape<0>::TX) * ((d.ny + tile_shape<0>::TY - 1) / tile_shape<0>::TY);
+  const long t1 = (long)((d.nx + tile_shape<1>::TX - 1) / tile_shape<1>::TX) * ((d.ny + tile_shape<1>::TY - 1) / tile_shape<1>::TY);
+  return 10 * t1 < 9 * t0 ? 1 : 0;
 }
 
 // Per-kernel dispatch on (radius, outputs per thread).  The two kernels are independent: the update is smoothed
 // with sigma_u (radius RA) and the field with sigma_d (radius RB), so each runs the narrowest template that fits.
-template <int R, int OPT>
+template <int R, int OPT, int SH>
 int occ_force() {
   int a = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fused_force_smooth<R, OPT>, TX * TY / OPT, 0) != hipSuccess) a = 2;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fused_force_smooth<R, OPT, SH>, TILE_OUT / OPT, 0) != hipSuccess) a = 2;
   (void)hipGetLastError();
   return a < 1 ? 1 : a;
 }
-template <int R, int OPT>
+template <int R, int OPT, int SH>
 int occ_warp() {
   int a = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fused_add_smooth_warp<R, OPT>, TX * TY / OPT, 0) != hipSuccess) a = 2;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fused_add_smooth_warp<R, OPT, SH>, TILE_OUT / OPT, 0) != hipSuccess) a = 2;
   (void)hipGetLastError();
   return a < 1 ? 1 : a;
 }
@@ -726,26 +753,57 @@ int occ_warp() {
   ((OPT) == 4 ? ((R) == 1 ? CALL(1, 4) : ((R) == 2 ? CALL(2, 4) : CALL(3, 4)))                       \
               : ((R) == 1 ? CALL(1, 2) : ((R) == 2 ? CALL(2, 2) : ((R) == 3 ? CALL(3, 2) : ((R) == 4 ? CALL(4, 2) : CALL(5, 2))))))
 
+// The 32 x 32 shape exists for the 512-thread layout only (OPT = 2).
 template <int R, int OPT>
-int launch_force(pp_ctx* ctx, const float* F, const float* Mw_in, float* Us, const fused_args& fu, const pp_esm_consts& K,
+int occ_force_sh(int sh) {
+  if constexpr (OPT == 2) {
+    if (sh == 1) return occ_force<R, 2, 1>();
+  }
+  return occ_force<R, OPT, 0>();
+}
+template <int R, int OPT>
+int occ_warp_sh(int sh) {
+  if constexpr (OPT == 2) {
+    if (sh == 1) return occ_warp<R, 2, 1>();
+  }
+  return occ_warp<R, OPT, 0>();
+}
+
+template <int R, int OPT>
+int launch_force(pp_ctx* ctx, int sh, const float* F, const float* Mw_in, float* Us, const fused_args& fu, const pp_esm_consts& K,
                  double* partials, const int* halt) {
   pp_prof_scope ps(ctx, "k_fused_force_smooth");
-  hipLaunchKernelGGL((k_fused_force_smooth<R, OPT>), dim3(8u * (unsigned)fu.per_xcd), dim3(TX * TY / OPT), 0, ctx->stream, F, Mw_in, Us,
+  if constexpr (OPT == 2) {
+    if (sh == 1) {
+      hipLaunchKernelGGL((k_fused_force_smooth<R, 2, 1>), dim3(8u * (unsigned)fu.per_xcd), dim3(TILE_OUT / 2), 0, ctx->stream, F, Mw_in, Us,
+                         fu, K, partials, halt);
+      return PP_OK;
+    }
+  }
+  hipLaunchKernelGGL((k_fused_force_smooth<R, OPT, 0>), dim3(8u * (unsigned)fu.per_xcd), dim3(TILE_OUT / OPT), 0, ctx->stream, F, Mw_in, Us,
                      fu, K, partials, halt);
   return PP_OK;
 }
 template <int R, int OPT>
-int launch_warp(pp_ctx* ctx, const float* D, const float* Us, const float* M, float* Dn, float* Mw_out, const fused_args& fd,
+int launch_warp(pp_ctx* ctx, int sh, const float* D, const float* Us, const float* M, float* Dn, float* Mw_out, const fused_args& fd,
                 const pp_warp_scale& sc, const int* halt) {
   pp_prof_scope ps(ctx, "k_fused_add_smooth_warp");
-  hipLaunchKernelGGL((k_fused_add_smooth_warp<R, OPT>), dim3(8u * (unsigned)fd.per_xcd), dim3(TX * TY / OPT), 0, ctx->stream, D, Us, M,
+  if constexpr (OPT == 2) {
+    if (sh == 1) {
+      hipLaunchKernelGGL((k_fused_add_smooth_warp<R, 2, 1>), dim3(8u * (unsigned)fd.per_xcd), dim3(TILE_OUT / 2), 0, ctx->stream, D, Us, M,
+                         Dn, Mw_out, fd, sc, halt);
+      return PP_OK;
+    }
+  }
+  hipLaunchKernelGGL((k_fused_add_smooth_warp<R, OPT, 0>), dim3(8u * (unsigned)fd.per_xcd), dim3(TILE_OUT / OPT), 0, ctx->stream, D, Us, M,
                      Dn, Mw_out, fd, sc, halt);
   return PP_OK;
 }
 
-void fused_grid(fused_args* f, const pp_dims& d, int occupancy) {
+void fused_grid(fused_args* f, const pp_dims& d, int occupancy, int sh) {
+  const int TX = sh ? tile_shape<1>::TX : tile_shape<0>::TX, TY = sh ? tile_shape<1>::TY : tile_shape<0>::TY;
   f->d = d;
-  f->zchunk = fused_zchunk(d, 256 * occupancy);
+  f->zchunk = fused_zchunk(d, 256 * occupancy, TX, TY);
   f->gx = (d.nx + TX - 1) / TX;
   f->gy = (d.ny + TY - 1) / TY;
   f->gz = (d.nz + f->zchunk - 1) / f->zchunk;
@@ -898,12 +956,21 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   if (const char* e = getenv("PP_FUSED_OPT")) opt = atoi(e) == 2 ? 2 : 4;
   const int opt_a = ra > 3 ? 2 : opt, opt_b = rb > 3 ? 2 : opt;   // radii 4 and 5 exist in the 512-thread layout only
   fused_args fu, fd;
-#define PP_OCC_A(RR, OO) occ_force<RR, OO>()
-#define PP_OCC_B(RR, OO) occ_warp<RR, OO>()
-  fused_grid(&fu, d, PP_BY_RADIUS(ra, opt_a, PP_OCC_A));
-  fused_grid(&fd, d, PP_BY_RADIUS(rb, opt_b, PP_OCC_B));
-#undef PP_OCC_A
-#undef PP_OCC_B
+  // tile shape per kernel: 32 x 32 where the z-chunk model says the 64 x 16 launch wastes >= 10 % (OPT = 2 only)
+#define PP_OCC_A0(RR, OO) occ_force_sh<RR, OO>(0)
+#define PP_OCC_A1(RR, OO) occ_force_sh<RR, OO>(1)
+#define PP_OCC_B0(RR, OO) occ_warp_sh<RR, OO>(0)
+#define PP_OCC_B1(RR, OO) occ_warp_sh<RR, OO>(1)
+  const int occ_a0 = PP_BY_RADIUS(ra, opt_a, PP_OCC_A0), occ_b0 = PP_BY_RADIUS(rb, opt_b, PP_OCC_B0);
+  const int occ_a1 = opt_a == 2 ? PP_BY_RADIUS(ra, opt_a, PP_OCC_A1) : occ_a0, occ_b1 = opt_b == 2 ? PP_BY_RADIUS(rb, opt_b, PP_OCC_B1) : occ_b0;
+#undef PP_OCC_A0
+#undef PP_OCC_A1
+#undef PP_OCC_B0
+#undef PP_OCC_B1
+  const int sh_a = opt_a == 2 ? fused_shape(d, 256 * occ_a0, 256 * occ_a1) : 0;
+  const int sh_b = opt_b == 2 ? fused_shape(d, 256 * occ_b0, 256 * occ_b1) : 0;
+  fused_grid(&fu, d, sh_a ? occ_a1 : occ_a0, sh_a);
+  fused_grid(&fd, d, sh_b ? occ_b1 : occ_b0, sh_b);
   small_taps(tu[0], ra, &fu.wx);
   small_taps(tu[1], ra, &fu.wy);
   small_taps(tu[2], ra, &fu.wz);
@@ -930,8 +997,8 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     float* mw_out = (it & 1) ? MwB : MwA;
     const float* Dcur = (it & 1) ? D2 : field;
     float* Dnext = (it & 1) ? field : D2;
-#define PP_CALL_A(RR, OO) launch_force<RR, OO>(ctx, fixed, mw_in, Us, fu, K, partials, halt)
-#define PP_CALL_B(RR, OO) launch_warp<RR, OO>(ctx, Dcur, (const float*)Us, moving, Dnext, mw_out, fd, sc, halt)
+#define PP_CALL_A(RR, OO) launch_force<RR, OO>(ctx, sh_a, fixed, mw_in, Us, fu, K, partials, halt)
+#define PP_CALL_B(RR, OO) launch_warp<RR, OO>(ctx, sh_b, Dcur, (const float*)Us, moving, Dnext, mw_out, fd, sc, halt)
     rc = PP_BY_RADIUS(ra, opt_a, PP_CALL_A);
     PP_LAUNCH_CHECK(ctx, "k_fused_force_smooth");
     rc = PP_BY_RADIUS(rb, opt_b, PP_CALL_B);

@@ -273,6 +273,27 @@ def test_demons_execute(backend, grid, variant):
     assert np.abs(want).max() > 0.2  # the registration did something
 
 
+@pytest.mark.parametrize("grid", GRIDS + [HIRES])
+def test_fused_demons_tile_shapes_agree(backend, grid, monkeypatch):
+    """The 32 x 32 tile variant of the fused kernels (chosen for grids that 64 x 16 tiles fit badly) computes every
+    output voxel with the same operations in the same order: bit-identical fields, equal statistics."""
+    shape, spacing, origin = grid
+    fix = phantom(shape, seed=40)
+    dv = random_dvf(shape, spacing, seed=41, max_mm=2.5)
+    mov = O.warp_image(O.Vol(fix, spacing, origin), dv.astype(np.float64), edge_value=-1000.0).arr.astype(np.float32)
+    p = _demons_params(backend.ctx, 3, spacing, _lib.DEMONS_FUSED, max_rms=0.0)
+    out = {}
+    for tile in ("0", "1"):
+        monkeypatch.setenv("PP_FUSED_TILE", tile)
+        f = backend.empty((3,) + shape)
+        st = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, f)
+        out[tile] = (backend.host(f).copy(), st.metric, st.rms_change, st.elapsed_iterations)
+    np.testing.assert_array_equal(out["0"][0], out["1"][0])
+    np.testing.assert_allclose(out["0"][1:3], out["1"][1:3], rtol=1e-6)
+    assert out["0"][3] == out["1"][3] == 3
+    assert np.abs(out["0"][0]).max() > 0.1
+
+
 @pytest.mark.parametrize("zchunk", [1, 2, 3, 5, 100])
 def test_fused_demons_is_independent_of_the_z_chunking(backend, zchunk, monkeypatch):
     """The fused schedule splits z into chunks (halo planes recomputed at the seams); any chunk length, shorter
