@@ -300,6 +300,42 @@ struct mval_args {
   int stride;
 };
 
+// pp_trilinear with the two x-neighbours of each corner row fetched as ONE 8-byte access when they are adjacent
+// in memory (they are, except on the clamped high edge): the probe kernel's lanes sit a full cache-line sector apart,
+// so every access is its own L2 request and halving their number is what counts.  Same lerps, same order.
+__device__ __forceinline__ float msq_trilinear_pairs(const float* __restrict__ im, int nx, int ny, int nz, int bx, float fx, int by,
+                                                     float fy, int bz, float fz) {
+  int x0, x1, y0, y1, z0, z1;
+  float wx, wy, wz;
+  pp_axis_setup(bx, fx, nx, x0, x1, wx);
+  pp_axis_setup(by, fy, ny, y0, y1, wy);
+  pp_axis_setup(bz, fz, nz, z0, z1, wz);
+  const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+  const float* p00 = im + z0 * sz + y0 * sy + x0;
+  const float* p10 = im + z0 * sz + y1 * sy + x0;
+  const float* p01 = im + z1 * sz + y0 * sy + x0;
+  const float* p11 = im + z1 * sz + y1 * sy + x0;
+  float a000, a100, a010, a110, a001, a101, a011, a111;
+  if (x1 == x0 + 1) {
+    a000 = p00[0]; a100 = p00[1];
+    a010 = p10[0]; a110 = p10[1];
+    a001 = p01[0]; a101 = p01[1];
+    a011 = p11[0]; a111 = p11[1];
+  } else {
+    a000 = a100 = p00[0];
+    a010 = a110 = p10[0];
+    a001 = a101 = p01[0];
+    a011 = a111 = p11[0];
+  }
+  const float v00 = a000 + (a100 - a000) * wx;
+  const float v10 = a010 + (a110 - a010) * wx;
+  const float v01 = a001 + (a101 - a001) * wx;
+  const float v11 = a011 + (a111 - a011) * wx;
+  const float v0 = v00 + (v10 - v00) * wy;
+  const float v1 = v01 + (v11 - v01) * wy;
+  return v0 + (v1 - v0) * wz;
+}
+
 // MODE 0: [sum (f-m)^2, count].  MODE 1: [count, sum f, sum m, sum f^2, sum m^2, sum f m].
 // One thread walks its samples and, per sample, ALL candidates of its chunk (CH per blockIdx.y): the lattice is
 // sparse in the full-resolution images (every gather is its own cache line, so an evaluation is HBM traffic, not
@@ -333,7 +369,7 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
       const int qx = (int)floor(cf[0] + 0.5), qy = (int)floor(cf[1] + 0.5), qz = (int)floor(cf[2] + 0.5);
       if (!fmask[((size_t)qz * df.ny + qy) * df.nx + qx]) continue;
     }
-    const double fd = pp_trilinear(F, df.nx, df.ny, df.nz, bf_[0], ff[0], bf_[1], ff[1], bf_[2], ff[2]);
+    const double fd = msq_trilinear_pairs(F, df.nx, df.ny, df.nz, bf_[0], ff[0], bf_[1], ff[1], bf_[2], ff[2]);
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       double cm[3];
@@ -347,7 +383,7 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
         ok = mmask[((size_t)qz * dm.ny + qy) * dm.nx + qx] != 0;
       }
       if (ok) {
-        const double md = pp_trilinear(M, dm.nx, dm.ny, dm.nz, bm_[0], fm[0], bm_[1], fm[1], bm_[2], fm[2]);
+        const double md = msq_trilinear_pairs(M, dm.nx, dm.ny, dm.nz, bm_[0], fm[0], bm_[1], fm[1], bm_[2], fm[2]);
         if (MODE == 0) {
           const double diff = fd - md;
           acc[j * NV + 0] += diff * diff;
