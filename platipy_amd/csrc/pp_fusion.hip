@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
                                                       unsigned* __restrict__ ticket, double* __restrict__ result /* [cand][6] */) {
   constexpr int NV = MODE == 0 ? 2 : 6;
   constexpr int ROW = CH * NV;
-  __shared__ double red[3 * NT];
+  __shared__ double red[CH * (MODE == 0 ? 2 : 6) * NT];   // 64 KB / 48 KB: every accumulator of every thread
   __shared__ int is_last;
   const int c0 = blockIdx.y * CH;
   const int nc = ncand - c0 < CH ? ncand - c0 : CH;
@@ -399,21 +399,25 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
       }
     }
   }
+  // one wide tree for all ROW accumulators (8 barrier rounds instead of 8 per triple): red[f][thread]
   double* mine = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ROW;
 #pragma unroll
-  for (int k = 0; k < ROW; k += 3) {
-    double p = acc[k], q = k + 1 < ROW ? acc[k + 1] : 0.0, r = k + 2 < ROW ? acc[k + 2] : 0.0;
-    pp_block_sum3<NT>(p, q, r, red);
-    if (threadIdx.x == 0) {
-      mine[k] = p;
-      if (k + 1 < ROW) mine[k + 1] = q;
-      if (k + 2 < ROW) mine[k + 2] = r;
+  for (int k = 0; k < ROW; ++k) red[k * NT + threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int st = NT / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+#pragma unroll
+      for (int k = 0; k < ROW; ++k) red[k * NT + threadIdx.x] += red[k * NT + threadIdx.x + st];
     }
     __syncthreads();
   }
+  if ((int)threadIdx.x < ROW) {
+    mine[threadIdx.x] = red[threadIdx.x * NT];
+    __threadfence();   // each writer publishes its own store before the block takes its ticket
+  }
+  __syncthreads();
   // the last block of this chunk to arrive folds the chunk's rows (fixed tree, independent of arrival order)
   if (threadIdx.x == 0) {
-    __threadfence();
     const unsigned t = atomicAdd(ticket + blockIdx.y, 1u);
     is_last = t == gridDim.x - 1u;
   }
