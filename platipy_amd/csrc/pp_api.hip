@@ -1,5 +1,8 @@
 // platipy_amd/csrc/pp_api.hip -- context management and host-side helpers of the C ABI
 // (include/platipy_amd.h).
+#include <atomic>
+#include <chrono>
+
 #include "pp_internal.h"
 
 #include <cstdlib>
@@ -103,6 +106,42 @@ int pp_read_back(pp_ctx* ctx, const void* dev, void* host, size_t bytes) {
   return PP_OK;
 }
 
+int pp_mailbox(pp_ctx* ctx, char** payload, unsigned long long** flags, unsigned long long* seq) {
+  if (!ctx->mailbox) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 4096, 0) != hipSuccess || !p) {
+      (void)hipGetLastError();
+      return pp_fail(ctx, PP_ERR_ALLOC, "mailbox allocation failed");
+    }
+    memset(p, 0, 4096);
+    ctx->mailbox = static_cast<char*>(p);
+    ctx->mail_seq = 0;
+  }
+  *payload = ctx->mailbox;
+  *flags = reinterpret_cast<unsigned long long*>(ctx->mailbox + PP_MAIL_FLAGS_OFF);
+  *seq = ++ctx->mail_seq;
+  return PP_OK;
+}
+
+int pp_mail_wait(pp_ctx* ctx, int nflags, unsigned long long seq) {
+  volatile unsigned long long* flags = reinterpret_cast<volatile unsigned long long*>(ctx->mailbox + PP_MAIL_FLAGS_OFF);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    bool all = true;
+    for (int k = 0; k < nflags; ++k) all = all && flags[k] == seq;
+    if (all) break;
+    if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+      // not there yet: wait for the stream the ordinary way (also surfaces a failed launch), then look once more
+      PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      for (int k = 0; k < nflags; ++k)
+        if (flags[k] != seq) return pp_fail(ctx, PP_ERR_HIP, "kernel finished without posting its result");
+      break;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return PP_OK;
+}
+
 int pp_ticket(pp_ctx* ctx, unsigned** out) {
   if (!ctx->ticket) {
     void* p = nullptr;
@@ -142,6 +181,7 @@ void pp_destroy(pp_ctx* ctx) {
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->ticket) (void)hipFree(ctx->ticket);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   if (ctx->prof) {
     for (auto& s : ctx->prof->spans) {
       (void)hipEventDestroy(s.a);

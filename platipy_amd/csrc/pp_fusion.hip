@@ -345,7 +345,9 @@ template <int MODE, int CH>
 __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ F, pp_dims df, const float* __restrict__ M, pp_dims dm,
                                                       const uint8_t* __restrict__ fmask, const uint8_t* __restrict__ mmask, mval_args a,
                                                       int ncand, double* partials /* [chunk][grid.x][CH*NV] */,
-                                                      unsigned* __restrict__ ticket, double* __restrict__ result /* [cand][6] */) {
+                                                      unsigned* __restrict__ ticket, double* result /* host mailbox: [cand][6] */,
+                                                      unsigned long long* flags /* host mailbox: one per chunk */,
+                                                      unsigned long long seq) {
   constexpr int NV = MODE == 0 ? 2 : 6;
   constexpr int ROW = CH * NV;
   __shared__ double red[CH * (MODE == 0 ? 2 : 6) * NT];   // 64 KB / 48 KB: every accumulator of every thread
@@ -439,7 +441,11 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) ticket[blockIdx.y] = 0u;
+  if (threadIdx.x == 0) {
+    ticket[blockIdx.y] = 0u;
+    __threadfence_system();   // the results above reach host memory before the flag that announces them
+    flags[blockIdx.y] = seq;
+  }
 }
 
 }  // namespace
@@ -597,26 +603,40 @@ int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, con
   a.stride = stride;
   const size_t nsamp = ((size_t)vsize[0] * vsize[1] * vsize[2] + stride - 1) / stride;
   const pp_dims df{fsize[0], fsize[1], fsize[2]}, dm{msize[0], msize[1], msize[2]};
-  constexpr int CH0 = 16, CH1 = 4;   // candidates per thread: 32 / 24 fp64 accumulators
-  const int ch = metric == 0 ? CH0 : CH1, nv = metric == 0 ? 2 : 6;
+  // Candidates per thread: 16 on big lattices (HBM/L2-bound: the candidates of a sample share cache lines), 4 on small
+  // ones (latency-bound: a thread's candidates are a serial chain of dependent gathers, so spread them over blocks).
+  constexpr int CH0 = 16, CH0S = 4, CH1 = 4;
+  const bool small = metric == 0 && nsamp < 150000;
+  const int ch = metric == 0 ? (small ? CH0S : CH0) : CH1, nv = metric == 0 ? 2 : 6;
   const int nchunk = (ncand + ch - 1) / ch;
   const unsigned nb = grid_for(nsamp, 1024u);
   const size_t row = (size_t)ch * nv;
-  int rc = pp_reserve(ctx, pp_align_up(((size_t)nb * nchunk * row + (size_t)PP_MAX_CAND * 6) * sizeof(double), 256));
+  int rc = pp_reserve(ctx, pp_align_up((size_t)nb * nchunk * row * sizeof(double), 256));
   if (rc) return rc;
   unsigned* ticket = nullptr;
   rc = pp_ticket(ctx, &ticket);
   if (rc) return rc;
   double* partials = reinterpret_cast<double*>(ctx->ws);
-  double* dres = partials + (size_t)nb * nchunk * row;
-  if (metric == 0)
+  char* mail = nullptr;
+  unsigned long long* flags = nullptr;
+  unsigned long long seq = 0;
+  rc = pp_mailbox(ctx, &mail, &flags, &seq);
+  if (rc) return rc;
+  double* hres = reinterpret_cast<double*>(mail);      // 16 x 6 doubles = 768 B of the payload area
+  if (metric == 0 && small)
+    hipLaunchKernelGGL((k_metric_values<0, CH0S>), dim3(nb, nchunk), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask,
+                       moving_mask, a, ncand, partials, ticket, hres, flags, seq);
+  else if (metric == 0)
     hipLaunchKernelGGL((k_metric_values<0, CH0>), dim3(nb, nchunk), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask,
-                       moving_mask, a, ncand, partials, ticket, dres);
+                       moving_mask, a, ncand, partials, ticket, hres, flags, seq);
   else
     hipLaunchKernelGGL((k_metric_values<1, CH1>), dim3(nb, nchunk), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask,
-                       moving_mask, a, ncand, partials, ticket, dres);
+                       moving_mask, a, ncand, partials, ticket, hres, flags, seq);
   PP_LAUNCH_CHECK(ctx, "k_metric_values");
-  return pp_read_back(ctx, dres, result, (size_t)ncand * 6 * sizeof(double));
+  rc = pp_mail_wait(ctx, nchunk, seq);
+  if (rc) return rc;
+  memcpy(result, hres, (size_t)ncand * 6 * sizeof(double));
+  return PP_OK;
 }
 
 }  // extern "C"

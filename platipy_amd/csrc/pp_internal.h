@@ -25,6 +25,8 @@ struct pp_ctx {
   pp_profiler* prof;  // NULL unless pp_profile_enable(ctx, 1)
   char* pinned;       // 4 KB of page-locked host memory for small read-backs (lazy)
   unsigned* ticket;   // device counter for last-block-finishes reductions (lazy, kept at 0 between launches)
+  char* mailbox;      // 4 KB of page-locked, device-visible host memory a kernel writes small results into (lazy)
+  unsigned long long mail_seq;  // sequence number of the last posted result
   char err[512];
 };
 
@@ -45,6 +47,14 @@ int pp_reserve(pp_ctx* ctx, size_t bytes);
 int pp_read_back(pp_ctx* ctx, const void* dev, void* host, size_t bytes);
 // Device counter (zero between launches) for kernels whose last block folds the partial sums.
 int pp_ticket(pp_ctx* ctx, unsigned** out);
+// Mailbox for kernels that hand a few numbers straight to the host: 4 KB of page-locked memory the device writes
+// through its host pointer.  Layout: bytes [0, 3072) payload, [3072, 4096) up to 128 completion flags (uint64).
+// A kernel stores its payload, __threadfence_system(), then stores the launch's sequence number into its flag;
+// pp_mail_wait spins on `nflags` flags (falling back to a stream sync if they do not arrive) -- no copy command and
+// no interrupt-driven wake-up between a launch-latency-bound kernel and the host code that consumes it.
+constexpr size_t PP_MAIL_FLAGS_OFF = 3072;
+int pp_mailbox(pp_ctx* ctx, char** payload, unsigned long long** flags, unsigned long long* seq);
+int pp_mail_wait(pp_ctx* ctx, int nflags, unsigned long long seq);
 
 #define PP_HIP(ctx, call)                                                              \
   do {                                                                                 \
