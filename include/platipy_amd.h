@@ -120,6 +120,13 @@ void pp_demons_default_params(pp_demons_params* p);
 int pp_discrete_gaussian_f32(pp_ctx* ctx, const float* in, float* out, const int size[3],
                              const double spacing[3], const double variance[3], double max_error,
                              int max_kernel_width, int use_image_spacing);
+/* The same filter when only rows (y, z) with need_y[y] && need_z[z] (device uint8 masks of ny / nz entries) of the
+ * result will be read -- the pyramid's blur is followed by a resample onto a coarser grid (registration/utils.py:226,
+ * :257-267).  Values that are produced equal the dense filter's bit for bit; other entries of out are unspecified. */
+int pp_discrete_gaussian_rows_f32(pp_ctx* ctx, const float* in, float* out, const int size[3],
+                                  const double spacing[3], const double variance[3], double max_error,
+                                  int max_kernel_width, int use_image_spacing, const uint8_t* need_y,
+                                  const uint8_t* need_z);
 /* PDEDeformableRegistrationFilter::SmoothDisplacementField / SmoothUpdateField, in place on
  * a planar 3-vector field; sigma in voxels (deformable.py:248-257). */
 int pp_smooth_field_f32(pp_ctx* ctx, float* field, const int size[3], const double sigma_vox[3],

@@ -93,6 +93,8 @@ _SIGNATURES = {
     "pp_demons_default_params": (None, [C.POINTER(DemonsParams)]),
     "pp_discrete_gaussian_f32": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                            C.c_double, C.c_int, C.c_int]),
+    "pp_discrete_gaussian_rows_f32": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                C.c_double, C.c_int, C.c_int, _P, _P]),
     "pp_smooth_field_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_double, C.c_int]),
     "pp_recursive_gaussian_field_f32": (C.c_int, [_P, _P, C.POINTER(Geom), C.POINTER(C.c_double)]),
     "pp_recursive_gaussian_f32": (C.c_int, [_P, _P, _P, C.POINTER(Geom), C.POINTER(C.c_double)]),
@@ -265,6 +267,13 @@ class Context:
         self._chk(self.lib.pp_discrete_gaussian_f32(self.h, ptr(src), ptr(dst), _i3(size), _d3(spacing), _d3(variance),
                                                     float(max_error), int(max_kernel_width), int(bool(use_spacing))),
                   "pp_discrete_gaussian_f32")
+
+    def discrete_gaussian_rows(self, src, dst, size, spacing, variance, need_y, need_z, max_error=0.01, max_kernel_width=32,
+                               use_spacing=True):
+        """DiscreteGaussian valid only at rows (y, z) with need_y[y] and need_z[z] (uint8 device masks)."""
+        self._chk(self.lib.pp_discrete_gaussian_rows_f32(self.h, ptr(src), ptr(dst), _i3(size), _d3(spacing), _d3(variance),
+                                                         float(max_error), int(max_kernel_width), int(bool(use_spacing)), ptr(need_y),
+                                                         ptr(need_z)), "pp_discrete_gaussian_rows_f32")
 
     def smooth_field(self, field, size, sigma_vox, max_error=0.1, max_kernel_width=30):
         self._chk(self.lib.pp_smooth_field_f32(self.h, ptr(field), _i3(size), _d3(sigma_vox), float(max_error),

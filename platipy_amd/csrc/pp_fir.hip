@@ -19,7 +19,8 @@ constexpr int NT = 256;
 template <int AXIS, int VEC, bool ADD>
 __global__ void __launch_bounds__(NT) k_conv_axis(const float* __restrict__ in, const float* __restrict__ add,
                                                   float* __restrict__ out, pp_dims d, size_t cstride, pp_taps taps,
-                                                  const int* __restrict__ halt) {
+                                                  const int* __restrict__ halt, const uint8_t* __restrict__ need_y,
+                                                  const uint8_t* __restrict__ need_z) {
   if (halt && *halt) return;
   const size_t comp = (size_t)blockIdx.y * cstride;
   in += comp;
@@ -32,6 +33,7 @@ __global__ void __launch_bounds__(NT) k_conv_axis(const float* __restrict__ in, 
     const int xv = (int)(e % nxv);
     const int y = (int)((e / nxv) % d.ny);
     const int z = (int)(e / ((size_t)nxv * d.ny));
+    if ((need_y && !need_y[y]) || (need_z && !need_z[z])) continue;   // sparse mode: this output row is never read
     const size_t row = ((size_t)z * d.ny + y) * d.nx;
     if (AXIS == 0) {
       float s = 0.0f;
@@ -84,7 +86,8 @@ __global__ void __launch_bounds__(NT) k_conv_axis(const float* __restrict__ in, 
 template <bool ADD>
 __global__ void __launch_bounds__(NT) k_conv_x4(const float* __restrict__ in, const float* __restrict__ add,
                                                 float* __restrict__ out, pp_dims d, size_t cstride, pp_taps taps,
-                                                const int* __restrict__ halt) {
+                                                const int* __restrict__ halt, const uint8_t* __restrict__ need_y,
+                                                const uint8_t* __restrict__ need_z) {
   if (halt && *halt) return;
   const size_t comp = (size_t)blockIdx.y * cstride;
   in += comp;
@@ -96,7 +99,9 @@ __global__ void __launch_bounds__(NT) k_conv_x4(const float* __restrict__ in, co
   const int r4 = (r + 3) / 4 * 4;
   for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
     const int x0 = (int)(e % nxv) * 4;
-    const size_t row = (e / nxv) * (size_t)d.nx;
+    const size_t rowi = e / nxv;
+    if ((need_y && !need_y[rowi % d.ny]) || (need_z && !need_z[rowi / d.ny])) continue;
+    const size_t row = rowi * (size_t)d.nx;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     for (int o = -r4; o < 4 + r4; o += 4) {           // chunk covers inputs x0 + o .. x0 + o + 3
       float v[4];
@@ -136,14 +141,14 @@ __global__ void __launch_bounds__(NT) k_conv_x4(const float* __restrict__ in, co
 
 template <int AXIS, bool ADD>
 int launch_axis(pp_ctx* ctx, const float* in, const float* add, float* out, const pp_dims& d, int ncomp,
-                const pp_taps& taps, const int* halt) {
+                const pp_taps& taps, const int* halt, const uint8_t* need_y = nullptr, const uint8_t* need_z = nullptr) {
   const size_t cstride = (size_t)d.nx * d.ny * d.nz;
   if (AXIS == 0 && (d.nx % 4 == 0) && taps.r >= 3 &&
       ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | (ADD ? reinterpret_cast<uintptr_t>(add) : 0)) % 16 == 0)) {
     size_t blocks = (cstride / 4 + NT - 1) / NT;
     if (blocks > 65535u * 4u) blocks = 65535u * 4u;
     hipLaunchKernelGGL((k_conv_x4<ADD>), dim3((unsigned)blocks, (unsigned)ncomp, 1), dim3(NT, 1, 1), 0, ctx->stream, in, add, out, d,
-                       cstride, taps, halt);
+                       cstride, taps, halt, need_y, need_z);
     PP_LAUNCH_CHECK(ctx, "k_conv_x4");
     return PP_OK;
   }
@@ -155,9 +160,9 @@ int launch_axis(pp_ctx* ctx, const float* in, const float* add, float* out, cons
   if (blocks < 1) blocks = 1;
   const dim3 grid((unsigned)blocks, (unsigned)ncomp, 1), block(NT, 1, 1);
   if (vec4)
-    hipLaunchKernelGGL((k_conv_axis<AXIS, 4, ADD>), grid, block, 0, ctx->stream, in, add, out, d, cstride, taps, halt);
+    hipLaunchKernelGGL((k_conv_axis<AXIS, 4, ADD>), grid, block, 0, ctx->stream, in, add, out, d, cstride, taps, halt, need_y, need_z);
   else
-    hipLaunchKernelGGL((k_conv_axis<AXIS, 1, ADD>), grid, block, 0, ctx->stream, in, add, out, d, cstride, taps, halt);
+    hipLaunchKernelGGL((k_conv_axis<AXIS, 1, ADD>), grid, block, 0, ctx->stream, in, add, out, d, cstride, taps, halt, need_y, need_z);
   PP_LAUNCH_CHECK(ctx, "k_conv_axis");
   return PP_OK;
 }
@@ -218,6 +223,41 @@ int pp_discrete_gaussian_f32(pp_ctx* ctx, const float* in, float* out, const int
   // The ITK mini-pipeline convolves the last axis first: z, y, x.
   const int order[3] = {2, 1, 0};
   return pp_smooth3_staged(ctx, in, nullptr, out, t1, t2, d, 1, taps, order, nullptr);
+}
+
+// DiscreteGaussian whose result will only be read at rows (y, z) with need_y[y] && need_z[z] (masks in device
+// memory) -- the pyramid's blur feeds a resample onto a several-times coarser grid (registration/utils.py:226 then
+// :257-267), which touches a fraction of the rows.  Pass order z, y, x as above: the z pass runs for the needed z
+// (all y: the y pass reads along y), the y and x passes for the needed (y, z).  Every value that is produced is the
+// value the dense filter produces; the other entries of `out` are unspecified.
+int pp_discrete_gaussian_rows_f32(pp_ctx* ctx, const float* in, float* out, const int size[3], const double spacing[3],
+                                  const double variance[3], double max_error, int max_kernel_width, int use_image_spacing,
+                                  const uint8_t* need_y, const uint8_t* need_z) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, in && out && size && spacing && variance && need_y && need_z, "pp_discrete_gaussian_rows_f32: NULL argument");
+  PP_REQUIRE(ctx, size[0] > 0 && size[1] > 0 && size[2] > 0, "pp_discrete_gaussian_rows_f32: empty volume");
+  const pp_dims d{size[0], size[1], size[2]};
+  pp_taps taps[3];
+  for (int a = 0; a < 3; ++a) {
+    double var = variance[a];
+    if (use_image_spacing) {
+      PP_REQUIRE(ctx, spacing[a] > 0.0, "pp_discrete_gaussian_rows_f32: spacing must be positive");
+      var /= spacing[a] * spacing[a];
+    }
+    const int rc = pp_make_taps(ctx, var, max_error, max_kernel_width, &taps[a]);
+    if (rc) return rc;
+  }
+  const size_t N = pp_nvox(size);
+  int rc = pp_reserve(ctx, 2 * pp_align_up(N * sizeof(float), 256));
+  if (rc) return rc;
+  pp_carver cv{ctx->ws, 0};
+  float* t1 = cv.take<float>(N);
+  float* t2 = cv.take<float>(N);
+  rc = launch_axis<2, false>(ctx, in, nullptr, t1, d, 1, taps[2], nullptr, nullptr, need_z);
+  if (rc) return rc;
+  rc = launch_axis<1, false>(ctx, t1, nullptr, t2, d, 1, taps[1], nullptr, need_y, need_z);
+  if (rc) return rc;
+  return launch_axis<0, false>(ctx, t2, nullptr, out, d, 1, taps[0], nullptr, need_y, need_z);
 }
 
 int pp_smooth_field_f32(pp_ctx* ctx, float* field, const int size[3], const double sigma_vox[3], double max_error,
