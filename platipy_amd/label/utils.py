@@ -76,3 +76,27 @@ def correct_volume_overlap(binary_label_dict, assign_overlap_to_largest=True):
         taken |= m
         out[k] = labels[k].like(m.to(torch.uint8))
     return out
+
+
+def binary_encode_structure_list(structure_list):
+    """Encode up to 32 binary labels into one integer image, structure k in bit k + 1 (reference label/utils.py:219-254).
+    The reference casts to UInt32, which cannot hold bit 32; the tensor here is int64."""
+    if len(structure_list) > 32:
+        raise ValueError("You can only encode a maximum of 32 structures with this method!")
+    first = as_image(structure_list[0])
+    enc = torch.zeros(first.shape, dtype=torch.int64, device=first.device)
+    for power, s_img in enumerate(structure_list):
+        enc |= (as_image(s_img).tensor != 0).to(torch.int64) << (power + 1)
+    return first.like(enc)
+
+
+def binary_decode_image(binary_encoded_img):
+    """Decode a binary-encoded label map into the list of non-empty structures (reference label/utils.py:257-288)."""
+    img = as_image(binary_encoded_img)
+    enc = img.tensor.to(torch.int64)
+    out = []
+    for power in range(32):
+        s = (enc & (1 << (power + 1))) != 0
+        if bool(s.any()):
+            out.append(img.like(s.to(torch.uint8)))
+    return out

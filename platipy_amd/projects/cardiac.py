@@ -145,8 +145,6 @@ def run_cardiac_segmentation(img, guide_structure=None, settings=CARDIAC_SETTING
         raise NotImplementedError(
             "run_cardiac_segmentation: geometric valve / conduction-node definitions are outside this build's scope; set "
             "geometric_segmentation_settings['run_geometric_algorithms'] = False")
-    if settings.get("return_proba_as_contours", False):
-        raise NotImplementedError("run_cardiac_segmentation: return_proba_as_contours (binary_encode_structure_list) is not built")
     out = atlas_pipeline(as_image(img), settings, guide_structure, atlases, streams_per_gpu, cardiac=True)
     run_cardiac_segmentation.last_iar_removed = out["iar_removed"]
     return out["results"], out["results_prob"]

@@ -387,11 +387,20 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
     for s in vote_structures:
         prob = combined_label_dict[s]
         binary = process_probability_image(prob, thresholds.get(s, 0.5))
+        if cardiac and settings.get("return_proba_as_contours", False):      # cardiac/run.py:945-951, 964-970
+            if dd.world > 1:
+                raise NotImplementedError("return_proba_as_contours needs every atlas's contour on one rank: single-process runs only")
+            from ..label.utils import binary_encode_structure_list
+
+            prob = binary_encode_structure_list([process_probability_image(atlas_set[a]["DIR"][s], 0.5) for a in atlas_id_list])
+            template_p = img.like(torch.zeros(img.shape, dtype=prob.tensor.dtype, device=device))
+        else:
+            template_p = template_prob
         if as_cropped:
             results[s], results_prob[s] = binary, prob
         else:
             results[s] = paste(template_binary, binary, crop_box_index)
-            results_prob[s] = paste(template_prob, prob, crop_box_index)
+            results_prob[s] = paste(template_p, prob, crop_box_index)
         if cardiac and guided and not settings.get("return_atlas_guide_structure", False):   # :955-960, :994-1004
             g = guide_structure.like(guide_structure.tensor.to(torch.uint8))
             g = g if as_cropped else paste(template_binary, g, crop_box_index)

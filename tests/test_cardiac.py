@@ -186,3 +186,12 @@ def test_cardiac_options_cropped_output_and_postprocessing(monkeypatch, tmp_path
     # overlap correction made the two structures disjoint; the larger (whole heart) kept the shared voxels
     wh, ss = output["WHOLEHEART"].numpy() > 0, output["SUBSTRUCTURE"].numpy() > 0
     assert not (wh & ss).any() and wh.sum() > 0
+    # return_proba_as_contours (cardiac/run.py:945-951): every atlas's propagated contour, one bit per atlas
+    s["return_proba_as_contours"] = True
+    s["postprocessing_settings"]["run_postprocessing"] = False
+    _, enc = pa.projects.cardiac.run_cardiac_segmentation(data[infer]["CT"], settings=s)
+    contours = pa.label.binary_decode_image(enc["WHOLEHEART"])
+    assert len(contours) == len(s["atlas_settings"]["atlas_id_list"])
+    again = pa.label.binary_encode_structure_list(contours)
+    np.testing.assert_array_equal(again.numpy(), enc["WHOLEHEART"].numpy())
+    assert all(dice(c.numpy(), gt) > 0.85 for c in contours)
