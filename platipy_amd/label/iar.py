@@ -177,3 +177,62 @@ def run_iar(atlas_set, reference_structure, smooth_distance_maps=False, smooth_s
                    smooth_sigma=smooth_sigma, z_score_statistic=z_score_statistic, outlier_method=outlier_method,
                    min_best_atlases=min_best_atlases, outlier_factor=outlier_factor, iteration=iteration + 1,
                    project_on_sphere=project_on_sphere, label=label)
+
+
+def run_iar_distributed(dd, atlas_set, my_ids, atlas_id_list, reference_structure, target, weights, smooth_distance_maps=False,
+                        smooth_sigma=1, z_score_statistic="MAD", outlier_method="IQR", min_best_atlases=10, outlier_factor=1.5,
+                        project_on_sphere=False, label="DIR"):
+    """run_iar when the atlases are spread over ranks (one process per GPU): the same passes, with each rank doing the
+    work of its own atlases only and three small exchanges per pass --
+      * the consensus: all_reduce(SUM) of [sum w, sum w L] for the reference structure (w = the atlas's global-vote
+        weight, one number), finalised identically everywhere;
+      * the distance samples on the consensus contour: all_gather of [slots, n] float32 per rank (n ~ 1e4-1e5);
+      * the Q values: all_reduce(SUM) of a vector with each rank's own entries filled in.
+    Every rank takes the same keep / drop decision from the same numbers.  `dd`: world, rank, all_reduce_sum(t),
+    all_gather(t); `weights`: {atlas_id: float} for this rank's atlases; `target`: the (cropped) target Image.
+    Returns the list of kept atlas ids (reference order)."""
+    if project_on_sphere:
+        raise NotImplementedError("project_on_sphere=True is outside this build's scope (SURVEY 2)")
+    from .. import runtime
+    from .fusion import finalize_probability
+
+    device = target.device
+    ctx = runtime.context(device)
+    kept = list(atlas_id_list)
+    slots = (len(atlas_id_list) + dd.world - 1) // dd.world
+    iteration = 0
+    while True:
+        mine = [i for i in my_ids if i in kept]
+        buf = torch.zeros((2,) + tuple(target.shape), dtype=torch.float32, device=device)
+        for i in mine:
+            lab = (atlas_set[i][label][reference_structure].tensor != 0).to(torch.float32)
+            buf[0] += float(weights[i])
+            buf[1] += float(weights[i]) * lab
+        dd.all_reduce_sum(buf)
+        consensus = finalize_probability(ctx, target, buf[0].contiguous(), buf[1].contiguous())
+        resample_factor = 5 if len(kept) < 12 else 1
+        reference_volume = process_probability_image(consensus, threshold=0.95)
+        ref_index = torch.nonzero((label_contour(reference_volume).tensor == 1).flatten()).flatten()[::resample_factor]
+        n = int(ref_index.numel())
+        local = torch.zeros((slots, n), dtype=torch.float32, device=device)
+        for k, i in enumerate(my_ids):
+            if i in kept:
+                local[k] = distance_map(process_probability_image(atlas_set[i][label][reference_structure], 0.1),
+                                        signed=False).tensor.flatten()[ref_index]
+        gathered = dd.all_gather(local)
+        rows = [gathered[idx % dd.world][idx // dd.world].to(device) for idx, aid in enumerate(atlas_id_list) if aid in kept]
+        samples = torch.stack(rows)
+        q = torch.zeros(len(kept), dtype=torch.float64, device=device)
+        for pos, aid in enumerate(kept):
+            if aid in mine:
+                q[pos] = float(_q_metric(_z_scores_device(samples, pos, z_score_statistic)))
+        dd.all_reduce_sum(q)
+        q_results = dict(zip(kept, q.cpu().numpy()))
+        limit = _outlier_limit(list(q_results.values()), outlier_method, outlier_factor, min_best_atlases)
+        keep = [i for i in kept if q_results[i] <= limit]
+        run_iar_distributed.last_q_results = dict(q_results)
+        logger.info("IAR step %d (distributed): limit %.4g, Q = %s", iteration, limit, {i: round(float(v), 4) for i, v in q_results.items()})
+        if len(keep) == len(kept):
+            return kept
+        kept = keep
+        iteration += 1

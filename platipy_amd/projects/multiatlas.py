@@ -173,31 +173,6 @@ def _map_atlases(fn, ids, streams_per_gpu, device):
     return out
 
 
-def _iar_exchange(dd, atlas_set, my_ids, atlas_id_list, ref_struct, img_crop):
-    """Iterative atlas removal looks at ALL atlases: every rank needs every atlas's propagated reference structure
-    (a uint8 volume) and its global-vote weight -- one number per atlas (fusion.py:154-161), so only that number
-    travels.  all_gather slot by slot (slot k of rank r is atlas_id_list[r + k * world]); returns the atlas set
-    run_iar expects, in the reference's atlas order, identical on every rank."""
-    device = img_crop.device
-    slots = (len(atlas_id_list) + dd.world - 1) // dd.world
-    full_set = {}
-    for k in range(slots):
-        if k < len(my_ids):
-            d = atlas_set[my_ids[k]]["DIR"]
-            m = (d[ref_struct].tensor != 0).to(torch.uint8).contiguous()
-            w = compute_weight_map(img_crop, d["CT Image"], vote_type="global").tensor.flatten()[:1].float().contiguous()
-        else:
-            m = torch.zeros(img_crop.shape, dtype=torch.uint8, device=device)
-            w = torch.zeros(1, dtype=torch.float32, device=device)
-        ms, ws = dd.all_gather(m), dd.all_gather(w)
-        for r in range(dd.world):
-            idx = r + k * dd.world
-            if idx < len(atlas_id_list):
-                weight = torch.zeros(img_crop.shape, dtype=torch.float32, device=device) + ws[r].to(device)
-                full_set[atlas_id_list[idx]] = {"DIR": {"Weight Map": img_crop.like(weight), ref_struct: img_crop.like(ms[r])}}
-    return {i: full_set[i] for i in atlas_id_list}
-
-
 def _mask_outside(image, mask, outside_value):
     """sitk.Mask(image, mask, outsideValue): image where mask != 0, outsideValue elsewhere."""
     t = image.tensor
@@ -345,15 +320,24 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
     ref_struct = iar.pop("reference_structure", False)
     removed = []
     if ref_struct:
-        from ..label.iar import run_iar
+        from ..label.iar import run_iar, run_iar_distributed
 
-        full_set = _iar_exchange(dd, atlas_set, my_ids, atlas_id_list, ref_struct, img_crop)
-        kept = run_iar(atlas_set=full_set, reference_structure=ref_struct, **iar)
+        if dd.world > 1:
+            # every rank scores its own atlases; consensus, distance samples and Q values are exchanged (label/iar.py)
+            weights = {i: float(compute_weight_map(img_crop, atlas_set[i]["DIR"]["CT Image"], vote_type="global").tensor.flatten()[0])
+                       for i in my_ids}
+            kept = run_iar_distributed(dd, {i: atlas_set[i] for i in my_ids}, my_ids, atlas_id_list, ref_struct, img_crop, weights, **iar)
+        else:
+            full_set = {}
+            for i in atlas_id_list:
+                d = atlas_set[i]["DIR"]
+                full_set[i] = {"DIR": {"Weight Map": compute_weight_map(img_crop, d["CT Image"], vote_type="global"), ref_struct: d[ref_struct]}}
+            kept = list(run_iar(atlas_set=full_set, reference_structure=ref_struct, **iar))
+            del full_set
         removed = [i for i in atlas_id_list if i not in kept]
         if removed:
             logger.info("IAR removed atlases: %s", removed)
         my_ids = [i for i in my_ids if i in kept]
-        del full_set, kept
     else:
         logger.info("IAR: No reference structure, skipping iterative atlas removal.")
 

@@ -130,43 +130,73 @@ def test_run_segmentation_two_ranks_gloo(tmp_path):
     assert dice(wh0, tmask) > 0.93
 
 
-def _exchange_worker(rank, world, port, out_dir):
+def _iar_case(pa):
+    """Seven small atlases (wobbly spheres, one of them displaced) with their CT images, and a target."""
+    from tests.helpers import smooth_noise
+
+    shape, sp = (22, 30, 34), (1.0, 1.0, 2.0)
+    rng = np.random.default_rng(21)
+    zz, yy, xx = np.meshgrid(*[np.arange(n) for n in shape], indexing="ij")
+    target = pa.image_from_array(rng.normal(0, 40, shape).astype(np.float32), sp, (0, 0, 0))
+    ids = [f"{i:02d}" for i in range(7)]
+    aset = {}
+    for k, cid in enumerate(ids):
+        r = 8 + 1.0 * smooth_noise(shape, 700 + k, cells=4)
+        m = ((zz - 11) ** 2 + (yy - 15) ** 2 + (xx - 17) ** 2 <= r ** 2).astype(np.uint8)
+        if k == 5:
+            m = np.roll(m, (0, 6, -5), axis=(0, 1, 2))
+        ct = (target.numpy() + rng.normal(0, 10 + 3 * k, shape)).astype(np.float32)
+        aset[cid] = {"DIR": {"CT Image": pa.image_from_array(ct, sp, (0, 0, 0)), "HEART": pa.image_from_array(m, sp, (0, 0, 0))}}
+    return target, ids, aset
+
+
+def _iar_worker(rank, world, port, out_dir):
     os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world)})
     import torch.distributed as dist
 
     import platipy_amd as pa
+    from platipy_amd.label.iar import run_iar_distributed
     from platipy_amd.projects import multiatlas
     from tests.helpers import install_emu_runtime
 
     install_emu_runtime()
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ids, shape = ["a", "b", "c", "d", "e"], (5, 6, 7)           # 5 atlases on 2 ranks: the last slot is half empty
-        rng = np.random.default_rng(11)
-        target = pa.image_from_array(rng.normal(0, 50, shape).astype(np.float32), (1, 1, 2), (0, 0, 0))
-        everything = {i: {"DIR": {"CT Image": pa.image_from_array(rng.normal(0, 50, shape).astype(np.float32), (1, 1, 2), (0, 0, 0)),
-                                  "HEART": pa.image_from_array((rng.random(shape) > 0.5).astype(np.uint8), (1, 1, 2), (0, 0, 0))}}
-                      for i in ids}
-        my_ids = ids[rank::world]
-        full = multiatlas._iar_exchange(multiatlas._Dist(), {i: everything[i] for i in my_ids}, my_ids, ids, "HEART", target)
-        assert list(full) == ids
-        for i in ids:      # what came over the wire equals what the owner holds
-            np.testing.assert_array_equal(full[i]["DIR"]["HEART"].numpy(), everything[i]["DIR"]["HEART"].numpy())
-            w = pa.label.compute_weight_map(target, everything[i]["DIR"]["CT Image"], vote_type="global").numpy()
-            np.testing.assert_allclose(full[i]["DIR"]["Weight Map"].numpy(), w, rtol=1e-6)
-        np.save(os.path.join(out_dir, f"ok_{rank}.npy"), np.array([1]))
+        target, ids, aset = _iar_case(pa)
+        my_ids = ids[rank::world]                                   # 7 atlases on 2 ranks: the last slot is half empty
+        weights = {i: float(pa.label.compute_weight_map(target, aset[i]["DIR"]["CT Image"], vote_type="global").tensor.flatten()[0])
+                   for i in my_ids}
+        kept = run_iar_distributed(multiatlas._Dist(), {i: aset[i] for i in my_ids}, my_ids, ids, "HEART", target, weights,
+                                   min_best_atlases=3, z_score_statistic="mad", outlier_method="iqr", outlier_factor=1.5)
+        q = run_iar_distributed.last_q_results
+        np.save(os.path.join(out_dir, f"kept_{rank}.npy"), np.array(kept))
+        np.save(os.path.join(out_dir, f"q_{rank}.npy"), np.array([q[k] for k in sorted(q)]))
     finally:
         dist.destroy_process_group()
 
 
-def test_iar_exchange_two_ranks_gloo(tmp_path):
-    """The atlas-selection exchange at world_size 2 (gloo, CPU): every rank ends up with every atlas's reference
-    structure and global-vote weight, in the reference's atlas order, with an uneven atlas count."""
+def test_distributed_iar_two_ranks_gloo(tmp_path, monkeypatch):
+    """Atlas selection with the atlases spread over two ranks (gloo, CPU): both ranks take the decision the
+    single-process run_iar takes on all atlases, from the same Q values."""
     import torch.multiprocessing as mp
 
+    import platipy_amd as pa
+    from platipy_amd.label import iar
+    from tests.helpers import install_emu_runtime
+
     port = 31500 + (os.getpid() % 2000)
-    mp.spawn(_exchange_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert (tmp_path / "ok_0.npy").exists() and (tmp_path / "ok_1.npy").exists()
+    mp.spawn(_iar_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    kept0, kept1 = np.load(tmp_path / "kept_0.npy"), np.load(tmp_path / "kept_1.npy")
+    assert list(kept0) == list(kept1)
+    np.testing.assert_array_equal(np.load(tmp_path / "q_0.npy"), np.load(tmp_path / "q_1.npy"))
+    install_emu_runtime(lambda obj, name, value: monkeypatch.setattr(obj, name, value, raising=False))
+    target, ids, aset = _iar_case(pa)
+    for i in ids:
+        aset[i]["DIR"]["Weight Map"] = pa.label.compute_weight_map(target, aset[i]["DIR"]["CT Image"], vote_type="global")
+    single = iar.run_iar(atlas_set=aset, reference_structure="HEART", min_best_atlases=3, z_score_statistic="mad", outlier_method="iqr",
+                         outlier_factor=1.5)
+    assert list(single) == list(kept0)
+    assert "05" not in kept0 and len(kept0) >= 3                       # the displaced contour went
 
 
 def test_run_segmentation_with_iterative_atlas_removal(host_api):
