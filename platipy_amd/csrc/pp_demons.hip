@@ -52,8 +52,9 @@ __device__ __forceinline__ float pp_esm_axis(float fm, float fp, float mc, float
   const float SENT = FLT_MAX;
   const bool up = !hi && (mp != SENT);
   const bool um = !lo && (mm != SENT);
-  const float cen = (mp - mm) * h, fwd = (mp - mc) * inv_sp, bwd = (mc - mm) * inv_sp;
-  const float wg = (up && um) ? cen : (up ? fwd : (um ? bwd : 0.0f));
+  // (mp - mm) h, (mp - mc) / sp, (mc - mm) / sp or 0, as one difference: an unusable side falls back to the centre value
+  const float hi_v = up ? mp : mc, lo_v = um ? mm : mc;
+  const float wg = (hi_v - lo_v) * ((up && um) ? h : inv_sp);
   const float fg = (lo || hi) ? 0.0f : (fp - fm) * h;
   return fg + wg;
 }
