@@ -25,7 +25,7 @@ from concurrent.futures import ThreadPoolExecutor
 import torch
 
 from .. import runtime
-from ..image import Image, as_image
+from ..image import as_image
 from ..label.fusion import compute_weight_map, finalize_probability, process_probability_image
 from ..registration.deformable import fast_symmetric_forces_demons_registration
 from ..registration.linear import linear_registration

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from .. import runtime
-from ..image import Image, as_image, cast_tensor
+from ..image import as_image, cast_tensor
 from ..transform import (
     AffineTransform,
     CompositeTransform,

@@ -9,7 +9,6 @@ from .. import _lib
 from ..image import Image, as_image, cast_tensor
 from .. import runtime
 from ..transform import (
-    AffineTransform,
     CompositeTransform,
     DisplacementFieldTransform,
     Transform,
