@@ -267,7 +267,8 @@ __global__ void __launch_bounds__(NT) k_metric_affine(const float* __restrict__ 
 
 // Fold [count][14] partial rows into 14 sums with one tree (8 barrier steps for all fields at once); launched
 // with one block per group of 14 fields (blockIdx.x selects the group of a wider row).
-__global__ void __launch_bounds__(NT) k_sum14_final(const double* __restrict__ partials, int count, int row, double* __restrict__ result) {
+__global__ void __launch_bounds__(NT) k_sum14_final(const double* __restrict__ partials, int count, int row, double* result,
+                                                    unsigned long long* flags, unsigned long long seq) {
   __shared__ double red[NT * 14];
   const int f0 = blockIdx.x * 14;
   const int nf = row - f0 < 14 ? row - f0 : 14;
@@ -282,7 +283,12 @@ __global__ void __launch_bounds__(NT) k_sum14_final(const double* __restrict__ p
       for (int f = 0; f < 14; ++f) red[f * NT + threadIdx.x] += red[f * NT + threadIdx.x + s];
     __syncthreads();
   }
-  if ((int)threadIdx.x < nf) result[f0 + threadIdx.x] = red[threadIdx.x * NT];
+  if ((int)threadIdx.x < nf) {
+    result[f0 + threadIdx.x] = red[threadIdx.x * NT];
+    if (flags) __threadfence_system();      // result may be the host mailbox: publish before the flag
+  }
+  __syncthreads();
+  if (flags && threadIdx.x == 0) flags[blockIdx.x] = seq;
 }
 
 // ---- line-search evaluations: K candidate moving maps in ONE launch, values only --------------------------
@@ -557,7 +563,7 @@ static int metric_affine(pp_ctx* ctx, int mode, const float* fixed, const int fs
   const size_t nsamp = ((size_t)vsize[0] * vsize[1] * vsize[2] + stride - 1) / stride;
   const pp_dims df{fsize[0], fsize[1], fsize[2]}, dm{msize[0], msize[1], msize[2]};
   const unsigned nb = grid_for(nsamp, 512u);
-  int rc = pp_reserve(ctx, pp_align_up(((size_t)nb * nacc + nacc) * sizeof(double), 256));
+  int rc = pp_reserve(ctx, pp_align_up((size_t)nb * nacc * sizeof(double), 256));
   if (rc) return rc;
   double* partials = reinterpret_cast<double*>(ctx->ws);
   if (mode == 0)
@@ -565,10 +571,19 @@ static int metric_affine(pp_ctx* ctx, int mode, const float* fixed, const int fs
   else
     hipLaunchKernelGGL((k_metric_affine<1>), dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, partials);
   PP_LAUNCH_CHECK(ctx, "k_metric_affine");
-  hipLaunchKernelGGL(k_sum14_final, dim3((nacc + 13) / 14), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, nacc,
-                     partials + (size_t)nb * nacc);
+  char* mail = nullptr;
+  unsigned long long* flags = nullptr;
+  unsigned long long seq = 0;
+  rc = pp_mailbox(ctx, &mail, &flags, &seq);
+  if (rc) return rc;
+  double* hres = reinterpret_cast<double*>(mail);       // up to 42 doubles of the payload area
+  const int nfold = (nacc + 13) / 14;
+  hipLaunchKernelGGL(k_sum14_final, dim3(nfold), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, nacc, hres, flags, seq);
   PP_LAUNCH_CHECK(ctx, "k_sum14_final");
-  return pp_read_back(ctx, partials + (size_t)nb * nacc, result, nacc * sizeof(double));
+  rc = pp_mail_wait(ctx, nfold, seq);
+  if (rc) return rc;
+  memcpy(result, hres, nacc * sizeof(double));
+  return PP_OK;
 }
 
 int pp_meansq_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], const float* moving, const int msize[3],
