@@ -10,7 +10,7 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libplatipy_hip.so")
 SOURCES = ["pp_api.hip", "pp_fir.hip", "pp_resample.hip", "pp_demons.hip", "pp_iir.hip", "pp_fusion.hip", "pp_cc.hip", "pp_dist.hip", "pp_morph.hip", "pp_linear.hip"]
-HEADERS = ["pp_internal.h", "pp_kernels.h", os.path.join("..", "..", "include", "platipy_amd.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "platipy_amd.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function"]
 
 

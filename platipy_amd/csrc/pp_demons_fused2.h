@@ -1,0 +1,637 @@
+// platipy_amd/csrc/pp_demons_fused2.h -- second generation of the two fused demons kernels
+// (included by pp_demons.hip after the shared tile geometry / ESM helpers).
+//
+// Same schedule, tiles and arithmetic (operation for operation, so fields are bit-identical to the
+// first generation) as k_fused_force_smooth / k_fused_add_smooth_warp; what changed is what the
+// round-1 ISA spent its issue slots on:
+//   * streaming loads, gathers and stores are buffer instructions (scalar resource + one 32-bit
+//     per-lane byte offset): no 64-bit VALU address arithmetic per access;
+//   * every plane-invariant index (LDS slots of the x pass, gather row strides) is computed once
+//     per block, not once per plane;
+//   * the trilinear warp is straight-line (clamped addresses, one select at the end) instead of a
+//     nest of divergent exec-mask regions;
+//   * the z window rotates by renaming (a wave-uniform switch on the plane phase) instead of moving
+//     3 x OPT x 2R registers per plane;
+//   * the per-plane pipeline is two barrier intervals instead of three (B) / four (A): work on
+//     different LDS buffers that used to be separated by a barrier now shares an interval
+//     (publish plane z+1 | y/z pass + warp of plane z;  x pass of plane z+1), so LDS-bound and
+//     VALU/VMEM-bound phases of one block overlap;
+//   * the ESM phase reads the fixed and warped tiles as one packed float2 tile (half the DS
+//     instructions), and block reductions use wavefront shuffles + one 8-entry LDS hop.
+#pragma once
+
+typedef __amdgpu_buffer_rsrc_t pp_rsrc;
+typedef unsigned pp_u2 __attribute__((vector_size(8)));
+
+// Raw buffer resource over the whole 32-bit offset range (bounds are guaranteed by construction:
+// every offset below is clamped into the volume).  0x00020000 = gfx9 DATA_FORMAT_32.
+__device__ __forceinline__ pp_rsrc pp_make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float pp_bld(pp_rsrc r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+// 8 bytes from a 4-byte-aligned position: a global load through a wave-uniform base plus a 32-bit per-lane byte offset
+// (global_load_dwordx2 v, v_off, s[base]; gfx950 runs global accesses in unaligned mode -- buffer loads of 8 bytes do
+// not: they drop the low address bits).
+struct pp_f2u {
+  float x, y;
+} __attribute__((aligned(4)));
+__device__ __forceinline__ float2 pp_gld2(const char* base, unsigned byte_off) {
+  const pp_f2u v = *reinterpret_cast<const pp_f2u*>(base + (size_t)byte_off);
+  return make_float2(v.x, v.y);
+}
+#ifndef PP_STORE_AUX
+#define PP_STORE_AUX 0
+#endif
+__device__ __forceinline__ void pp_bst(pp_rsrc r, unsigned byte_off, float a) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a), r, byte_off, 0, PP_STORE_AUX);
+}
+__device__ __forceinline__ void pp_bst2(pp_rsrc r, unsigned byte_off, float a, float b) {
+  pp_u2 v;
+  v[0] = __builtin_bit_cast(unsigned, a);
+  v[1] = __builtin_bit_cast(unsigned, b);
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, PP_STORE_AUX);
+}
+
+// Sum of three doubles over the block: butterfly inside each wavefront (ds_bpermute shuffles, no LDS
+// storage), one LDS hop for the per-wave results, fixed order -> deterministic.  Valid on thread 0.
+template <int NTH>
+__device__ __forceinline__ void pp_block_sum3_shfl(double& a, double& b, double& c, double* sm /* 3 * NTH / 64 */) {
+  constexpr int NW = NTH / 64;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    a += __shfl_xor(a, m, 64);
+    b += __shfl_xor(b, m, 64);
+    c += __shfl_xor(c, m, 64);
+  }
+  const int t = threadIdx.x;
+  __syncthreads();
+  if ((t & 63) == 0) {
+    sm[3 * (t >> 6) + 0] = a;
+    sm[3 * (t >> 6) + 1] = b;
+    sm[3 * (t >> 6) + 2] = c;
+  }
+  __syncthreads();
+  if (t == 0) {
+    a = sm[0];
+    b = sm[1];
+    c = sm[2];
+    for (int w = 1; w < NW; ++w) {
+      a += sm[3 * w + 0];
+      b += sm[3 * w + 1];
+      c += sm[3 * w + 2];
+    }
+  }
+}
+
+// x pass with per-thread precomputed LDS offsets (float indices; src < 0: no item).
+template <int R, int NXI, int NITEMS>
+__device__ __forceinline__ void fused2_xpass(const float* __restrict__ us, float* __restrict__ xs, const pp_taps_small& wx,
+                                             const int (&xsrc)[NXI], const int (&xdst)[NXI]) {
+#pragma unroll
+  for (int i = 0; i < NXI; ++i) {
+    if ((i + 1) * 512 > NITEMS && xsrc[i] < 0) continue;   // only the last round can be partial
+    const float* src = us + xsrc[i];
+    float in[4 + 2 * R];
+#pragma unroll
+    for (int q = 0; q < (4 + 2 * R) / 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+      in[4 * q + 0] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
+    }
+    if constexpr ((4 + 2 * R) % 4 == 2) {
+      const float2 v = *reinterpret_cast<const float2*>(src + (4 + 2 * R) / 4 * 4);
+      in[(4 + 2 * R) / 4 * 4 + 0] = v.x;
+      in[(4 + 2 * R) / 4 * 4 + 1] = v.y;
+    }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float s = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 2 * R + 1; ++k) s = fmaf(wx.h[k < R ? R - k : k - R], in[j + k], s);
+      o[j] = s;
+    }
+    *reinterpret_cast<float4*>(xs + xdst[i]) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+template <int R, int SH, int NXI>
+__device__ __forceinline__ void fused2_xpass_setup(int t, int (&xsrc)[NXI], int (&xdst)[NXI]) {
+  using G = fused_geom<R, 2, SH>;
+#pragma unroll
+  for (int i = 0; i < NXI; ++i) {
+    const int it = t + i * G::NTH;
+    if (it < 3 * G::XI) {
+      const int c = it / G::XI;
+      const int rem = it - c * G::XI;
+      const int uy = rem / (G::TX / 4);
+      const int c4 = rem - uy * (G::TX / 4);
+      xsrc[i] = (c * G::UH + uy) * G::UWP + 4 * c4;
+      xdst[i] = (c * G::UH + uy) * G::TX + 4 * c4;
+    } else {
+      xsrc[i] = -1;
+      xdst[i] = 0;
+    }
+  }
+}
+
+// y pass: this thread's two outputs of component c (s_x row pitch TX, `yb` = cy * TX + 2 cx).
+template <int R, int SH>
+__device__ __forceinline__ void fused2_ypass(const float* __restrict__ xs, int c, int yb, const pp_taps_small& wy, float v[2]) {
+  using G = fused_geom<R, 2, SH>;
+  v[0] = 0.0f;
+  v[1] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 2 * R + 1; ++k) {
+    const float2 a = *reinterpret_cast<const float2*>(xs + (c * G::UH + k) * G::TX + yb);
+    const float w = wy.h[k < R ? R - k : k - R];
+    v[0] = fmaf(w, a.x, v[0]);
+    v[1] = fmaf(w, a.y, v[1]);
+  }
+}
+
+// z window: slot P receives the newest plane; the dot runs oldest -> newest like zring::dot.
+template <int R, int P>
+__device__ __forceinline__ void fused2_ring_step(float (&rg)[3][2][2 * R + 1], const float (&v)[3][2], const pp_taps_small& wz,
+                                                 float (&out)[3][2]) {
+  constexpr int W = 2 * R + 1;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      rg[c][j][P] = v[c][j];
+      float s = 0.0f;
+#pragma unroll
+      for (int k = 0; k < W; ++k) s = fmaf(wz.h[k < R ? R - k : k - R], rg[c][j][(P + 1 + k) % W], s);
+      out[c][j] = s;
+    }
+}
+// P < 0: the window is shifted by register moves (one loop body for every plane; radii whose (2R+1)-fold unrolled body
+// would not fit the instruction cache).
+template <int R, int P>
+__device__ __forceinline__ void fused2_ring(float (&rg)[3][2][2 * R + 1], const float (&v)[3][2], const pp_taps_small& wz,
+                                            float (&out)[3][2]) {
+  if constexpr (P >= 0) {
+    fused2_ring_step<R, P>(rg, v, wz, out);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int k = 0; k < 2 * R; ++k) rg[c][j][k] = rg[c][j][k + 1];
+        rg[c][j][2 * R] = v[c][j];
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 2 * R + 1; ++k) s = fmaf(wz.h[k < R ? R - k : k - R], rg[c][j][k], s);
+        out[c][j] = s;
+      }
+  }
+}
+template <int P>
+struct pp_phase { static constexpr int value = P; };
+// Plane loop driver: step(n, pp_phase<P>) for n = 0 .. nsteps-1.  UNROLL: the body is instantiated once per
+// window phase (2R+1 copies, the z window is renamed instead of moved); otherwise one copy with P = -1.
+template <int P, int W>
+struct pp_phase_unroll {
+  template <class F>
+  static __device__ __forceinline__ bool run(F& step, int n0, int nsteps) {
+    if (n0 + P >= nsteps) return false;
+    step(n0 + P, pp_phase<P>{});
+    return pp_phase_unroll<P + 1, W>::run(step, n0, nsteps);
+  }
+};
+template <int W>
+struct pp_phase_unroll<W, W> {
+  template <class F>
+  static __device__ __forceinline__ bool run(F&, int, int) { return true; }
+};
+template <int R, bool UNROLL, class F>
+__device__ __forceinline__ void fused2_plane_loop(F& step, int nsteps) {
+  if constexpr (UNROLL) {
+    for (int n0 = 0; n0 < nsteps; n0 += 2 * R + 1)
+      if (!pp_phase_unroll<0, 2 * R + 1>::run(step, n0, nsteps)) break;
+  } else {
+    for (int n = 0; n < nsteps; ++n) step(n, pp_phase<-1>{});
+  }
+}
+
+// Straight-line itk::LinearInterpolateImageFunction sample through a buffer resource; the arithmetic equals
+// pp_trilinear's (lerps nested x, y, z as a + (b - a) w).  nx4 = nx * 4; volumes hold < 2^30 voxels.
+struct pp_warp_dims {
+  int nx, ny, nz;
+  unsigned nx4, sz4;   // bytes per row / per plane
+};
+__device__ __forceinline__ float fused2_warp_sample(const char* rm, const pp_warp_dims& wd, int xi, float dvx, int yi, float dvy, int zi,
+                                                    float dvz, bool lane_ok) {
+  // pp_split and pp_inside1 without short-circuit control flow: `h` = floor(2 * continuous index), and the buffer test
+  // [-0.5, n - 0.5) is -1 <= h <= 2n - 2.
+  const bool sx = fabsf(dvx) < 1.0e6f, sy_ = fabsf(dvy) < 1.0e6f, sz_ = fabsf(dvz) < 1.0e6f;
+  const float flx = floorf(dvx), fly = floorf(dvy), flz = floorf(dvz);
+  const int bx = sx ? xi + (int)flx : -0x40000000, by = sy_ ? yi + (int)fly : -0x40000000, bz = sz_ ? zi + (int)flz : -0x40000000;
+  const float fx = sx ? dvx - flx : 0.0f, fy = sy_ ? dvy - fly : 0.0f, fz = sz_ ? dvz - flz : 0.0f;
+  const int hx = 2 * bx + (fx >= 0.5f ? 1 : 0), hy = 2 * by + (fy >= 0.5f ? 1 : 0), hz = 2 * bz + (fz >= 0.5f ? 1 : 0);
+  const bool inside = lane_ok & ((unsigned)(hx + 1) <= (unsigned)(2 * wd.nx - 1)) & ((unsigned)(hy + 1) <= (unsigned)(2 * wd.ny - 1)) &
+                      ((unsigned)(hz + 1) <= (unsigned)(2 * wd.nz - 1));
+  // pp_axis_setup, with the base index also clamped from above so that outside lanes still form valid addresses
+  const int x0 = pp_clampi(bx, 0, wd.nx - 1), y0 = pp_clampi(by, 0, wd.ny - 1), z0 = pp_clampi(bz, 0, wd.nz - 1);
+  const float wx = bx < 0 ? 0.0f : fx, wy = by < 0 ? 0.0f : fy, wz = bz < 0 ? 0.0f : fz;
+  // byte offsets of the 8 corners; the upper corner of an axis repeats the lower one on the last index (ITK's clamp).
+  // 24-bit multiplies (full rate): z0 * ny + y0 < 2^24 and nx * 4 < 2^24 are checked on the host.
+  const unsigned r00 = __umul24(__umul24((unsigned)z0, (unsigned)wd.ny) + (unsigned)y0, wd.nx4);
+  const unsigned dy = y0 < wd.ny - 1 ? wd.nx4 : 0u, dz = z0 < wd.nz - 1 ? wd.sz4 : 0u;
+  const unsigned r10 = r00 + dy, r01 = r00 + dz, r11 = r01 + dy;
+  // The two x corners of a row come from ONE 8-byte load: it starts at min(x0, nx - 2), so on the last index (where
+  // ITK's upper corner repeats the lower one) both corners are its second element and nothing is read past the row.
+  const bool xlast = x0 > wd.nx - 2;
+  const unsigned c0 = (unsigned)(xlast ? wd.nx - 2 : x0) * 4u;
+  const float2 p00 = pp_gld2(rm, r00 + c0), p10 = pp_gld2(rm, r10 + c0), p01 = pp_gld2(rm, r01 + c0), p11 = pp_gld2(rm, r11 + c0);
+  const float a000 = xlast ? p00.y : p00.x, a100 = p00.y;
+  const float a010 = xlast ? p10.y : p10.x, a110 = p10.y;
+  const float a001 = xlast ? p01.y : p01.x, a101 = p01.y;
+  const float a011 = xlast ? p11.y : p11.x, a111 = p11.y;
+  const float v00 = a000 + (a100 - a000) * wx;
+  const float v10 = a010 + (a110 - a010) * wx;
+  const float v01 = a001 + (a101 - a001) * wx;
+  const float v11 = a011 + (a111 - a011) * wx;
+  const float v0 = v00 + (v10 - v00) * wy;
+  const float v1 = v01 + (v11 - v01) * wy;
+  const float r = v0 + (v1 - v0) * wz;
+  return inside ? r : FLT_MAX;
+}
+
+// ---- kernel B, generation 2: D' = G_d * (D + U), then the next iteration's warped moving image --------
+template <int R, int SH, bool UNROLL>
+__global__ void __launch_bounds__(512, PP_B_WAVES) k_fused2_add_smooth_warp(const float* __restrict__ D, const float* __restrict__ Us,
+                                                                            const float* __restrict__ M, float* __restrict__ Dn,
+                                                                            float* __restrict__ Mw, fused_args a, pp_warp_scale sc,
+                                                                            const int* __restrict__ halt) {
+  using G = fused_geom<R, 2, SH>;
+  constexpr int NTH = G::NTH, TX = G::TX, TY = G::TY, W = 2 * R + 1;
+  constexpr int NXI = (3 * G::XI + NTH - 1) / NTH;
+  __shared__ __attribute__((aligned(16))) float smem[G::SZ_X + G::SZ_U];
+  float* const s_x = smem;
+  float* const s_u = smem + G::SZ_X;
+  if (halt && *halt) return;
+  int tx0, ty0, z0;
+  unsigned rank;
+  if (!fused_tile(a, TX, TY, tx0, ty0, z0, rank)) return;
+
+  const pp_dims d = a.d;
+  const int t = threadIdx.x;
+  const int cx = t % G::LX, cy = t / G::LX;
+  const unsigned sy = d.nx, sz = (unsigned)d.nx * d.ny;
+  const size_t N = (size_t)sz * d.nz;
+
+  unsigned own_g[G::KU];  // in-plane BYTE offset of the clamped position
+  int own_u[G::KU];       // slot in s_u (< 0: not owned)
+#pragma unroll
+  for (int k = 0; k < G::KU; ++k) {
+    const int e = t + k * NTH;
+    const int ee = e < G::NU ? e : 0;
+    const int uy = ee / G::UW, ux = ee - uy * G::UW;
+    const int xc = pp_clampi(tx0 - R + ux, 0, d.nx - 1), yc = pp_clampi(ty0 - R + uy, 0, d.ny - 1);
+    own_g[k] = ((unsigned)yc * sy + (unsigned)xc) * 4u;
+    own_u[k] = e < G::NU ? uy * G::UWP + ux : -1;
+  }
+  int xsrc[NXI], xdst[NXI];
+  fused2_xpass_setup<R, SH, NXI>(t, xsrc, xdst);
+  const int yb = cy * TX + 2 * cx;
+  const int x = tx0 + 2 * cx, y = ty0 + cy;
+  const bool out_ok = (y < d.ny) && (x < d.nx);
+  const bool pair_ok = (d.nx % 2) == 0;     // then x + 1 < nx whenever x < nx and the 8-B stores are aligned
+  const unsigned o_xy = ((unsigned)y * sy + (unsigned)x) * 4u;
+  const pp_warp_dims wd{d.nx, d.ny, d.nz, (unsigned)d.nx * 4u, sz * 4u};
+  const char* const rm = reinterpret_cast<const char*>(M);
+
+  const int zs = z0 - R;
+  const int zo_last = (z0 + a.zchunk - 1 < d.nz - 1) ? z0 + a.zchunk - 1 : d.nz - 1;
+  const int ze = zo_last + R;
+  const int zhi = pp_clampi(ze, 0, d.nz - 1);
+  const int nsteps = ze - zs + 1;
+
+  float dl[3][G::KU], ul[3][G::KU];   // raw D and U of the plane about to be published
+  auto load_plane = [&](int zc) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const pp_rsrc rd = pp_make_rsrc(D + c * N + (size_t)zc * sz);
+      const pp_rsrc ru = pp_make_rsrc(Us + c * N + (size_t)zc * sz);
+#pragma unroll
+      for (int k = 0; k < G::KU; ++k) {
+#ifdef PP_ABL_NOLOAD
+        dl[c][k] = (float)own_g[k] * 1e-9f + (float)zc;
+        ul[c][k] = (float)own_g[k] * 1e-9f;
+#else
+        dl[c][k] = pp_bld(rd, own_g[k]);
+        ul[c][k] = pp_bld(ru, own_g[k]);
+#endif
+      }
+    }
+  };
+  auto publish = [&]() {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int k = 0; k < G::KU; ++k)
+        if ((k + 1) * NTH <= G::NU || own_u[k] >= 0) s_u[c * G::UH * G::UWP + own_u[k]] = dl[c][k] + ul[c][k];
+  };
+
+  float rg[3][2][W];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < W; ++k) rg[c][j][k] = 0.0f;
+  float v[3][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+
+  // prologue: first plane through publish + x pass, second plane in flight
+  {
+    const int zc0 = pp_clampi(zs, 0, d.nz - 1);
+    load_plane(zc0);
+    publish();
+    if (zc0 < zhi) load_plane(zc0 + 1);
+    __syncthreads();
+    fused2_xpass<R, NXI, 3 * G::XI>(s_u, s_x, a.wx, xsrc, xdst);
+    __syncthreads();
+  }
+
+  auto step = [&](int n, auto phase_tag) {
+    constexpr int P = decltype(phase_tag)::value;
+    const int zi = zs + n;
+    const int cur = pp_clampi(zi, 0, d.nz - 1);
+    const bool fresh_cur = (n == 0) || (cur != pp_clampi(zi - 1, 0, d.nz - 1));
+    const int nxt = pp_clampi(zi + 1, 0, d.nz - 1);
+    const bool fresh_next = (n + 1 < nsteps) && (nxt != cur);
+    // ---- interval 1: y pass of plane `cur` (reads s_x) | publish plane `nxt` (writes s_u) ----
+    if (fresh_cur) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) fused2_ypass<R, SH>(s_x, c, yb, a.wy, v[c]);
+    }
+    if (fresh_next) publish();
+#ifdef PP_B_LOAD_EARLY
+    if (fresh_next && nxt < zhi) load_plane(nxt + 1);
+#endif
+    float dn[3][2];
+    fused2_ring<R, P>(rg, v, a.wz, dn);
+    const int zo = zi - R;
+    const bool emit = (zo >= z0) && (zo <= zo_last);
+    float mw0 = FLT_MAX, mw1 = FLT_MAX;
+#ifdef PP_ABL_NOGATHER
+    if (emit) {
+      mw0 = dn[0][0] + dn[1][0] * dn[2][0];
+      mw1 = dn[0][1] + dn[1][1] * dn[2][1];
+    } else
+#endif
+    if (emit) {
+      mw0 = fused2_warp_sample(rm, wd, x, dn[0][0] * sc.ix, y, dn[1][0] * sc.iy, zo, dn[2][0] * sc.iz, out_ok);
+      mw1 = fused2_warp_sample(rm, wd, x + 1, dn[0][1] * sc.ix, y, dn[1][1] * sc.iy, zo, dn[2][1] * sc.iz, out_ok && (x + 1 < d.nx));
+    }
+    // the plane after `nxt` goes in flight behind the gathers
+#ifndef PP_B_LOAD_EARLY
+    if (fresh_next && nxt < zhi) load_plane(nxt + 1);
+#endif
+#ifdef PP_ABL_NOSTORE
+    if (emit && out_ok && mw0 == 1.2345e-30f && dn[0][0] == 3.21e-29f && dn[1][1] == 1e-31f && dn[2][0] == 7e-33f && mw1 == 1e-30f && dn[0][1] == 2e-30f && dn[1][0] == 3e-30f && dn[2][1] == 4e-30f) {
+#else
+    if (emit && out_ok) {
+#endif
+      const size_t po = (size_t)zo * sz;
+      const pp_rsrc rw = pp_make_rsrc(Mw + po);
+      if (pair_ok) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pp_bst2(pp_make_rsrc(Dn + c * N + po), o_xy, dn[c][0], dn[c][1]);
+        pp_bst2(rw, o_xy, mw0, mw1);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const pp_rsrc rdn = pp_make_rsrc(Dn + c * N + po);
+          pp_bst(rdn, o_xy, dn[c][0]);
+          if (x + 1 < d.nx) pp_bst(rdn, o_xy + 4u, dn[c][1]);
+        }
+        pp_bst(rw, o_xy, mw0);
+        if (x + 1 < d.nx) pp_bst(rw, o_xy + 4u, mw1);
+      }
+    }
+    // ---- interval 2: x pass of plane `nxt` ----
+    if (fresh_next) {
+      __syncthreads();
+      fused2_xpass<R, NXI, 3 * G::XI>(s_u, s_x, a.wx, xsrc, xdst);
+      __syncthreads();
+    }
+  };
+  fused2_plane_loop<R, UNROLL>(step, nsteps);
+}
+
+// ---- kernel A, generation 2: ESM update + 3-D Gaussian of the update -----------------------------------
+template <int R, int SH, bool UNROLL>
+__global__ void __launch_bounds__(512, PP_A_WAVES) k_fused2_force_smooth(const float* __restrict__ F, const float* __restrict__ Mw,
+                                                                         float* __restrict__ Us, fused_args a, pp_esm_consts K,
+                                                                         double* __restrict__ partials, const int* __restrict__ halt) {
+  using G = fused_geom<R, 2, SH>;
+  constexpr int NTH = G::NTH, TX = G::TX, TY = G::TY, W = 2 * R + 1;
+  constexpr int NXI = (3 * G::XI + NTH - 1) / NTH;
+  constexpr int SZ_IMG2 = (2 * G::MH * G::MWP + 3) / 4 * 4;   // packed (moving, fixed) tile, floats
+  __shared__ __attribute__((aligned(16))) float smem[SZ_IMG2 + G::SZ_U + G::SZ_X];
+  float2* const s_mf = reinterpret_cast<float2*>(smem);
+  float* const s_u = smem + SZ_IMG2;
+  float* const s_x = smem + SZ_IMG2 + G::SZ_U;
+  if (halt && *halt) return;
+  int tx0, ty0, z0;
+  unsigned rank;
+  if (!fused_tile(a, TX, TY, tx0, ty0, z0, rank)) return;
+
+  const pp_dims d = a.d;
+  const int t = threadIdx.x;
+  const int cx = t % G::LX, cy = t / G::LX;
+  const unsigned sy = d.nx, sz = (unsigned)d.nx * d.ny;
+  const size_t N = (size_t)sz * d.nz;
+
+  // Owned smoothing-input voxels.  Image values are fetched at the clamped position, so out-of-volume halo slots
+  // replicate the edge update (ZeroFluxNeumann on the smoothing input).
+  unsigned slots[G::KU];  // read slot of the clamped position | write slot << 16   (in s_mf)
+  unsigned uflag[G::KU];  // slot in s_u | flags << 16
+  unsigned own_g[G::KU];  // in-plane BYTE offset of the clamped position
+  float mprev[G::KU], mcur[G::KU], mnext[G::KU], fprev[G::KU], fcur[G::KU], fnext[G::KU];
+#pragma unroll
+  for (int k = 0; k < G::KU; ++k) {
+    const int e = t + k * NTH;
+    const int ee = e < G::NU ? e : 0;
+    const int uy = ee / G::UW, ux = ee - uy * G::UW;
+    const int xg = tx0 - R + ux, yg = ty0 - R + uy;
+    const int xc = pp_clampi(xg, 0, d.nx - 1), yc = pp_clampi(yg, 0, d.ny - 1);
+    own_g[k] = ((unsigned)yc * sy + (unsigned)xc) * 4u;
+    const unsigned wslot = (unsigned)((uy + 1) * G::MWP + (ux + 1));
+    const unsigned rslot = (unsigned)((yc - (ty0 - R - 1)) * G::MWP + (xc - (tx0 - R - 1)));
+    slots[k] = rslot | (wslot << 16);
+    unsigned fl = 0;
+    if (e < G::NU) fl |= F_VALID;
+    if (e < G::NU && xg >= tx0 && xg < tx0 + TX && xg < d.nx && yg >= ty0 && yg < ty0 + TY && yg < d.ny) fl |= F_CNT;
+    if (xc == 0) fl |= F_XLO;
+    if (xc == d.nx - 1) fl |= F_XHI;
+    if (yc == 0) fl |= F_YLO;
+    if (yc == d.ny - 1) fl |= F_YHI;
+    uflag[k] = (unsigned)(uy * G::UWP + ux) | (fl << 16);
+  }
+  // Border ring of the image tile (needed only in-plane): one element per low thread.
+  int brd_w = -1;
+  unsigned brd_g = 0;
+  if (t < G::NB) {
+    int my, mx;
+    if (t < G::MW) { my = 0; mx = t; }
+    else if (t < 2 * G::MW) { my = G::MH - 1; mx = t - G::MW; }
+    else { const int q = t - 2 * G::MW; my = 1 + q / 2; mx = (q & 1) ? G::MW - 1 : 0; }
+    const int xc = pp_clampi(tx0 - R - 1 + mx, 0, d.nx - 1), yc = pp_clampi(ty0 - R - 1 + my, 0, d.ny - 1);
+    brd_w = my * G::MWP + mx;
+    brd_g = ((unsigned)yc * sy + (unsigned)xc) * 4u;
+  }
+  int xsrc[NXI], xdst[NXI];
+  fused2_xpass_setup<R, SH, NXI>(t, xsrc, xdst);
+  const int yb = cy * TX + 2 * cx;
+  const int x = tx0 + 2 * cx, y = ty0 + cy;
+  const bool out_ok = (y < d.ny) && (x < d.nx);
+  const bool pair_ok = (d.nx % 2) == 0;
+  const unsigned o_xy = ((unsigned)y * sy + (unsigned)x) * 4u;
+
+  const int zs = z0 - R;
+  const int zo_last = (z0 + a.zchunk - 1 < d.nz - 1) ? z0 + a.zchunk - 1 : d.nz - 1;
+  const int ze = zo_last + R;
+  const int nsteps = ze - zs + 1;
+
+  float bm = 0.0f, bf = 0.0f;          // border ring values of the plane about to be published
+  float min_[G::KU], fin_[G::KU];      // plane two ahead of the window centre, in flight
+  float bm_n = 0.0f, bf_n = 0.0f;
+  float a_ssd = 0.0f, a_ssc = 0.0f, a_n = 0.0f;   // <= ~40 terms per thread: fp32 is exact enough, folded in fp64 below
+
+  auto publish = [&]() {   // window centre (mcur, fcur) + border ring -> packed image tile
+#pragma unroll
+    for (int k = 0; k < G::KU; ++k)
+      if ((k + 1) * NTH <= G::NU || ((uflag[k] >> 16) & F_VALID)) s_mf[slots[k] >> 16] = make_float2(mcur[k], fcur[k]);
+    if (brd_w >= 0) s_mf[brd_w] = make_float2(bm, bf);
+  };
+  auto prefetch = [&](int zc) {   // own voxels of plane zc + 2, border ring of plane zc + 1
+    const size_t p2 = (size_t)pp_clampi(zc + 2, 0, d.nz - 1) * sz, p1 = (size_t)pp_clampi(zc + 1, 0, d.nz - 1) * sz;
+    const pp_rsrc rm2 = pp_make_rsrc(Mw + p2), rf2 = pp_make_rsrc(F + p2);
+#pragma unroll
+    for (int k = 0; k < G::KU; ++k) {
+      min_[k] = pp_bld(rm2, own_g[k]);
+      fin_[k] = pp_bld(rf2, own_g[k]);
+    }
+    if (brd_w >= 0) {
+      bm_n = pp_bld(pp_make_rsrc(Mw + p1), brd_g);
+      bf_n = pp_bld(pp_make_rsrc(F + p1), brd_g);
+    }
+  };
+  auto esm = [&](int zc) {   // update at every smoothing-input voxel of plane zc (the window centre) -> s_u, then rotate
+    const bool count_plane = (zc >= z0 && zc <= zo_last);
+    const bool zlo_b = (zc == 0), zhi_b = (zc == d.nz - 1);
+#pragma unroll
+    for (int k = 0; k < G::KU; ++k) {
+      const unsigned fl = uflag[k] >> 16;
+      if ((k + 1) * NTH <= G::NU || (fl & F_VALID)) {
+        const int l = (int)(slots[k] & 0xffffu);
+        const float2 xm = s_mf[l - 1], xp = s_mf[l + 1], ym = s_mf[l - G::MWP], yp = s_mf[l + G::MWP];
+        const float gx = pp_esm_axis(xm.y, xp.y, mcur[k], xm.x, xp.x, (fl & F_XLO) != 0, (fl & F_XHI) != 0, K.ix);
+        const float gy = pp_esm_axis(ym.y, yp.y, mcur[k], ym.x, yp.x, (fl & F_YLO) != 0, (fl & F_YHI) != 0, K.iy);
+        const float gz = pp_esm_axis(fprev[k], fnext[k], mcur[k], mprev[k], mnext[k], zlo_b, zhi_b, K.iz);
+        const pp_esm_out o = pp_esm_voxel(K, fcur[k], mcur[k], gx, gy, gz);
+        const int u = (int)(uflag[k] & 0xffffu);
+        s_u[u] = o.ux;
+        s_u[G::UH * G::UWP + u] = o.uy;
+        s_u[2 * G::UH * G::UWP + u] = o.uz;
+        if (count_plane && (fl & F_CNT)) {
+          a_ssd += o.sq_speed;
+          a_ssc += o.sq_update;
+          a_n += (float)o.counted;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < G::KU; ++k) {
+      mprev[k] = mcur[k]; mcur[k] = mnext[k]; mnext[k] = min_[k];
+      fprev[k] = fcur[k]; fcur[k] = fnext[k]; fnext[k] = fin_[k];
+    }
+    bm = bm_n;
+    bf = bf_n;
+  };
+
+  float rg[3][2][W];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < W; ++k) rg[c][j][k] = 0.0f;
+  float v[3][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+
+  // prologue: z window and border ring at the first plane, published; its ESM update in s_u
+  {
+    const int zc0 = pp_clampi(zs, 0, d.nz - 1);
+    const size_t pm = (size_t)pp_clampi(zc0 - 1, 0, d.nz - 1) * sz, pc = (size_t)zc0 * sz, pn = (size_t)pp_clampi(zc0 + 1, 0, d.nz - 1) * sz;
+    const pp_rsrc rmm = pp_make_rsrc(Mw + pm), rfm = pp_make_rsrc(F + pm), rmc = pp_make_rsrc(Mw + pc), rfc = pp_make_rsrc(F + pc),
+                  rmn = pp_make_rsrc(Mw + pn), rfn = pp_make_rsrc(F + pn);
+#pragma unroll
+    for (int k = 0; k < G::KU; ++k) {
+      mprev[k] = pp_bld(rmm, own_g[k]); fprev[k] = pp_bld(rfm, own_g[k]);
+      mcur[k] = pp_bld(rmc, own_g[k]);  fcur[k] = pp_bld(rfc, own_g[k]);
+      mnext[k] = pp_bld(rmn, own_g[k]); fnext[k] = pp_bld(rfn, own_g[k]);
+    }
+    if (brd_w >= 0) {
+      bm = pp_bld(rmc, brd_g);
+      bf = pp_bld(rfc, brd_g);
+    }
+    publish();
+    prefetch(zc0);
+    __syncthreads();
+    esm(zc0);
+    __syncthreads();
+  }
+
+  auto step = [&](int n, auto phase_tag) {
+    constexpr int P = decltype(phase_tag)::value;
+    const int zi = zs + n;
+    const int cur = pp_clampi(zi, 0, d.nz - 1);
+    const bool fresh_cur = (n == 0) || (cur != pp_clampi(zi - 1, 0, d.nz - 1));
+    const int nxt = pp_clampi(zi + 1, 0, d.nz - 1);
+    const bool fresh_next = (n + 1 < nsteps) && (nxt != cur);
+    // ---- interval 1: x pass of plane `cur` (s_u -> s_x) | publish the image tile of plane `nxt` ----
+    if (fresh_next) {
+      publish();
+      prefetch(nxt);
+    }
+    if (fresh_cur) fused2_xpass<R, NXI, 3 * G::XI>(s_u, s_x, a.wx, xsrc, xdst);
+    if (fresh_cur || fresh_next) __syncthreads();
+    // ---- interval 2: y pass of plane `cur` (s_x -> registers) | ESM update of plane `nxt` (s_mf -> s_u) ----
+    if (fresh_cur) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) fused2_ypass<R, SH>(s_x, c, yb, a.wy, v[c]);
+    }
+    if (fresh_next) esm(nxt);
+    float us[3][2];
+    fused2_ring<R, P>(rg, v, a.wz, us);
+    const int zo = zi - R;
+    if (zo >= z0 && zo <= zo_last && out_ok) {
+      const size_t po = (size_t)zo * sz;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const pp_rsrc ro = pp_make_rsrc(Us + c * N + po);
+        if (pair_ok) {
+          pp_bst2(ro, o_xy, us[c][0], us[c][1]);
+        } else {
+          pp_bst(ro, o_xy, us[c][0]);
+          if (x + 1 < d.nx) pp_bst(ro, o_xy + 4u, us[c][1]);
+        }
+      }
+    }
+    if (fresh_cur || fresh_next) __syncthreads();
+  };
+  fused2_plane_loop<R, UNROLL>(step, nsteps);
+  double r_ssd = (double)a_ssd, r_ssc = (double)a_ssc, r_n = (double)a_n;
+  pp_block_sum3_shfl<NTH>(r_ssd, r_ssc, r_n, reinterpret_cast<double*>(s_u));
+  if (t == 0) {
+    partials[3 * (size_t)rank + 0] = r_ssd;
+    partials[3 * (size_t)rank + 1] = r_ssc;
+    partials[3 * (size_t)rank + 2] = r_n;
+  }
+}

@@ -15,6 +15,7 @@
 namespace hipemu {
 
 thread_local Fiber* t_current = nullptr;
+thread_local double t_shfl[1024];
 dim3 g_blockDim, g_gridDim;
 
 namespace {

@@ -136,3 +136,38 @@ static inline int __float2int_rd(float x) { return (int)floorf(x); }
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
 static inline float __fdividef(float a, float b) { return a / b; }
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))   // v_rcp_f32 (1 ulp) on the GPU
+static inline unsigned __umul24(unsigned a, unsigned b) { return (unsigned)((unsigned long long)(a & 0xffffffu) * (b & 0xffffffu)); }
+
+// buffer resources: base pointer + 32-bit byte offsets (the stand-in ignores the range / format words)
+struct __amdgpu_buffer_rsrc_t { char* base; };
+static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int, int) { return __amdgpu_buffer_rsrc_t{static_cast<char*>(p)}; }
+static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int) {
+  unsigned v;
+  memcpy(&v, r.base + (size_t)voff + soff, 4);
+  return v;
+}
+static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int) {
+  memcpy(r.base + (size_t)voff + soff, &v, 4);
+}
+typedef unsigned hipemu_u2 __attribute__((vector_size(8)));
+static inline hipemu_u2 __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int) {
+  hipemu_u2 v;
+  memcpy(&v, r.base + (size_t)voff + soff, 8);
+  return v;
+}
+static inline void __builtin_amdgcn_raw_buffer_store_b64(hipemu_u2 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int) {
+  memcpy(r.base + (size_t)voff + soff, &v, 8);
+}
+
+// Wavefront shuffle (64 lanes).  Every thread of the block must reach the call (uniform control flow): the value is
+// exchanged through a per-block table between two block-wide yields.
+namespace hipemu { extern thread_local double t_shfl[1024]; }
+static inline double __shfl_xor(double v, int lane_mask, int /*width*/ = 64) {
+  const unsigned t = threadIdx.x;
+  ::hipemu::t_shfl[t] = v;
+  ::hipemu::fiber_yield();
+  const unsigned src = (t & ~63u) | ((t ^ (unsigned)lane_mask) & 63u);
+  const double r = src < blockDim.x ? ::hipemu::t_shfl[src] : v;
+  ::hipemu::fiber_yield();
+  return r;
+}

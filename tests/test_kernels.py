@@ -294,6 +294,33 @@ def test_fused_demons_tile_shapes_agree(backend, grid, monkeypatch):
     assert np.abs(out["0"][0]).max() > 0.1
 
 
+ODD = ((9, 21, 67), (1.3, 0.9, 0.8), (0.0, 0.0, 0.0))   # odd nx: the scalar-store path; radii 1, 2, 2
+
+
+@pytest.mark.parametrize("tile", ["0", "1"])
+@pytest.mark.parametrize("grid", GRIDS + [HIRES, ODD])
+def test_fused_demons_generations_agree(backend, grid, tile, monkeypatch):
+    """The second-generation fused kernels (buffer addressing, two barrier intervals per plane, renamed z window,
+    straight-line warp) perform the first generation's arithmetic operation for operation: bit-identical fields,
+    warped images (through the next iteration) and statistics, for both tile shapes, radii 1..5 and odd row lengths."""
+    shape, spacing, origin = grid
+    fix = phantom(shape, seed=40)
+    dv = random_dvf(shape, spacing, seed=41, max_mm=2.5)
+    mov = O.warp_image(O.Vol(fix, spacing, origin), dv.astype(np.float64), edge_value=-1000.0).arr.astype(np.float32)
+    p = _demons_params(backend.ctx, 3, spacing, _lib.DEMONS_FUSED, max_rms=0.0)
+    monkeypatch.setenv("PP_FUSED_TILE", tile)
+    out = {}
+    for gen in ("1", "2"):
+        monkeypatch.setenv("PP_FUSED_GEN", gen)
+        f = backend.empty((3,) + shape)
+        st = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, f)
+        out[gen] = (backend.host(f).copy(), st.metric, st.rms_change, st.n_pixels, st.elapsed_iterations)
+    np.testing.assert_array_equal(out["1"][0], out["2"][0])
+    np.testing.assert_allclose(out["1"][1:3], out["2"][1:3], rtol=1e-12)   # same per-tile partial sums, same fold order
+    assert out["1"][3] == out["2"][3] and out["1"][4] == out["2"][4] == 3
+    assert np.abs(out["2"][0]).max() > 0.1
+
+
 @pytest.mark.parametrize("zchunk", [1, 2, 3, 5, 100])
 def test_fused_demons_is_independent_of_the_z_chunking(backend, zchunk, monkeypatch):
     """The fused schedule splits z into chunks (halo planes recomputed at the seams); any chunk length, shorter

@@ -1,0 +1,151 @@
+// tools/kbench/kbench.cpp -- kernel A/B harness for the fused demons iteration (measurement tooling, not product).
+//
+// dlopens a build of libplatipy_hip.so given on the command line, runs pp_demons_execute_f32 on a synthetic
+// nx x ny x nz pair for `iters` iterations with per-kernel HIP-event profiling on, and prints one line per
+// configuration: per-kernel mean launch time, whole-iteration time, Mvoxel/s and a checksum of the field (equal
+// checksums across builds = bit-identical fields).  Environment knobs of the library (PP_FUSED_GEN, PP_FUSED_TILE,
+// PP_FUSED_ZCHUNK, ...) are read per call, so one process sweeps them:
+//   kbench <lib.so> nx ny nz iters "ENV1=a,ENV2=b" ["ENV1=c" ...]
+// Build: hipcc -O2 --offload-arch=gfx950 -o kbench kbench.cpp -ldl
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/platipy_amd.h"
+
+#define CK(x)                                                                     \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      fprintf(stderr, "%s failed: %s\n", #x, hipGetErrorString(e_));              \
+      exit(2);                                                                    \
+    }                                                                             \
+  } while (0)
+
+__device__ float hash01(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return (float)(x & 0xffffff) / 16777216.0f;
+}
+__device__ float scene(float x, float y, float z) {
+  return 300.0f * __sinf(0.045f * x) * __cosf(0.037f * y) * __sinf(0.051f * z + 0.3f) + 150.0f * __cosf(0.011f * (x + y + z)) - 200.0f;
+}
+__global__ void k_init(float* F, float* M, int nx, int ny, int nz) {
+  const size_t N = (size_t)nx * ny * nz;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % nx), y = (int)((i / nx) % ny), z = (int)(i / ((size_t)nx * ny));
+    const float dx = 2.5f * __sinf(0.013f * y + 0.021f * z), dy = 2.0f * __cosf(0.017f * x + 0.009f * z), dz = 1.5f * __sinf(0.015f * x + 0.019f * y);
+    F[i] = scene((float)x, (float)y, (float)z) + 10.0f * (hash01((unsigned)i) - 0.5f);
+    M[i] = scene(x + dx, y + dy, z + dz) + 10.0f * (hash01((unsigned)i * 2654435761u + 17u) - 0.5f);
+  }
+}
+__global__ void k_checksum(const float* a, size_t n, unsigned long long* out) {
+  unsigned long long s = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    s += (unsigned long long)__float_as_uint(a[i]) * (unsigned long long)((i % 1000003u) + 1u);
+  atomicAdd(out, s);
+}
+
+template <typename T>
+T sym(void* h, const char* name) {
+  void* p = dlsym(h, name);
+  if (!p) { fprintf(stderr, "missing symbol %s\n", name); exit(2); }
+  return reinterpret_cast<T>(p);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 7) { fprintf(stderr, "usage: kbench lib nx ny nz iters env-spec...\n"); return 1; }
+  void* h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+  if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
+  auto create = sym<int (*)(int, void*, pp_ctx**)>(h, "pp_create");
+  auto last_error = sym<const char* (*)(const pp_ctx*)>(h, "pp_last_error");
+  auto defaults = sym<void (*)(pp_demons_params*)>(h, "pp_demons_default_params");
+  auto execute = sym<int (*)(pp_ctx*, const float*, const float*, const pp_geom*, const pp_demons_params*, float*, pp_demons_stats*)>(h, "pp_demons_execute_f32");
+  auto prof_enable = sym<int (*)(pp_ctx*, int)>(h, "pp_profile_enable");
+  auto prof_read = sym<int (*)(pp_ctx*, pp_profile_entry*, int)>(h, "pp_profile_read");
+  auto sync = sym<int (*)(pp_ctx*)>(h, "pp_sync");
+
+  const int nx = atoi(argv[2]), ny = atoi(argv[3]), nz = atoi(argv[4]), iters = atoi(argv[5]);
+  const size_t N = (size_t)nx * ny * nz;
+  float *F, *M, *D;
+  unsigned long long* cs;
+  CK(hipMalloc(&F, N * 4)); CK(hipMalloc(&M, N * 4)); CK(hipMalloc(&D, 3 * N * 4)); CK(hipMalloc(&cs, 8));
+  hipLaunchKernelGGL(k_init, dim3(4096), dim3(256), 0, 0, F, M, nx, ny, nz);
+  CK(hipDeviceSynchronize());
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  pp_ctx* ctx = nullptr;
+  if (create(0, st, &ctx) != 0) { fprintf(stderr, "pp_create failed\n"); return 2; }
+  pp_geom g;
+  g.size[0] = nx; g.size[1] = ny; g.size[2] = nz;
+  for (int i = 0; i < 3; ++i) { g.spacing[i] = 1.0; g.origin[i] = 0.0; }
+  for (int i = 0; i < 9; ++i) g.direction[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  if (const char* sp = getenv("KB_SPACING")) sscanf(sp, "%lf,%lf,%lf", &g.spacing[0], &g.spacing[1], &g.spacing[2]);
+  pp_demons_params p;
+  defaults(&p);
+  p.iterations = iters;
+  for (int i = 0; i < 3; ++i) p.sigma_d_vox[i] = 1.5 / g.spacing[i];
+  p.max_rms_error = 0.0;
+  p.smooth_displacement = 1;
+  p.smooth_update = 1;
+  p.variant = PP_DEMONS_FUSED;
+  if (getenv("KB_STAGED")) p.variant = PP_DEMONS_STAGED;
+
+  for (int a = 6; a < argc; ++a) {
+    // apply the env spec "K=V,K2=V2" (an entry "K=" unsets)
+    std::string spec = argv[a];
+    std::vector<std::string> keys;
+    size_t pos = 0;
+    while (pos < spec.size()) {
+      size_t c = spec.find(',', pos);
+      if (c == std::string::npos) c = spec.size();
+      std::string kv = spec.substr(pos, c - pos);
+      size_t e = kv.find('=');
+      if (e != std::string::npos) {
+        std::string k = kv.substr(0, e), v = kv.substr(e + 1);
+        if (v.empty()) unsetenv(k.c_str()); else setenv(k.c_str(), v.c_str(), 1);
+        keys.push_back(k);
+      }
+      pos = c + 1;
+    }
+    // warm-up (also sizes the workspace), then the timed run with per-kernel events
+    pp_demons_params pw = p;
+    pw.iterations = 2;
+    if (execute(ctx, F, M, &g, &pw, D, nullptr) != 0) { fprintf(stderr, "execute failed: %s\n", last_error(ctx)); return 3; }
+    sync(ctx);
+    prof_enable(ctx, 1);
+    pp_profile_entry ent[16];
+    prof_read(ctx, ent, 16);
+    auto t0 = std::chrono::steady_clock::now();
+    if (execute(ctx, F, M, &g, &p, D, nullptr) != 0) { fprintf(stderr, "execute failed: %s\n", last_error(ctx)); return 3; }
+    sync(ctx);
+    auto t1 = std::chrono::steady_clock::now();
+    const int ne = prof_read(ctx, ent, 16);
+    prof_enable(ctx, 0);
+    // un-profiled wall time of the same call
+    auto t2 = std::chrono::steady_clock::now();
+    if (execute(ctx, F, M, &g, &p, D, nullptr) != 0) return 3;
+    sync(ctx);
+    auto t3 = std::chrono::steady_clock::now();
+    CK(hipMemsetAsync(cs, 0, 8, st));
+    hipLaunchKernelGGL(k_checksum, dim3(2048), dim3(256), 0, st, (const float*)D, 3 * N, cs);
+    unsigned long long hcs = 0;
+    CK(hipMemcpyAsync(&hcs, cs, 8, hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
+    const double ms_prof = std::chrono::duration<double, std::milli>(t1 - t0).count() / iters;
+    const double ms = std::chrono::duration<double, std::milli>(t3 - t2).count() / iters;
+    printf("%-44s | %s | ms/iter %.4f (profiled %.4f) | %.0f Mvox/s | cs %016llx |", argv[1] + (strlen(argv[1]) > 44 ? strlen(argv[1]) - 44 : 0),
+           spec.c_str(), ms, ms_prof, (double)N / ms / 1e3, hcs);
+    for (int i = 0; i < ne && i < 16; ++i)
+      if (ent[i].launches > 0 && ent[i].total_ms / ent[i].launches > 0.005) printf(" %s %.4f", ent[i].name, ent[i].total_ms / ent[i].launches);
+    printf("\n");
+    fflush(stdout);
+    for (auto& k : keys) unsetenv(k.c_str());
+  }
+  return 0;
+}
