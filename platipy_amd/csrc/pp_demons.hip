@@ -1008,48 +1008,56 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   }
   int opt = PP_FUSED_DEFAULT_OPT;
   if (const char* e = getenv("PP_FUSED_OPT")) opt = atoi(e) == 2 ? 2 : 4;
-  // kernel generation: 2 (pp_demons_fused2.h) unless the volume exceeds its 32-bit gather offsets, the 256-thread
-  // layout was asked for, or PP_FUSED_GEN=1 selects the first generation (kept for A/B measurements)
-  // (32-bit gather byte offsets, 24-bit row arithmetic, 8-byte corner loads need two voxels per row)
-  const bool gen2_ok = N * sizeof(float) < ((size_t)1 << 32) && (size_t)d.ny * d.nz < ((size_t)1 << 24) && d.nx >= 2 && d.nx < (1 << 22);
+  // kernel generation: 2 (pp_demons_fused2.h) unless the volume exceeds its 32-bit gather offsets / 24-bit row arithmetic,
+  // rows are shorter than one strip, the 256-thread layout was asked for, or PP_FUSED_GEN=1 selects the first generation
+  // (kept for A/B measurements).
+  const bool gen2_ok = N * sizeof(float) < ((size_t)1 << 32) && (size_t)d.ny * d.nz < ((size_t)1 << 24) && d.nx >= 4 && d.nx < (1 << 22);
   int gen = (gen2_ok && opt == 2) ? 2 : 1;
   if (const char* e = getenv("PP_FUSED_GEN")) {
     if (atoi(e) == 1) gen = 1;
   }
+  // (the second generation needs > 128 registers for kernel A from radius 4 -- sigma_u = 1 voxel gives radius 2 -- and for
+  // kernel B at radius 5, i.e. voxels under 0.55 mm: measured slower than the first generation there)
+  const int gen_a = (gen == 2 && ra <= 3) ? 2 : 1, gen_b = (gen == 2 && rb <= 4) ? 2 : 1;
   const int opt_a = ra > 3 ? 2 : opt, opt_b = rb > 3 ? 2 : opt;   // radii 4 and 5 exist in the 512-thread layout only
   fused_args fu, fd;
   int sh_a = 0, sh_b = 0;
-  if (gen == 2) {
+  // tile shape per kernel: 32 x 32 where the z-chunk model says the 64 x 16 launch wastes >= 10 % (512-thread layouts only)
+  if (gen_a == 2) {
 #define PP_OCC_A20(RR) occ_force2<RR>(0)
 #define PP_OCC_A21(RR) occ_force2<RR>(1)
-#define PP_OCC_B20(RR) occ_warp2<RR>(0)
-#define PP_OCC_B21(RR) occ_warp2<RR>(1)
     const int occ_a0 = PP_BY_RADIUS2(ra, PP_OCC_A20), occ_a1 = PP_BY_RADIUS2(ra, PP_OCC_A21);
-    const int occ_b0 = PP_BY_RADIUS2(rb, PP_OCC_B20), occ_b1 = PP_BY_RADIUS2(rb, PP_OCC_B21);
 #undef PP_OCC_A20
 #undef PP_OCC_A21
-#undef PP_OCC_B20
-#undef PP_OCC_B21
     sh_a = fused_shape(d, 256 * occ_a0, 256 * occ_a1);
-    sh_b = fused_shape(d, 256 * occ_b0, 256 * occ_b1);
     fused_grid(&fu, d, sh_a ? occ_a1 : occ_a0, sh_a);
-    fused_grid(&fd, d, sh_b ? occ_b1 : occ_b0, sh_b);
   } else {
-  // tile shape per kernel: 32 x 32 where the z-chunk model says the 64 x 16 launch wastes >= 10 % (OPT = 2 only)
 #define PP_OCC_A0(RR, OO) occ_force_sh<RR, OO>(0)
 #define PP_OCC_A1(RR, OO) occ_force_sh<RR, OO>(1)
-#define PP_OCC_B0(RR, OO) occ_warp_sh<RR, OO>(0)
-#define PP_OCC_B1(RR, OO) occ_warp_sh<RR, OO>(1)
-  const int occ_a0 = PP_BY_RADIUS(ra, opt_a, PP_OCC_A0), occ_b0 = PP_BY_RADIUS(rb, opt_b, PP_OCC_B0);
-  const int occ_a1 = opt_a == 2 ? PP_BY_RADIUS(ra, opt_a, PP_OCC_A1) : occ_a0, occ_b1 = opt_b == 2 ? PP_BY_RADIUS(rb, opt_b, PP_OCC_B1) : occ_b0;
+    const int occ_a0 = PP_BY_RADIUS(ra, opt_a, PP_OCC_A0);
+    const int occ_a1 = opt_a == 2 ? PP_BY_RADIUS(ra, opt_a, PP_OCC_A1) : occ_a0;
 #undef PP_OCC_A0
 #undef PP_OCC_A1
+    sh_a = opt_a == 2 ? fused_shape(d, 256 * occ_a0, 256 * occ_a1) : 0;
+    fused_grid(&fu, d, sh_a ? occ_a1 : occ_a0, sh_a);
+  }
+  if (gen_b == 2) {
+#define PP_OCC_B20(RR) occ_warp2<RR>(0)
+#define PP_OCC_B21(RR) occ_warp2<RR>(1)
+    const int occ_b0 = PP_BY_RADIUS2(rb, PP_OCC_B20), occ_b1 = PP_BY_RADIUS2(rb, PP_OCC_B21);
+#undef PP_OCC_B20
+#undef PP_OCC_B21
+    sh_b = fused_shape(d, 256 * occ_b0, 256 * occ_b1);
+    fused_grid(&fd, d, sh_b ? occ_b1 : occ_b0, sh_b);
+  } else {
+#define PP_OCC_B0(RR, OO) occ_warp_sh<RR, OO>(0)
+#define PP_OCC_B1(RR, OO) occ_warp_sh<RR, OO>(1)
+    const int occ_b0 = PP_BY_RADIUS(rb, opt_b, PP_OCC_B0);
+    const int occ_b1 = opt_b == 2 ? PP_BY_RADIUS(rb, opt_b, PP_OCC_B1) : occ_b0;
 #undef PP_OCC_B0
 #undef PP_OCC_B1
-  sh_a = opt_a == 2 ? fused_shape(d, 256 * occ_a0, 256 * occ_a1) : 0;
-  sh_b = opt_b == 2 ? fused_shape(d, 256 * occ_b0, 256 * occ_b1) : 0;
-  fused_grid(&fu, d, sh_a ? occ_a1 : occ_a0, sh_a);
-  fused_grid(&fd, d, sh_b ? occ_b1 : occ_b0, sh_b);
+    sh_b = opt_b == 2 ? fused_shape(d, 256 * occ_b0, 256 * occ_b1) : 0;
+    fused_grid(&fd, d, sh_b ? occ_b1 : occ_b0, sh_b);
   }
   small_taps(tu[0], ra, &fu.wx);
   small_taps(tu[1], ra, &fu.wy);
@@ -1077,29 +1085,29 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     float* mw_out = (it & 1) ? MwB : MwA;
     const float* Dcur = (it & 1) ? D2 : field;
     float* Dnext = (it & 1) ? field : D2;
-    if (gen == 2) {
+    // a failed first launch must not be masked by the second one's status
+    if (gen_a == 2) {
 #define PP_CALL_A2(RR) launch_force2<RR>(ctx, sh_a, fixed, mw_in, Us, fu, K, partials, halt)
-#define PP_CALL_B2(RR) launch_warp2<RR>(ctx, sh_b, Dcur, (const float*)Us, moving, Dnext, mw_out, fd, sc, halt)
       rc = PP_BY_RADIUS2(ra, PP_CALL_A2);
-      PP_LAUNCH_CHECK(ctx, "k_fused2_force_smooth");
-      if (rc) return rc;
-      rc = PP_BY_RADIUS2(rb, PP_CALL_B2);
-      PP_LAUNCH_CHECK(ctx, "k_fused2_add_smooth_warp");
-      if (rc) return rc;
 #undef PP_CALL_A2
-#undef PP_CALL_B2
     } else {
 #define PP_CALL_A(RR, OO) launch_force<RR, OO>(ctx, sh_a, fixed, mw_in, Us, fu, K, partials, halt)
-#define PP_CALL_B(RR, OO) launch_warp<RR, OO>(ctx, sh_b, Dcur, (const float*)Us, moving, Dnext, mw_out, fd, sc, halt)
       rc = PP_BY_RADIUS(ra, opt_a, PP_CALL_A);
-      PP_LAUNCH_CHECK(ctx, "k_fused_force_smooth");
-      if (rc) return rc;   // a failed first launch must not be masked by the second one's status
-      rc = PP_BY_RADIUS(rb, opt_b, PP_CALL_B);
-      PP_LAUNCH_CHECK(ctx, "k_fused_add_smooth_warp");
-      if (rc) return rc;
 #undef PP_CALL_A
+    }
+    PP_LAUNCH_CHECK(ctx, "k_fused_force_smooth");
+    if (rc) return rc;
+    if (gen_b == 2) {
+#define PP_CALL_B2(RR) launch_warp2<RR>(ctx, sh_b, Dcur, (const float*)Us, moving, Dnext, mw_out, fd, sc, halt)
+      rc = PP_BY_RADIUS2(rb, PP_CALL_B2);
+#undef PP_CALL_B2
+    } else {
+#define PP_CALL_B(RR, OO) launch_warp<RR, OO>(ctx, sh_b, Dcur, (const float*)Us, moving, Dnext, mw_out, fd, sc, halt)
+      rc = PP_BY_RADIUS(rb, opt_b, PP_CALL_B);
 #undef PP_CALL_B
     }
+    PP_LAUNCH_CHECK(ctx, "k_fused_add_smooth_warp");
+    if (rc) return rc;
     hipLaunchKernelGGL(k_demons_finalize, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nblk, dst, max_rms);
     PP_LAUNCH_CHECK(ctx, "k_demons_finalize");
   }

@@ -20,6 +20,12 @@
 //     instructions), and block reductions use wavefront shuffles + one 8-entry LDS hop.
 #pragma once
 
+// Register budget: 4 waves per SIMD = two 512-thread blocks per CU (<= 128 VGPRs); without the bound the scheduler
+// spends up to ~170 registers on load latency it cannot use with one block per CU.
+#ifndef PP_GEN2_WAVES
+#define PP_GEN2_WAVES 4
+#endif
+
 typedef __amdgpu_buffer_rsrc_t pp_rsrc;
 typedef unsigned pp_u2 __attribute__((vector_size(8)));
 
@@ -85,6 +91,77 @@ __device__ __forceinline__ void pp_block_sum3_shfl(double& a, double& b, double&
   }
 }
 
+// 16 bytes from a 4-byte-aligned position (global_load_dwordx4 v, v_off, s[base]; rows are 16-B aligned when nx % 4 == 0)
+struct pp_f4u {
+  float x, y, z, w;
+} __attribute__((aligned(4)));
+__device__ __forceinline__ float4 pp_gld4(const char* base, unsigned byte_off) {
+  const pp_f4u v = *reinterpret_cast<const pp_f4u*>(base + (size_t)byte_off);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// Strip geometry of the generation-2 kernels.  The smoothing-input tile is fetched and published as STRIPS of four
+// consecutive x voxels (one 16-byte load / LDS store per strip and array instead of four 4-byte ones): the tile's x
+// halo is padded from R to RP = a whole number of strips, so its rows start on a strip boundary of the volume.
+//   H  = extra halo rows/columns on top of R (0: smoothing input of kernel B;  1: image tile of kernel A)
+template <int R, int SH, int H>
+struct strip_geom {
+  static constexpr int TX = tile_shape<SH>::TX, TY = tile_shape<SH>::TY;
+  static constexpr int NTH = 512, LX = TX / 2;
+  static constexpr int RP = (R + H + 3) / 4 * 4;   // padded x halo
+  static constexpr int UW = TX + 2 * RP;           // tile width = row pitch (floats), a multiple of 4
+  static constexpr int UH = TY + 2 * R;            // smoothing-input rows
+  static constexpr int TH = UH + 2 * H;            // tile rows
+  static constexpr int SPR = UW / 4;               // strips per row
+  static constexpr int NS = SPR * TH;              // strips per plane
+  static constexpr int NSL = (NS + NTH - 1) / NTH; // strips per thread (1 except at radius 4-5)
+  // x pass: the four outputs at tile x = 4c .. 4c+3 read tile columns 4c + RP - R .. 4c + RP + R + 3
+  static constexpr int XA0 = (RP - R) / 4 * 4;     // first 16-B group read, relative to 4c
+  static constexpr int XOFF = (RP - R) - XA0;      // position of the first tap inside it
+  static constexpr int XNR = (XOFF + 4 + 2 * R + 3) / 4;   // 16-B LDS reads per item
+  static constexpr int XI = UH * (TX / 4);         // x-pass items per component
+  static constexpr int NXI = (3 * XI + NTH - 1) / NTH;
+  static constexpr int SZ_U = 3 * UH * UW;         // smoothing input (3 components)
+  static constexpr int SZ_X = 3 * UH * TX;         // after the x pass
+  static_assert(UH * UW < 32768, "LDS slots are 16 bit");
+};
+
+// Plane-invariant description of one strip of a thread.  A strip whose voxels leave the volume in x is loaded from
+// the nearest 4 in-row voxels (xl) and re-mapped element-wise (jm: 2 bits per element = index into the loaded four)
+// so that every position holds the value of its clamped voxel (ZeroFluxNeumann); rows are clamped by address.
+struct pp_strip {
+  unsigned goff;   // in-plane BYTE offset of the four voxels that are loaded
+  int slot;        // float index of the strip in the LDS tile (< 0: this thread has no such strip)
+  unsigned jm;     // element map; 0xE4 = identity
+};
+__device__ __forceinline__ pp_strip pp_strip_setup(int s, int ns, int spr, int uw, int x_first, int y_first, const pp_dims& d) {
+  pp_strip st;
+  const int ss = s < ns ? s : 0;
+  const int uy = ss / spr, sx = ss - uy * spr;
+  const int xs = x_first + 4 * sx;
+  const int yc = pp_clampi(y_first + uy, 0, d.ny - 1);
+  const int xl = pp_clampi(xs, 0, d.nx - 4);
+  unsigned jm = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) jm |= (unsigned)(pp_clampi(xs + i, 0, d.nx - 1) - xl) << (2 * i);
+  st.goff = ((unsigned)yc * (unsigned)d.nx + (unsigned)xl) * 4u;
+  st.slot = s < ns ? uy * uw + 4 * sx : -1;
+  st.jm = jm;
+  return st;
+}
+// Element map of a strip that leaves the volume in x, applied in place on the thread's own freshly written LDS strip
+// (NC components `cstride` floats apart): position i takes loaded element (jm >> 2i) & 3.  Same-thread LDS accesses
+// are ordered, so no barrier is involved; only lanes of x-border tiles come here.
+template <int NC>
+__device__ __forceinline__ void pp_strip_remap_lds(float* strip, int cstride, unsigned jm) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    float* p = strip + c * cstride;
+    const float e0 = p[jm & 3u], e1 = p[(jm >> 2) & 3u], e2 = p[(jm >> 4) & 3u], e3 = p[(jm >> 6) & 3u];
+    *reinterpret_cast<float4*>(p) = make_float4(e0, e1, e2, e3);
+  }
+}
+
 // x pass with per-thread precomputed LDS offsets (float indices; src < 0: no item).
 template <int R, int NXI, int NITEMS>
 __device__ __forceinline__ void fused2_xpass(const float* __restrict__ us, float* __restrict__ xs, const pp_taps_small& wx,
@@ -145,6 +222,64 @@ __device__ __forceinline__ void fused2_ypass(const float* __restrict__ xs, int c
 #pragma unroll
   for (int k = 0; k < 2 * R + 1; ++k) {
     const float2 a = *reinterpret_cast<const float2*>(xs + (c * G::UH + k) * G::TX + yb);
+    const float w = wy.h[k < R ? R - k : k - R];
+    v[0] = fmaf(w, a.x, v[0]);
+    v[1] = fmaf(w, a.y, v[1]);
+  }
+}
+
+// x pass over a strip-layout tile: item i of this thread reads XNR aligned 16-B groups of `us` (pitch UW) starting at
+// xsrc[i] and writes four outputs to xs at xdst[i].
+template <int R, class SG>
+__device__ __forceinline__ void fused2_xpass_strips(const float* __restrict__ us, float* __restrict__ xs, const pp_taps_small& wx,
+                                                    const int (&xsrc)[SG::NXI], const int (&xdst)[SG::NXI]) {
+#pragma unroll
+  for (int i = 0; i < SG::NXI; ++i) {
+    if ((i + 1) * SG::NTH > 3 * SG::XI && xsrc[i] < 0) continue;   // only the last round can be partial
+    const float* src = us + xsrc[i];
+    float in[4 * SG::XNR];
+#pragma unroll
+    for (int q = 0; q < SG::XNR; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+      in[4 * q + 0] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
+    }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 2 * R + 1; ++k) a = fmaf(wx.h[k < R ? R - k : k - R], in[SG::XOFF + j + k], a);
+      o[j] = a;
+    }
+    *reinterpret_cast<float4*>(xs + xdst[i]) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+template <class SG>
+__device__ __forceinline__ void fused2_xpass_strips_setup(int t, int (&xsrc)[SG::NXI], int (&xdst)[SG::NXI]) {
+#pragma unroll
+  for (int i = 0; i < SG::NXI; ++i) {
+    const int it = t + i * SG::NTH;
+    if (it < 3 * SG::XI) {
+      const int c = it / SG::XI;
+      const int rem = it - c * SG::XI;
+      const int uy = rem / (SG::TX / 4);
+      const int c4 = rem - uy * (SG::TX / 4);
+      xsrc[i] = (c * SG::UH + uy) * SG::UW + 4 * c4 + SG::XA0;
+      xdst[i] = (c * SG::UH + uy) * SG::TX + 4 * c4;
+    } else {
+      xsrc[i] = -1;
+      xdst[i] = 0;
+    }
+  }
+}
+// y pass on the x-pass output (pitch TX), rows of the smoothing-input tile
+template <int R, class SG>
+__device__ __forceinline__ void fused2_ypass_strips(const float* __restrict__ xs, int c, int yb, const pp_taps_small& wy, float v[2]) {
+  v[0] = 0.0f;
+  v[1] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 2 * R + 1; ++k) {
+    const float2 a = *reinterpret_cast<const float2*>(xs + (c * SG::UH + k) * SG::TX + yb);
     const float w = wy.h[k < R ? R - k : k - R];
     v[0] = fmaf(w, a.x, v[0]);
     v[1] = fmaf(w, a.y, v[1]);
@@ -263,13 +398,12 @@ __device__ __forceinline__ float fused2_warp_sample(const char* rm, const pp_war
 
 // ---- kernel B, generation 2: D' = G_d * (D + U), then the next iteration's warped moving image --------
 template <int R, int SH, bool UNROLL>
-__global__ void __launch_bounds__(512, PP_B_WAVES) k_fused2_add_smooth_warp(const float* __restrict__ D, const float* __restrict__ Us,
+__global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(const float* __restrict__ D, const float* __restrict__ Us,
                                                                             const float* __restrict__ M, float* __restrict__ Dn,
                                                                             float* __restrict__ Mw, fused_args a, pp_warp_scale sc,
                                                                             const int* __restrict__ halt) {
-  using G = fused_geom<R, 2, SH>;
+  using G = strip_geom<R, SH, 0>;
   constexpr int NTH = G::NTH, TX = G::TX, TY = G::TY, W = 2 * R + 1;
-  constexpr int NXI = (3 * G::XI + NTH - 1) / NTH;
   __shared__ __attribute__((aligned(16))) float smem[G::SZ_X + G::SZ_U];
   float* const s_x = smem;
   float* const s_u = smem + G::SZ_X;
@@ -284,19 +418,11 @@ __global__ void __launch_bounds__(512, PP_B_WAVES) k_fused2_add_smooth_warp(cons
   const unsigned sy = d.nx, sz = (unsigned)d.nx * d.ny;
   const size_t N = (size_t)sz * d.nz;
 
-  unsigned own_g[G::KU];  // in-plane BYTE offset of the clamped position
-  int own_u[G::KU];       // slot in s_u (< 0: not owned)
+  pp_strip st[G::NSL];
 #pragma unroll
-  for (int k = 0; k < G::KU; ++k) {
-    const int e = t + k * NTH;
-    const int ee = e < G::NU ? e : 0;
-    const int uy = ee / G::UW, ux = ee - uy * G::UW;
-    const int xc = pp_clampi(tx0 - R + ux, 0, d.nx - 1), yc = pp_clampi(ty0 - R + uy, 0, d.ny - 1);
-    own_g[k] = ((unsigned)yc * sy + (unsigned)xc) * 4u;
-    own_u[k] = e < G::NU ? uy * G::UWP + ux : -1;
-  }
-  int xsrc[NXI], xdst[NXI];
-  fused2_xpass_setup<R, SH, NXI>(t, xsrc, xdst);
+  for (int i = 0; i < G::NSL; ++i) st[i] = pp_strip_setup(t + i * NTH, G::NS, G::SPR, G::UW, tx0 - G::RP, ty0 - R, d);
+  int xsrc[G::NXI], xdst[G::NXI];
+  fused2_xpass_strips_setup<G>(t, xsrc, xdst);
   const int yb = cy * TX + 2 * cx;
   const int x = tx0 + 2 * cx, y = ty0 + cy;
   const bool out_ok = (y < d.ny) && (x < d.nx);
@@ -311,30 +437,35 @@ __global__ void __launch_bounds__(512, PP_B_WAVES) k_fused2_add_smooth_warp(cons
   const int zhi = pp_clampi(ze, 0, d.nz - 1);
   const int nsteps = ze - zs + 1;
 
-  float dl[3][G::KU], ul[3][G::KU];   // raw D and U of the plane about to be published
+  float4 dl[3][G::NSL], ul[3][G::NSL];   // raw D and U strips of the plane about to be published
   auto load_plane = [&](int zc) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const pp_rsrc rd = pp_make_rsrc(D + c * N + (size_t)zc * sz);
-      const pp_rsrc ru = pp_make_rsrc(Us + c * N + (size_t)zc * sz);
+      const char* const pd = reinterpret_cast<const char*>(D + c * N + (size_t)zc * sz);
+      const char* const pu = reinterpret_cast<const char*>(Us + c * N + (size_t)zc * sz);
 #pragma unroll
-      for (int k = 0; k < G::KU; ++k) {
+      for (int i = 0; i < G::NSL; ++i)
+        if ((i + 1) * NTH <= G::NS || st[i].slot >= 0) {
 #ifdef PP_ABL_NOLOAD
-        dl[c][k] = (float)own_g[k] * 1e-9f + (float)zc;
-        ul[c][k] = (float)own_g[k] * 1e-9f;
+          dl[c][i] = make_float4((float)st[i].goff * 1e-9f + (float)zc, 0.f, 1.f, 2.f);
+          ul[c][i] = make_float4((float)st[i].goff * 1e-9f, 1.f, 0.f, 3.f);
 #else
-        dl[c][k] = pp_bld(rd, own_g[k]);
-        ul[c][k] = pp_bld(ru, own_g[k]);
+          dl[c][i] = pp_gld4(pd, st[i].goff);
+          ul[c][i] = pp_gld4(pu, st[i].goff);
 #endif
-      }
+        }
     }
   };
   auto publish = [&]() {
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int i = 0; i < G::NSL; ++i)
+      if ((i + 1) * NTH <= G::NS || st[i].slot >= 0) {
 #pragma unroll
-      for (int k = 0; k < G::KU; ++k)
-        if ((k + 1) * NTH <= G::NU || own_u[k] >= 0) s_u[c * G::UH * G::UWP + own_u[k]] = dl[c][k] + ul[c][k];
+        for (int c = 0; c < 3; ++c)
+          *reinterpret_cast<float4*>(s_u + c * G::UH * G::UW + st[i].slot) =
+              make_float4(dl[c][i].x + ul[c][i].x, dl[c][i].y + ul[c][i].y, dl[c][i].z + ul[c][i].z, dl[c][i].w + ul[c][i].w);
+        if (st[i].jm != 0xE4u) pp_strip_remap_lds<3>(s_u + st[i].slot, G::UH * G::UW, st[i].jm);   // x-border tiles only
+      }
   };
 
   float rg[3][2][W];
@@ -353,7 +484,7 @@ __global__ void __launch_bounds__(512, PP_B_WAVES) k_fused2_add_smooth_warp(cons
     publish();
     if (zc0 < zhi) load_plane(zc0 + 1);
     __syncthreads();
-    fused2_xpass<R, NXI, 3 * G::XI>(s_u, s_x, a.wx, xsrc, xdst);
+    fused2_xpass_strips<R, G>(s_u, s_x, a.wx, xsrc, xdst);
     __syncthreads();
   }
 
@@ -367,12 +498,9 @@ __global__ void __launch_bounds__(512, PP_B_WAVES) k_fused2_add_smooth_warp(cons
     // ---- interval 1: y pass of plane `cur` (reads s_x) | publish plane `nxt` (writes s_u) ----
     if (fresh_cur) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) fused2_ypass<R, SH>(s_x, c, yb, a.wy, v[c]);
+      for (int c = 0; c < 3; ++c) fused2_ypass_strips<R, G>(s_x, c, yb, a.wy, v[c]);
     }
     if (fresh_next) publish();
-#ifdef PP_B_LOAD_EARLY
-    if (fresh_next && nxt < zhi) load_plane(nxt + 1);
-#endif
     float dn[3][2];
     fused2_ring<R, P>(rg, v, a.wz, dn);
     const int zo = zi - R;
@@ -389,9 +517,7 @@ __global__ void __launch_bounds__(512, PP_B_WAVES) k_fused2_add_smooth_warp(cons
       mw1 = fused2_warp_sample(rm, wd, x + 1, dn[0][1] * sc.ix, y, dn[1][1] * sc.iy, zo, dn[2][1] * sc.iz, out_ok && (x + 1 < d.nx));
     }
     // the plane after `nxt` goes in flight behind the gathers
-#ifndef PP_B_LOAD_EARLY
     if (fresh_next && nxt < zhi) load_plane(nxt + 1);
-#endif
 #ifdef PP_ABL_NOSTORE
     if (emit && out_ok && mw0 == 1.2345e-30f && dn[0][0] == 3.21e-29f && dn[1][1] == 1e-31f && dn[2][0] == 7e-33f && mw1 == 1e-30f && dn[0][1] == 2e-30f && dn[1][0] == 3e-30f && dn[2][1] == 4e-30f) {
 #else
@@ -417,7 +543,7 @@ __global__ void __launch_bounds__(512, PP_B_WAVES) k_fused2_add_smooth_warp(cons
     // ---- interval 2: x pass of plane `nxt` ----
     if (fresh_next) {
       __syncthreads();
-      fused2_xpass<R, NXI, 3 * G::XI>(s_u, s_x, a.wx, xsrc, xdst);
+      fused2_xpass_strips<R, G>(s_u, s_x, a.wx, xsrc, xdst);
       __syncthreads();
     }
   };
@@ -426,7 +552,7 @@ __global__ void __launch_bounds__(512, PP_B_WAVES) k_fused2_add_smooth_warp(cons
 
 // ---- kernel A, generation 2: ESM update + 3-D Gaussian of the update -----------------------------------
 template <int R, int SH, bool UNROLL>
-__global__ void __launch_bounds__(512, PP_A_WAVES) k_fused2_force_smooth(const float* __restrict__ F, const float* __restrict__ Mw,
+__global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(const float* __restrict__ F, const float* __restrict__ Mw,
                                                                          float* __restrict__ Us, fused_args a, pp_esm_consts K,
                                                                          double* __restrict__ partials, const int* __restrict__ halt) {
   using G = fused_geom<R, 2, SH>;

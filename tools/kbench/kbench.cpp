@@ -51,6 +51,15 @@ __global__ void k_checksum(const float* a, size_t n, unsigned long long* out) {
   atomicAdd(out, s);
 }
 
+// PMC calibration kernels with known byte counts (MI355X_MICROARCH.md: calibrate FETCH_SIZE / WRITE_SIZE on your own
+// access widths): a 16 B/lane copy and a 4 B/lane copy of n floats (reads 4n bytes, writes 4n bytes each).
+__global__ void k_cal_copy16(const float4* __restrict__ a, float4* __restrict__ b, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+}
+__global__ void k_cal_copy4(const float* __restrict__ a, float* __restrict__ b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+}
+
 template <typename T>
 T sym(void* h, const char* name) {
   void* p = dlsym(h, name);
@@ -77,6 +86,12 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&F, N * 4)); CK(hipMalloc(&M, N * 4)); CK(hipMalloc(&D, 3 * N * 4)); CK(hipMalloc(&cs, 8));
   hipLaunchKernelGGL(k_init, dim3(4096), dim3(256), 0, 0, F, M, nx, ny, nz);
   CK(hipDeviceSynchronize());
+  if (getenv("KB_CALIBRATE")) {   // D (3N floats) as scratch: copy N floats F -> D with both access widths
+    hipLaunchKernelGGL(k_cal_copy16, dim3(8192), dim3(256), 0, 0, (const float4*)F, (float4*)D, N / 4);
+    hipLaunchKernelGGL(k_cal_copy4, dim3(8192), dim3(256), 0, 0, (const float*)F, D + N, N);
+    CK(hipDeviceSynchronize());
+    printf("calibration: k_cal_copy16 and k_cal_copy4 each read %zu and write %zu bytes\n", N * 4, N * 4);
+  }
   hipStream_t st;
   CK(hipStreamCreate(&st));
   pp_ctx* ctx = nullptr;
