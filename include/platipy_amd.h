@@ -158,6 +158,11 @@ int pp_resample_u8(pp_ctx* ctx, const uint8_t* in, const pp_geom* gin, const pp_
 /* sitk.Resample on the vector field itself (deformable.py:130,137,185): linear, default 0. */
 int pp_resample_field_f32(pp_ctx* ctx, const float* in, const pp_geom* gin, const pp_geom* gout,
                           float* out);
+/* sitk.TransformToDisplacementField(initial_transform, sitkVectorFloat64, fixed grid) (deformable.py:101-108) for a
+ * linear transform q = A p + t (fp64 coordinates): out(idx) = (A - I) p(idx) + t, plus `add_field` (planar, on the
+ * same grid, may be NULL) -- the displacement part of a composite whose last member is a displacement field. */
+int pp_transform_to_field_f32(pp_ctx* ctx, const pp_geom* g, const double* affine_A, const double* affine_t,
+                              const float* add_field, float* out);
 /* dvf_total + sitk.Resample(dvf_iter, DisplacementFieldTransform(dvf_total))
  * (deformable.py:154): total(x) += iter(x + total(x)), 0 outside; both on grid g. */
 int pp_compose_field_f32(pp_ctx* ctx, float* total, const float* iter, const pp_geom* g);
@@ -184,6 +189,10 @@ int pp_sum_sq_diff_f32(pp_ctx* ctx, const float* a, const float* b, size_t n, do
  * wsum += w (if wsum != NULL);  wlsum += w * label. */
 int pp_fuse_accumulate_u8(pp_ctx* ctx, const float* weight, const uint8_t* label, float* wsum,
                           float* wlsum, size_t n);
+/* the same with a float label (probabilistic atlas labels: the reference casts every label to sitkFloat32 before
+ * weighting, label/fusion.py:269-272, so values other than 0/1 are weighted as they are) */
+int pp_fuse_accumulate_f32(pp_ctx* ctx, const float* weight, const float* label, float* wsum,
+                           float* wlsum, size_t n);
 /* P = wlsum / (wsum == 0 ? 1 : wsum)  (label/fusion.py:264-276) */
 int pp_fuse_divide_f32(pp_ctx* ctx, const float* wlsum, const float* wsum, float* out, size_t n);
 /* global min / max (RescaleIntensity, label/fusion.py:282; process_probability_image :305) */

@@ -6,6 +6,8 @@ a torch tensor.  The same binding class is pointed at the CPU-emulated build of 
 kernel sources by the test-suite only (tests/emu), never by the package itself.
 """
 import ctypes as C
+
+import numpy as np
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -105,11 +107,13 @@ _SIGNATURES = {
                                  _P, C.c_int, C.c_double, _P]),
     "pp_resample_field_f32": (C.c_int, [_P, _P, C.POINTER(Geom), C.POINTER(Geom), _P]),
     "pp_compose_field_f32": (C.c_int, [_P, _P, _P, C.POINTER(Geom)]),
+    "pp_transform_to_field_f32": (C.c_int, [_P, C.POINTER(Geom), C.POINTER(C.c_double), C.POINTER(C.c_double), _P, _P]),
     "pp_demons_force_f32": (C.c_int, [_P, _P, _P, C.POINTER(Geom), C.POINTER(DemonsParams), _P, C.POINTER(DemonsStats)]),
     "pp_demons_execute_f32": (C.c_int, [_P, _P, _P, C.POINTER(Geom), C.POINTER(DemonsParams), _P, C.POINTER(DemonsStats)]),
     "pp_weight_map_local_f32": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_double, C.c_double, _P]),
     "pp_sum_sq_diff_f32": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_double)]),
     "pp_fuse_accumulate_u8": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t]),
+    "pp_fuse_accumulate_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t]),
     "pp_fuse_divide_f32": (C.c_int, [_P, _P, _P, _P, C.c_size_t]),
     "pp_minmax_f32": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pp_rescale_threshold_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, C.c_float]),
@@ -302,6 +306,13 @@ class Context:
         self._chk(self.lib.pp_resample_field_f32(self.h, ptr(src), C.byref(gin), C.byref(gout), ptr(out)),
                   "pp_resample_field_f32")
 
+    def transform_to_field(self, geom, A, t, add_field, out):
+        """out = (A - I) p + t (+ add_field) on the grid `geom` (sitk.TransformToDisplacementField for a linear map)."""
+        a = (C.c_double * 9)(*[float(v) for v in np.asarray(A, dtype=np.float64).ravel()])
+        tt = (C.c_double * 3)(*[float(v) for v in np.asarray(t, dtype=np.float64).ravel()])
+        self._chk(self.lib.pp_transform_to_field_f32(self.h, C.byref(geom), a, tt, ptr(add_field) if add_field is not None else None,
+                                                     ptr(out)), "pp_transform_to_field_f32")
+
     def compose_field(self, total, it, geom):
         self._chk(self.lib.pp_compose_field_f32(self.h, ptr(total), ptr(it), C.byref(geom)), "pp_compose_field_f32")
 
@@ -329,8 +340,13 @@ class Context:
         return r.value
 
     def fuse_accumulate(self, weight, label, wsum, wlsum, n):
-        self._chk(self.lib.pp_fuse_accumulate_u8(self.h, ptr(weight), ptr(label), ptr(wsum), ptr(wlsum), int(n)),
-                  "pp_fuse_accumulate_u8")
+        """wsum += w; wlsum += w * label.  `label` is uint8 (masks) or float32 (probabilistic labels)."""
+        if getattr(label, "dtype", None) is not None and str(label.dtype).endswith("float32"):
+            self._chk(self.lib.pp_fuse_accumulate_f32(self.h, ptr(weight), ptr(label), ptr(wsum), ptr(wlsum), int(n)),
+                      "pp_fuse_accumulate_f32")
+        else:
+            self._chk(self.lib.pp_fuse_accumulate_u8(self.h, ptr(weight), ptr(label), ptr(wsum), ptr(wlsum), int(n)),
+                      "pp_fuse_accumulate_u8")
 
     def fuse_divide(self, wlsum, wsum, out, n):
         self._chk(self.lib.pp_fuse_divide_f32(self.h, ptr(wlsum), ptr(wsum), ptr(out), int(n)), "pp_fuse_divide_f32")

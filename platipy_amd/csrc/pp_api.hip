@@ -163,7 +163,9 @@ int pp_abi_version(void) { return PP_ABI_VERSION; }
 int pp_create(int device, void* hip_stream, pp_ctx** out) {
   if (!out) return PP_ERR_ARG;
   *out = nullptr;
-  if (hipSetDevice(device) != hipSuccess) {
+  int prev = -1, count = 0;
+  (void)hipGetDevice(&prev);
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {   // validated without touching the caller's device
     (void)hipGetLastError();
     return PP_ERR_HIP;
   }
@@ -177,6 +179,7 @@ int pp_create(int device, void* hip_stream, pp_ctx** out) {
 
 void pp_destroy(pp_ctx* ctx) {
   if (!ctx) return;
+  pp_device_guard dev_guard_(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->ticket) (void)hipFree(ctx->ticket);
@@ -195,6 +198,7 @@ void pp_destroy(pp_ctx* ctx) {
 
 int pp_profile_enable(pp_ctx* ctx, int on) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   if (on && !ctx->prof) ctx->prof = new pp_profiler();
   if (!on && ctx->prof) {
     PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -211,6 +215,7 @@ int pp_profile_enable(pp_ctx* ctx, int on) {
 
 int pp_profile_read(pp_ctx* ctx, pp_profile_entry* out, int cap) {
   if (!ctx || (!out && cap > 0)) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   pp_profiler* p = ctx->prof;
   if (!p) return 0;
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -236,12 +241,14 @@ const char* pp_last_error(const pp_ctx* ctx) { return ctx ? ctx->err : "null ctx
 
 int pp_set_stream(pp_ctx* ctx, void* hip_stream) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   ctx->stream = static_cast<hipStream_t>(hip_stream);
   return PP_OK;
 }
 
 int pp_sync(pp_ctx* ctx) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PP_OK;
 }

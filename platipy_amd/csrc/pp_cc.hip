@@ -247,6 +247,7 @@ int cc_label(pp_ctx* ctx, const uint8_t* mask, int* L, const pp_dims& d, size_t 
 extern "C" int pp_fillhole_largest_component_u8(pp_ctx* ctx, const uint8_t* in, const int size[3], int fill_holes,
                                                  uint8_t* out, int64_t* component_voxels) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, in && out && size, "pp_fillhole_largest_component_u8: NULL argument");
   PP_REQUIRE(ctx, size[0] > 0 && size[1] > 0 && size[2] > 0, "pp_fillhole_largest_component_u8: empty volume");
   const size_t n = pp_nvox(size);

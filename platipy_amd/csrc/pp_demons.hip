@@ -895,6 +895,7 @@ extern "C" {
 int pp_demons_force_f32(pp_ctx* ctx, const float* fixed, const float* warped, const pp_geom* g, const pp_demons_params* p,
                         float* update, pp_demons_stats* stats) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, fixed && warped && update, "pp_demons_force_f32: NULL volume");
   int rc = check_demons_args(ctx, g, p);
   if (rc) return rc;
@@ -920,6 +921,7 @@ int pp_demons_force_f32(pp_ctx* ctx, const float* fixed, const float* warped, co
 int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, const pp_geom* g, const pp_demons_params* p,
                           float* field, pp_demons_stats* stats) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, fixed && moving && field, "pp_demons_execute_f32: NULL volume");
   int rc = check_demons_args(ctx, g, p);
   if (rc) return rc;

@@ -153,6 +153,7 @@ extern "C" {
 
 int pp_label_contour_u8(pp_ctx* ctx, const uint8_t* mask, const int size[3], uint8_t* out) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, mask && size && out && mask != out, "pp_label_contour_u8: NULL or aliased argument");
   const pp_dims d{size[0], size[1], size[2]};
   hipLaunchKernelGGL(k_contour6, dim3(grid_for(pp_nvox(size))), dim3(NT), 0, ctx->stream, mask, out, d);
@@ -162,6 +163,7 @@ int pp_label_contour_u8(pp_ctx* ctx, const uint8_t* mask, const int size[3], uin
 
 int pp_distance_map_f32(pp_ctx* ctx, const uint8_t* mask, const pp_geom* g, int want_signed, int inside_positive, float* out) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, mask && out, "pp_distance_map_f32: NULL argument");
   int rc = pp_geom_check(ctx, g, "grid");
   if (rc) return rc;

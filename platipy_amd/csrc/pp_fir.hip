@@ -201,6 +201,7 @@ extern "C" {
 int pp_discrete_gaussian_f32(pp_ctx* ctx, const float* in, float* out, const int size[3], const double spacing[3],
                              const double variance[3], double max_error, int max_kernel_width, int use_image_spacing) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, in && out && size && spacing && variance, "pp_discrete_gaussian_f32: NULL argument");
   PP_REQUIRE(ctx, size[0] > 0 && size[1] > 0 && size[2] > 0, "pp_discrete_gaussian_f32: empty volume");
   const pp_dims d{size[0], size[1], size[2]};
@@ -234,6 +235,7 @@ int pp_discrete_gaussian_rows_f32(pp_ctx* ctx, const float* in, float* out, cons
                                   const double variance[3], double max_error, int max_kernel_width, int use_image_spacing,
                                   const uint8_t* need_y, const uint8_t* need_z) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, in && out && size && spacing && variance && need_y && need_z, "pp_discrete_gaussian_rows_f32: NULL argument");
   PP_REQUIRE(ctx, size[0] > 0 && size[1] > 0 && size[2] > 0, "pp_discrete_gaussian_rows_f32: empty volume");
   const pp_dims d{size[0], size[1], size[2]};
@@ -263,6 +265,7 @@ int pp_discrete_gaussian_rows_f32(pp_ctx* ctx, const float* in, float* out, cons
 int pp_smooth_field_f32(pp_ctx* ctx, float* field, const int size[3], const double sigma_vox[3], double max_error,
                         int max_kernel_width) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, field && size && sigma_vox, "pp_smooth_field_f32: NULL argument");
   PP_REQUIRE(ctx, size[0] > 0 && size[1] > 0 && size[2] > 0, "pp_smooth_field_f32: empty volume");
   const pp_dims d{size[0], size[1], size[2]};

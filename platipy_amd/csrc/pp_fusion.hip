@@ -21,16 +21,124 @@ unsigned grid_for(size_t work, unsigned cap = 4096u) {
   return (unsigned)blocks;
 }
 
-__global__ void __launch_bounds__(NT) k_sqdiff(const float* __restrict__ a, const float* __restrict__ b,
-                                               float* __restrict__ out, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
-    const float d = a[i] - b[i];
-    out[i] = d * d;
-  }
+// Elementwise passes: one 16-byte access per lane and array (four voxels), grid-stride, the n % 4 tail by the first
+// lanes of block 0.  `vec` = every pointer is 16-byte aligned (torch allocations are; an offset view falls back to
+// 4-byte accesses through the same kernel).
+template <typename Op>
+__global__ void __launch_bounds__(NT) k_map4(size_t n, int vec, Op op) {
+  const size_t n4 = vec ? n / 4 : 0;
+  for (size_t g = (size_t)blockIdx.x * NT + threadIdx.x; g < n4; g += (size_t)gridDim.x * NT) op.four(g);
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) op.one(i);
 }
 
-__global__ void __launch_bounds__(NT) k_inv_eps(float* __restrict__ w, size_t n, float eps) {
-  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) w[i] = 1.0f / (w[i] + eps);
+struct op_sqdiff {
+  const float *a, *b;
+  float* out;
+  __device__ __forceinline__ static float f(float x, float y) { const float d = x - y; return d * d; }
+  __device__ __forceinline__ void four(size_t g) const {
+    const float4 x = reinterpret_cast<const float4*>(a)[g], y = reinterpret_cast<const float4*>(b)[g];
+    reinterpret_cast<float4*>(out)[g] = make_float4(f(x.x, y.x), f(x.y, y.y), f(x.z, y.z), f(x.w, y.w));
+  }
+  __device__ __forceinline__ void one(size_t i) const { out[i] = f(a[i], b[i]); }
+};
+
+struct op_inv_eps {
+  float* w;
+  float eps;
+  __device__ __forceinline__ void four(size_t g) const {
+    float4 v = reinterpret_cast<float4*>(w)[g];
+    v.x = 1.0f / (v.x + eps); v.y = 1.0f / (v.y + eps); v.z = 1.0f / (v.z + eps); v.w = 1.0f / (v.w + eps);
+    reinterpret_cast<float4*>(w)[g] = v;
+  }
+  __device__ __forceinline__ void one(size_t i) const { w[i] = 1.0f / (w[i] + eps); }
+};
+
+// wsum += w (if wsum);  wlsum += w * label.  LabelT = uint8_t (binary masks, the pipelines' case) or float (probabilistic
+// labels: the reference casts every label to float32 before weighting, label/fusion.py:269-272).
+template <typename LabelT>
+struct op_fuse_accumulate {
+  const float* w;
+  const LabelT* label;
+  float *wsum, *wlsum;
+  __device__ __forceinline__ void four(size_t g) const {
+    const float4 wi = reinterpret_cast<const float4*>(w)[g];
+    float l0, l1, l2, l3;
+    if (sizeof(LabelT) == 1) {
+      const uchar4 l = reinterpret_cast<const uchar4*>(label)[g];
+      l0 = (float)l.x; l1 = (float)l.y; l2 = (float)l.z; l3 = (float)l.w;
+    } else {
+      const float4 l = reinterpret_cast<const float4*>(label)[g];
+      l0 = l.x; l1 = l.y; l2 = l.z; l3 = l.w;
+    }
+    if (wsum) {
+      float4 s = reinterpret_cast<float4*>(wsum)[g];
+      s.x += wi.x; s.y += wi.y; s.z += wi.z; s.w += wi.w;
+      reinterpret_cast<float4*>(wsum)[g] = s;
+    }
+    float4 a = reinterpret_cast<float4*>(wlsum)[g];
+    a.x += wi.x * l0; a.y += wi.y * l1; a.z += wi.z * l2; a.w += wi.w * l3;
+    reinterpret_cast<float4*>(wlsum)[g] = a;
+  }
+  __device__ __forceinline__ void one(size_t i) const {
+    const float wi = w[i];
+    if (wsum) wsum[i] += wi;
+    wlsum[i] += wi * (float)label[i];
+  }
+};
+
+struct op_fuse_divide {
+  const float *wl, *ws;
+  float* out;
+  __device__ __forceinline__ static float f(float a, float s) { return a / (s == 0.0f ? 1.0f : s); }
+  __device__ __forceinline__ void four(size_t g) const {
+    const float4 a = reinterpret_cast<const float4*>(wl)[g], s = reinterpret_cast<const float4*>(ws)[g];
+    reinterpret_cast<float4*>(out)[g] = make_float4(f(a.x, s.x), f(a.y, s.y), f(a.z, s.z), f(a.w, s.w));
+  }
+  __device__ __forceinline__ void one(size_t i) const { out[i] = f(wl[i], ws[i]); }
+};
+
+// itk::RescaleIntensityImageFilter (scale/shift in double, clamped to the output range) then
+// itk::ThresholdImageFilter(lower, upper = 1, outside = 0).
+struct op_rescale_threshold {
+  float* data;
+  double scale, shift;
+  float lower;
+  __device__ __forceinline__ float f(float x) const {
+    double r = (double)x * scale + shift;
+    r = r < 0.0 ? 0.0 : (r > 1.0 ? 1.0 : r);
+    const float v = (float)r;
+    return (v < lower || v > 1.0f) ? 0.0f : v;
+  }
+  __device__ __forceinline__ void four(size_t g) const {
+    const float4 v = reinterpret_cast<float4*>(data)[g];
+    reinterpret_cast<float4*>(data)[g] = make_float4(f(v.x), f(v.y), f(v.z), f(v.w));
+  }
+  __device__ __forceinline__ void one(size_t i) const { data[i] = f(data[i]); }
+};
+
+// sitk image / max (Div functor: fp64 quotient cast to the fp32 pixel) then BinaryThreshold(lower <= pixel).
+struct op_binary_threshold {
+  const float* prob;
+  double max_value, threshold;
+  uint8_t* out;
+  __device__ __forceinline__ uint8_t f(float x) const {
+    const float q = (float)((double)x / max_value);
+    return ((double)q >= threshold) ? (uint8_t)1 : (uint8_t)0;
+  }
+  __device__ __forceinline__ void four(size_t g) const {
+    const float4 v = reinterpret_cast<const float4*>(prob)[g];
+    reinterpret_cast<uchar4*>(out)[g] = make_uchar4(f(v.x), f(v.y), f(v.z), f(v.w));
+  }
+  __device__ __forceinline__ void one(size_t i) const { out[i] = f(prob[i]); }
+};
+
+inline int all_aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+  return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(d)) % 16) == 0;
+}
+// enough blocks to fill 256 CUs x 8 resident blocks; each thread then strides over its share
+template <typename Op>
+void launch_map4(pp_ctx* ctx, size_t n, int vec, const Op& op) {
+  hipLaunchKernelGGL((k_map4<Op>), dim3(grid_for(vec ? (n + 3) / 4 : n, 2048u)), dim3(NT), 0, ctx->stream, n, vec, op);
 }
 
 __global__ void __launch_bounds__(NT) k_ssd_partial(const float* __restrict__ a, const float* __restrict__ b, size_t n,
@@ -54,23 +162,6 @@ __global__ void __launch_bounds__(NT) k_sum_final(const double* __restrict__ par
     pp_block_sum3<NT>(s, z0, z1, red);
     if (threadIdx.x == 0) result[f] = s;
     __syncthreads();
-  }
-}
-
-__global__ void __launch_bounds__(NT) k_fuse_accumulate(const float* __restrict__ w, const uint8_t* __restrict__ label,
-                                                        float* __restrict__ wsum, float* __restrict__ wlsum, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
-    const float wi = w[i];
-    if (wsum) wsum[i] += wi;
-    wlsum[i] += wi * (float)label[i];
-  }
-}
-
-__global__ void __launch_bounds__(NT) k_fuse_divide(const float* __restrict__ wl, const float* __restrict__ ws,
-                                                    float* __restrict__ out, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
-    const float s = ws[i];
-    out[i] = wl[i] / (s == 0.0f ? 1.0f : s);
   }
 }
 
@@ -118,27 +209,6 @@ __global__ void __launch_bounds__(NT) k_minmax_final(const float* __restrict__ p
   if (threadIdx.x == 0) {
     result[0] = smin[0];
     result[1] = smax[0];
-  }
-}
-
-// itk::RescaleIntensityImageFilter (scale/shift in double, clamped to the output range) then
-// itk::ThresholdImageFilter(lower, upper = 1, outside = 0).
-__global__ void __launch_bounds__(NT) k_rescale_threshold(float* __restrict__ data, size_t n, double scale, double shift,
-                                                          float lower) {
-  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
-    double r = (double)data[i] * scale + shift;
-    r = r < 0.0 ? 0.0 : (r > 1.0 ? 1.0 : r);
-    const float v = (float)r;
-    data[i] = (v < lower || v > 1.0f) ? 0.0f : v;
-  }
-}
-
-// sitk image / max (Div functor: fp64 quotient cast to the fp32 pixel) then BinaryThreshold(lower <= pixel).
-__global__ void __launch_bounds__(NT) k_binary_threshold(const float* __restrict__ prob, size_t n, double max_value,
-                                                         double threshold, uint8_t* __restrict__ out) {
-  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
-    const float q = (float)((double)prob[i] / max_value);
-    out[i] = ((double)q >= threshold) ? (uint8_t)1 : (uint8_t)0;
   }
 }
 
@@ -461,22 +531,24 @@ extern "C" {
 int pp_weight_map_local_f32(pp_ctx* ctx, const float* target, const float* moving, const int size[3],
                             const double spacing[3], double sigma, double epsilon, float* weight) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, target && moving && weight && size && spacing, "pp_weight_map_local_f32: NULL argument");
   const size_t N = pp_nvox(size);
   PP_REQUIRE(ctx, N > 0, "pp_weight_map_local_f32: empty volume");
-  hipLaunchKernelGGL(k_sqdiff, dim3(grid_for(N, 65535u)), dim3(NT), 0, ctx->stream, target, moving, weight, N);
-  PP_LAUNCH_CHECK(ctx, "k_sqdiff");
+  launch_map4(ctx, N, all_aligned16(target, moving, weight), op_sqdiff{target, moving, weight});
+  PP_LAUNCH_CHECK(ctx, "k_map4<op_sqdiff>");
   const double var[3] = {sigma * sigma, sigma * sigma, sigma * sigma};
   // sitk.DiscreteGaussian defaults: maximumKernelWidth 32, maximumError 0.01, useImageSpacing True
   int rc = pp_discrete_gaussian_f32(ctx, weight, weight, size, spacing, var, 0.01, 32, 1);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_inv_eps, dim3(grid_for(N, 65535u)), dim3(NT), 0, ctx->stream, weight, N, (float)epsilon);
-  PP_LAUNCH_CHECK(ctx, "k_inv_eps");
+  launch_map4(ctx, N, all_aligned16(weight), op_inv_eps{weight, (float)epsilon});
+  PP_LAUNCH_CHECK(ctx, "k_map4<op_inv_eps>");
   return PP_OK;
 }
 
 int pp_sum_sq_diff_f32(pp_ctx* ctx, const float* a, const float* b, size_t n, double* result) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, a && b && result, "pp_sum_sq_diff_f32: NULL argument");
   const unsigned nb = grid_for(n, 2048u);
   int rc = pp_reserve(ctx, pp_align_up((nb + 1) * sizeof(double), 256));
@@ -491,22 +563,36 @@ int pp_sum_sq_diff_f32(pp_ctx* ctx, const float* a, const float* b, size_t n, do
 
 int pp_fuse_accumulate_u8(pp_ctx* ctx, const float* weight, const uint8_t* label, float* wsum, float* wlsum, size_t n) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, weight && label && wlsum, "pp_fuse_accumulate_u8: NULL argument");
-  hipLaunchKernelGGL(k_fuse_accumulate, dim3(grid_for(n, 65535u)), dim3(NT), 0, ctx->stream, weight, label, wsum, wlsum, n);
-  PP_LAUNCH_CHECK(ctx, "k_fuse_accumulate");
+  // uint8 labels: 4 of them are one 4-byte access (alignment 4 suffices for that array)
+  launch_map4(ctx, n, all_aligned16(weight, wsum, wlsum) && reinterpret_cast<uintptr_t>(label) % 4 == 0,
+              op_fuse_accumulate<uint8_t>{weight, label, wsum, wlsum});
+  PP_LAUNCH_CHECK(ctx, "k_map4<op_fuse_accumulate<u8>>");
+  return PP_OK;
+}
+
+int pp_fuse_accumulate_f32(pp_ctx* ctx, const float* weight, const float* label, float* wsum, float* wlsum, size_t n) {
+  if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
+  PP_REQUIRE(ctx, weight && label && wlsum, "pp_fuse_accumulate_f32: NULL argument");
+  launch_map4(ctx, n, all_aligned16(weight, wsum, wlsum, label), op_fuse_accumulate<float>{weight, label, wsum, wlsum});
+  PP_LAUNCH_CHECK(ctx, "k_map4<op_fuse_accumulate<f32>>");
   return PP_OK;
 }
 
 int pp_fuse_divide_f32(pp_ctx* ctx, const float* wlsum, const float* wsum, float* out, size_t n) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, wlsum && wsum && out, "pp_fuse_divide_f32: NULL argument");
-  hipLaunchKernelGGL(k_fuse_divide, dim3(grid_for(n, 65535u)), dim3(NT), 0, ctx->stream, wlsum, wsum, out, n);
-  PP_LAUNCH_CHECK(ctx, "k_fuse_divide");
+  launch_map4(ctx, n, all_aligned16(wlsum, wsum, out), op_fuse_divide{wlsum, wsum, out});
+  PP_LAUNCH_CHECK(ctx, "k_map4<op_fuse_divide>");
   return PP_OK;
 }
 
 int pp_minmax_f32(pp_ctx* ctx, const float* in, size_t n, float* min_out, float* max_out) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, in && min_out && max_out && n > 0, "pp_minmax_f32: NULL or empty argument");
   const unsigned nb = grid_for(n, 2048u);
   int rc = pp_reserve(ctx, pp_align_up((2 * nb + 2) * sizeof(float), 256));
@@ -526,6 +612,7 @@ int pp_minmax_f32(pp_ctx* ctx, const float* in, size_t n, float* min_out, float*
 
 int pp_rescale_threshold_f32(pp_ctx* ctx, float* data, size_t n, float in_min, float in_max, float lower) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, data, "pp_rescale_threshold_f32: NULL argument");
   // RescaleIntensityImageFilter::BeforeThreadedGenerateData, output range [0, 1]
   double scale;
@@ -533,16 +620,17 @@ int pp_rescale_threshold_f32(pp_ctx* ctx, float* data, size_t n, float in_min, f
   else if (in_max != 0.0f) scale = 1.0 / (double)in_max;
   else scale = 0.0;
   const double shift = 0.0 - (double)in_min * scale;
-  hipLaunchKernelGGL(k_rescale_threshold, dim3(grid_for(n, 65535u)), dim3(NT), 0, ctx->stream, data, n, scale, shift, lower);
-  PP_LAUNCH_CHECK(ctx, "k_rescale_threshold");
+  launch_map4(ctx, n, all_aligned16(data), op_rescale_threshold{data, scale, shift, lower});
+  PP_LAUNCH_CHECK(ctx, "k_map4<op_rescale_threshold>");
   return PP_OK;
 }
 
 int pp_binary_threshold_f32(pp_ctx* ctx, const float* prob, size_t n, double max_value, double threshold, uint8_t* out) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, prob && out, "pp_binary_threshold_f32: NULL argument");
-  hipLaunchKernelGGL(k_binary_threshold, dim3(grid_for(n, 65535u)), dim3(NT), 0, ctx->stream, prob, n, max_value, threshold, out);
-  PP_LAUNCH_CHECK(ctx, "k_binary_threshold");
+  launch_map4(ctx, n, all_aligned16(prob) && reinterpret_cast<uintptr_t>(out) % 4 == 0, op_binary_threshold{prob, max_value, threshold, out});
+  PP_LAUNCH_CHECK(ctx, "k_map4<op_binary_threshold>");
   return PP_OK;
 }
 
@@ -550,6 +638,7 @@ static int metric_affine(pp_ctx* ctx, int mode, const float* fixed, const int fs
                          const double Af[9], const double bf[3], const double Am[9], const double bm[3], const int vsize[3],
                          int stride, const uint8_t* fixed_mask, const uint8_t* moving_mask, double* result) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, fixed && fsize && moving && msize && Af && bf && Am && bm && vsize && result, "metric: NULL argument");
   PP_REQUIRE(ctx, stride >= 1 && vsize[0] >= 1 && vsize[1] >= 1 && vsize[2] >= 1, "metric: bad sampling lattice");
   const int nacc = mode == 0 ? 14 : 42;
@@ -590,6 +679,7 @@ int pp_meansq_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], co
                          const double Af[9], const double bf[3], const double Am[9], const double bm[3],
                          const int vsize[3], int stride, const uint8_t* fixed_mask, const uint8_t* moving_mask,
                          double* result) {
+  pp_device_guard dev_guard_(ctx);
   return metric_affine(ctx, 0, fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask, result);
 }
 
@@ -597,6 +687,7 @@ int pp_corr_moments_affine_f32(pp_ctx* ctx, const float* fixed, const int fsize[
                                const double Af[9], const double bf[3], const double Am[9], const double bm[3],
                                const int vsize[3], int stride, const uint8_t* fixed_mask, const uint8_t* moving_mask,
                                double* result) {
+  pp_device_guard dev_guard_(ctx);
   return metric_affine(ctx, 1, fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask, result);
 }
 
@@ -604,6 +695,7 @@ int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, con
                                 const double Af[9], const double bf[3], int ncand, const double* Am, const double* bm,
                                 const int vsize[3], int stride, const uint8_t* fixed_mask, const uint8_t* moving_mask, double* result) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, fixed && fsize && moving && msize && Af && bf && Am && bm && vsize && result, "metric values: NULL argument");
   PP_REQUIRE(ctx, metric == 0 || metric == 1, "metric values: metric must be 0 (mean squares) or 1 (correlation moments)");
   PP_REQUIRE(ctx, ncand >= 1 && ncand <= PP_MAX_CAND, "metric values: 1..16 candidates per call");

@@ -213,6 +213,7 @@ extern "C" {
 
 int pp_recursive_gaussian_field_f32(pp_ctx* ctx, float* field, const pp_geom* g, const double sigma[3]) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, field && sigma, "pp_recursive_gaussian_field_f32: NULL argument");
   int rc = pp_geom_check(ctx, g, "grid");
   if (rc) return rc;
@@ -227,6 +228,7 @@ int pp_recursive_gaussian_field_f32(pp_ctx* ctx, float* field, const pp_geom* g,
 
 int pp_recursive_gaussian_f32(pp_ctx* ctx, const float* in, float* out, const pp_geom* g, const double sigma[3]) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, in && out && sigma, "pp_recursive_gaussian_f32: NULL argument");
   int rc = pp_geom_check(ctx, g, "grid");
   if (rc) return rc;

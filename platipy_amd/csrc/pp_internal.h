@@ -39,6 +39,22 @@ struct pp_prof_scope {
   ~pp_prof_scope() { if (c->prof) pp_prof_end(c); }
 };
 
+// Every entry point runs with the context's device current (allocations, event creation and launches on the legacy
+// default stream all follow the calling thread's current device) and restores the caller's device on return, so a ctx
+// may be driven from any thread -- a new Python thread starts on device 0 -- without disturbing the caller's state.
+struct pp_device_guard {
+  int prev = -1;
+  bool switched = false;
+  explicit pp_device_guard(const pp_ctx* ctx) {
+    if (ctx && hipGetDevice(&prev) == hipSuccess && prev != ctx->device) switched = (hipSetDevice(ctx->device) == hipSuccess);
+  }
+  ~pp_device_guard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  pp_device_guard(const pp_device_guard&) = delete;
+  pp_device_guard& operator=(const pp_device_guard&) = delete;
+};
+
 int pp_fail(pp_ctx* ctx, int code, const char* fmt, ...);
 // Reserve `bytes` of device scratch (256-B aligned slices are carved by the callers).
 int pp_reserve(pp_ctx* ctx, size_t bytes);

@@ -433,6 +433,7 @@ extern "C" int pp_linear_optimize_f32(pp_ctx* ctx, const float* fixed, const int
                                       const uint8_t* fixed_mask, const uint8_t* moving_mask, const pp_linreg_level* level, double* params,
                                       pp_linreg_stats* stats, double* history, int history_capacity) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, fixed && fsize && moving && msize && level && params, "pp_linear_optimize_f32: NULL argument");
   const int n = model_params(level->model);
   PP_REQUIRE(ctx, n > 0, "pp_linear_optimize_f32: unknown transform model");

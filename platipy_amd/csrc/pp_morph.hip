@@ -150,6 +150,7 @@ int launch(pp_ctx* ctx, const uint8_t* in, const pp_dims& din, uint8_t* out, con
 
 extern "C" int pp_binary_morph_ball_u8(pp_ctx* ctx, const uint8_t* in, const int size[3], const int radius[3], int op, uint8_t* out) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, in && out && size && radius && in != out, "pp_binary_morph_ball_u8: NULL or aliased argument");
   PP_REQUIRE(ctx, size[0] > 0 && size[1] > 0 && size[2] > 0, "pp_binary_morph_ball_u8: empty volume");
   PP_REQUIRE(ctx, op == PP_MORPH_DILATE || op == PP_MORPH_ERODE || op == PP_MORPH_CLOSE, "pp_binary_morph_ball_u8: unknown op");
@@ -173,6 +174,7 @@ extern "C" int pp_binary_morph_ball_u8(pp_ctx* ctx, const uint8_t* in, const int
 
 extern "C" int pp_bounding_box(pp_ctx* ctx, const void* data, int dtype, const int size[3], int box[6]) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, data && size && box, "pp_bounding_box: NULL argument");
   PP_REQUIRE(ctx, size[0] > 0 && size[1] > 0 && size[2] > 0, "pp_bounding_box: empty volume");
   PP_REQUIRE(ctx, dtype == PP_DTYPE_U8 || dtype == PP_DTYPE_F32, "pp_bounding_box: dtype must be PP_DTYPE_U8 or PP_DTYPE_F32");

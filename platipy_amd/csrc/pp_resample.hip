@@ -230,6 +230,7 @@ template <typename T>
 int resample_any(pp_ctx* ctx, const T* in, const pp_geom* gin, const pp_geom* gout, const double* A, const double* t,
                  const float* field, int interp, double default_value, T* out, const char* name) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, in && out, "resample: NULL volume");
   PP_REQUIRE(ctx, (const void*)in != (const void*)out, "resample: in-place is not supported");
   int rc = pp_geom_check(ctx, gin, "input");
@@ -260,6 +261,25 @@ int resample_any(pp_ctx* ctx, const T* in, const pp_geom* gin, const pp_geom* go
   return PP_OK;
 }
 
+// sitk.TransformToDisplacementField for a linear transform q = A p + t (reference deformable.py:101-108), optionally
+// plus a field already expressed on the grid: D(idx) = (A - I) p(idx) + t [+ add(idx)], coordinates in fp64.
+struct pp_affine_disp {
+  double i2p[9], origin[3], AmI[9], t[3];
+};
+__global__ void __launch_bounds__(NT) k_affine_displacement(pp_dims d, pp_affine_disp X, const float* __restrict__ add,
+                                                            float* __restrict__ out) {
+  const size_t N = (size_t)d.nx * d.ny * d.nz;
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < N; i += (size_t)gridDim.x * NT) {
+    const double ix = (double)(i % d.nx), iy = (double)((i / d.nx) % d.ny), iz = (double)(i / ((size_t)d.nx * d.ny));
+    double p[3];
+    for (int r = 0; r < 3; ++r) p[r] = X.origin[r] + X.i2p[r * 3 + 0] * ix + X.i2p[r * 3 + 1] * iy + X.i2p[r * 3 + 2] * iz;
+    for (int r = 0; r < 3; ++r) {
+      const double v = X.AmI[r * 3 + 0] * p[0] + X.AmI[r * 3 + 1] * p[1] + X.AmI[r * 3 + 2] * p[2] + X.t[r];
+      out[r * N + i] = (float)v + (add ? add[r * N + i] : 0.0f);
+    }
+  }
+}
+
 }  // namespace
 
 int pp_warp_same_grid(pp_ctx* ctx, const float* moving, const float* field, const pp_dims& d, const pp_warp_scale& sc,
@@ -281,6 +301,7 @@ extern "C" {
 
 int pp_warp_f32(pp_ctx* ctx, const float* moving, const float* field, const pp_geom* g, float edge_value, float* out) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, moving && field && out, "pp_warp_f32: NULL volume");
   PP_REQUIRE(ctx, moving != out, "pp_warp_f32: in-place is not supported");
   int rc = pp_geom_check(ctx, g, "grid");
@@ -294,16 +315,19 @@ int pp_warp_f32(pp_ctx* ctx, const float* moving, const float* field, const pp_g
 
 int pp_resample_f32(pp_ctx* ctx, const float* in, const pp_geom* gin, const pp_geom* gout, const double* affine_A,
                     const double* affine_t, const float* field, int interp, double default_value, float* out) {
+  pp_device_guard dev_guard_(ctx);
   return resample_any<float>(ctx, in, gin, gout, affine_A, affine_t, field, interp, default_value, out, "k_resample<f32>");
 }
 
 int pp_resample_u8(pp_ctx* ctx, const uint8_t* in, const pp_geom* gin, const pp_geom* gout, const double* affine_A,
                    const double* affine_t, const float* field, int interp, double default_value, uint8_t* out) {
+  pp_device_guard dev_guard_(ctx);
   return resample_any<uint8_t>(ctx, in, gin, gout, affine_A, affine_t, field, interp, default_value, out, "k_resample<u8>");
 }
 
 int pp_resample_field_f32(pp_ctx* ctx, const float* in, const pp_geom* gin, const pp_geom* gout, float* out) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, in && out && in != out, "pp_resample_field_f32: NULL or aliased field");
   int rc = pp_geom_check(ctx, gin, "input");
   if (rc) return rc;
@@ -318,8 +342,30 @@ int pp_resample_field_f32(pp_ctx* ctx, const float* in, const pp_geom* gin, cons
   return PP_OK;
 }
 
+int pp_transform_to_field_f32(pp_ctx* ctx, const pp_geom* g, const double* affine_A, const double* affine_t,
+                              const float* add_field, float* out) {
+  if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
+  PP_REQUIRE(ctx, affine_A && affine_t && out, "pp_transform_to_field_f32: NULL argument");
+  int rc = pp_geom_check(ctx, g, "grid");
+  if (rc) return rc;
+  pp_affine_disp X;
+  // p = origin + Dir * diag(spacing) * idx;  D = (A - I) p + t
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) X.i2p[r * 3 + c] = g->direction[r * 3 + c] * g->spacing[c];
+    X.origin[r] = g->origin[r];
+    for (int c = 0; c < 3; ++c) X.AmI[r * 3 + c] = affine_A[r * 3 + c] - (r == c ? 1.0 : 0.0);
+    X.t[r] = affine_t[r];
+  }
+  const pp_dims d{g->size[0], g->size[1], g->size[2]};
+  hipLaunchKernelGGL(k_affine_displacement, dim3(grid_for(pp_nvox(g->size))), dim3(NT), 0, ctx->stream, d, X, add_field, out);
+  PP_LAUNCH_CHECK(ctx, "k_affine_displacement");
+  return PP_OK;
+}
+
 int pp_compose_field_f32(pp_ctx* ctx, float* total, const float* iter, const pp_geom* g) {
   if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
   PP_REQUIRE(ctx, total && iter && total != iter, "pp_compose_field_f32: NULL or aliased field");
   int rc = pp_geom_check(ctx, g, "grid");
   if (rc) return rc;

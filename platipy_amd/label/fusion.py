@@ -71,6 +71,18 @@ def _normalise(weight, normalise):
     return weight
 
 
+def label_tensor(image):
+    """An atlas label as the fusion kernels take it: uint8 / bool masks stay uint8 (one byte per voxel through HBM);
+    anything else is weighted as sitk.Cast(label, sitkFloat32) weights it (reference fusion.py:269-272) -- a
+    probabilistic label of 0.7 contributes 0.7 w, an int16 label of 256 contributes 256 w."""
+    t = as_image(image).tensor
+    if t.dtype == torch.bool:
+        t = t.to(torch.uint8)
+    elif t.dtype != torch.uint8:
+        t = t.to(torch.float32)
+    return t.contiguous()
+
+
 def _accumulate(ctx, atlas_set, case_ids, label, s_name):
     """Left fold over the atlases, as functools.reduce over sitk images does (:263, :269-276)."""
     first = atlas_set[case_ids[0]][label]["Weight Map"]
@@ -79,9 +91,7 @@ def _accumulate(ctx, atlas_set, case_ids, label, s_name):
     n = wsum.numel()
     for cid in case_ids:
         w = _f32(as_image(atlas_set[cid][label]["Weight Map"]))
-        lab = as_image(atlas_set[cid][label][s_name]).tensor
-        lab = (lab if lab.dtype == torch.uint8 else lab.to(torch.uint8)).contiguous()
-        ctx.fuse_accumulate(w, lab, wsum, wlsum, n)
+        ctx.fuse_accumulate(w, label_tensor(atlas_set[cid][label][s_name]), wsum, wlsum, n)
     return first, wsum, wlsum
 
 

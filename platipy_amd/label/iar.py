@@ -194,7 +194,7 @@ def run_iar_distributed(dd, atlas_set, my_ids, atlas_id_list, reference_structur
     if project_on_sphere:
         raise NotImplementedError("project_on_sphere=True is outside this build's scope (SURVEY 2)")
     from .. import runtime
-    from .fusion import finalize_probability
+    from .fusion import finalize_probability, label_tensor
 
     device = target.device
     ctx = runtime.context(device)
@@ -205,7 +205,7 @@ def run_iar_distributed(dd, atlas_set, my_ids, atlas_id_list, reference_structur
         mine = [i for i in my_ids if i in kept]
         buf = torch.zeros((2,) + tuple(target.shape), dtype=torch.float32, device=device)
         for i in mine:
-            lab = (atlas_set[i][label][reference_structure].tensor != 0).to(torch.float32)
+            lab = label_tensor(atlas_set[i][label][reference_structure]).to(torch.float32)   # the rule combine_labels applies
             buf[0] += float(weights[i])
             buf[1] += float(weights[i]) * lab
         dd.all_reduce_sum(buf)

@@ -26,7 +26,7 @@ import torch
 
 from .. import runtime
 from ..image import as_image
-from ..label.fusion import compute_weight_map, finalize_probability, process_probability_image
+from ..label.fusion import compute_weight_map, finalize_probability, label_tensor, process_probability_image
 from ..registration.deformable import fast_symmetric_forces_demons_registration
 from ..registration.linear import linear_registration
 from ..generation.mask import extend_mask
@@ -353,9 +353,7 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
         w = d["Weight Map"].tensor.contiguous()
         for k, s in enumerate(atlas_structure_list):
             if s in d:
-                lab = d[s].tensor
-                lab = (lab if lab.dtype == torch.uint8 else lab.to(torch.uint8)).contiguous()
-                ctx.fuse_accumulate(w, lab, buf[2 * k], buf[2 * k + 1], n)
+                ctx.fuse_accumulate(w, label_tensor(d[s]), buf[2 * k], buf[2 * k + 1], n)
     dd.all_reduce_sum(buf)
     combined_label_dict = {s: finalize_probability(ctx, img_crop, buf[2 * k], buf[2 * k + 1]) for k, s in enumerate(atlas_structure_list)}
     del buf

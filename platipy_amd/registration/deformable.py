@@ -4,8 +4,8 @@ voxel-level work (pyramids, warps, the demons inner loop, field composition and 
 in the HIP kernels behind include/platipy_amd.h, on fp32 volumes resident in HBM.
 
 Deviations, all deliberate and visible:
-  * the displacement field is fp32 (the reference keeps sitkVectorFloat64); the tolerance against
-    the fp64 restatement is stated and tested in tests/;
+  * the displacement field is computed in fp32 (the reference keeps sitkVectorFloat64); the tolerance against the
+    fp64 restatement is stated and tested in tests/; `field_dtype=torch.float64` returns it in the reference's type;
   * `ncores` is accepted and ignored (it set ITK's CPU thread count);
   * B-spline interpolation (`interp_order=3`) raises NotImplementedError;
   * non-identity direction cosines (axis flips / oblique acquisitions): the registration runs in the image's
@@ -17,10 +17,10 @@ import numpy as np
 import torch
 
 from .. import _lib
-from ..image import Image, as_image, cast_tensor
+from ..image import Image, as_image, cast_tensor, to_sitk
 from .. import runtime
 from ..transform import DisplacementFieldTransform, sitkLinear
-from .utils import resample_field, resample_image, smooth_and_resample
+from .utils import resample_field, resample_image, smooth_and_resample, transform_to_displacement_field
 
 
 class HipDemonsFilter:
@@ -98,6 +98,11 @@ class HipDemonsFilter:
         return self._stats.rms_change if self._stats else float("nan")
 
     def Execute(self, fixed_image, moving_image):
+        """registration_algorithm.Execute(f_image, m_image) (reference deformable.py:149).  Given platipy_amd Images it
+        returns a planar fp32 vector Image in HBM; given SimpleITK images -- the reference's own multiscale_demons calling
+        this filter -- it returns what sitk's filter returns there, a VectorFloat64 sitk.Image on the fixed grid, which
+        the caller's sitk.Resample(dvf_iter, tfm_total) (:154) consumes."""
+        wants_sitk = not isinstance(fixed_image, Image)
         f, m = as_image(fixed_image), as_image(moving_image)
         if f.GetSize() != m.GetSize():
             raise ValueError("demons: fixed and moving image must be on the same grid (reference deformable.py:210-211)")
@@ -122,7 +127,8 @@ class HipDemonsFilter:
         self._stats = ctx.demons_execute(ft, mt, f.geom(), p, field, want_stats=True)
         for fn in self._commands:
             fn()
-        return Image(field, f.spacing, f.origin, f.direction, True)
+        out = Image(field, f.spacing, f.origin, f.direction, True)
+        return to_sitk(out) if wants_sitk else out
 
 
 def multiscale_demons(registration_algorithm, fixed_image, moving_image, initial_transform=None,
@@ -145,9 +151,11 @@ def multiscale_demons(registration_algorithm, fixed_image, moving_image, initial
 
     if initial_displacement_field is None:
         if initial_transform is not None:
-            raise NotImplementedError("initial_transform: pass initial_displacement_field instead")
-        dvf_total = Image(torch.zeros((3,) + fixed_image.shape, dtype=torch.float32, device=fixed_image.device),
-                          fixed_image.spacing, fixed_image.origin, fixed_image.direction, True)
+            # :101-108 -- sitk.TransformToDisplacementField(initial_transform, VectorFloat64, fixed grid)
+            dvf_total = transform_to_displacement_field(initial_transform, fixed_image)
+        else:
+            dvf_total = Image(torch.zeros((3,) + fixed_image.shape, dtype=torch.float32, device=fixed_image.device),
+                              fixed_image.spacing, fixed_image.origin, fixed_image.direction, True)
     else:
         dvf_total = resample_field(as_image(initial_displacement_field), fixed_image)
 
@@ -179,11 +187,14 @@ def fast_symmetric_forces_demons_registration(
     interp_order=sitkLinear,
     verbose=False,
     variant="auto",
+    field_dtype=torch.float32,
 ):
     """Deformable image propagation using Fast Symmetric-Forces Demons (reference deformable.py:190-306).
 
-    Returns (registered_image, output_transform, deformation_field), the field as a planar fp32 vector
-    Image on the fixed grid.  `variant` ("auto" | "fused" | "staged") picks the kernel schedule."""
+    Returns (registered_image, output_transform, deformation_field), the field as a planar vector Image on the
+    fixed grid.  The field is computed in fp32; `field_dtype=torch.float64` returns it as the reference does
+    (sitkVectorFloat64, :97-98, :159 -- twice the memory, same values).  `variant` ("auto" | "fused" | "staged") picks
+    the kernel schedule."""
     fixed_image, moving_image = as_image(fixed_image), as_image(moving_image)
     moving_image_type = moving_image.tensor.dtype
     fixed_image = fixed_image.astype(torch.float32)    # :236-241 (quirk N1: everything computes in float32)
@@ -194,14 +205,23 @@ def fast_symmetric_forces_demons_registration(
     if true_direction != identity:
         if moving_image.direction != true_direction:
             raise NotImplementedError("demons: fixed and moving image must share their direction cosines")
-        # work in the index-aligned frame: q_local = R^T (q - origin) + origin keeps every index map unchanged
+        # work in the fixed image's index-aligned frame, q_local = R^T (q - o_f) + o_f: every index map is unchanged, and
+        # an image whose own origin differs from the fixed one's sits at R^T (o - o_f) + o_f there
+        Rm = np.asarray(true_direction, dtype=np.float64).reshape(3, 3)
+        o_f = np.asarray(fixed_image.origin, dtype=np.float64)
+
+        def local_origin(o):
+            return tuple(Rm.T @ (np.asarray(o, dtype=np.float64) - o_f) + o_f)
+
+        moving_image = Image(moving_image.tensor, moving_image.spacing, local_origin(moving_image.origin), identity)
         fixed_image = Image(fixed_image.tensor, fixed_image.spacing, fixed_image.origin, identity)
-        moving_image = Image(moving_image.tensor, moving_image.spacing, moving_image.origin, identity)
         if initial_displacement_field is not None:
             f0 = as_image(initial_displacement_field)
+            if f0.direction != true_direction:
+                raise NotImplementedError("demons: the initial displacement field must share the images' direction cosines")
             Rt = torch.tensor(true_direction, dtype=torch.float32, device=f0.device).reshape(3, 3).t()
             initial_displacement_field = Image(torch.einsum("rc,czyx->rzyx", Rt, f0.tensor.float()).contiguous(), f0.spacing,
-                                               f0.origin, identity, True)
+                                               local_origin(f0.origin), identity, True)
 
     registration_method = HipDemonsFilter(variant=variant)
     registration_method.SetNumberOfThreads(ncores)
@@ -234,4 +254,7 @@ def fast_symmetric_forces_demons_registration(
         deformation_field = Image(phys, deformation_field.spacing, deformation_field.origin, true_direction, True)
         output_transform = DisplacementFieldTransform(deformation_field)
         registered_image = Image(registered_image.tensor, registered_image.spacing, registered_image.origin, true_direction)
+    if field_dtype != torch.float32:
+        deformation_field = deformation_field.like(deformation_field.tensor.to(field_dtype), True)
+        output_transform = DisplacementFieldTransform(deformation_field)
     return registered_image, output_transform, deformation_field

@@ -53,6 +53,23 @@ def _split_transform(transform, reference):
     return A, off, f
 
 
+def transform_to_displacement_field(transform, reference):
+    """sitk.TransformToDisplacementField(transform, sitkVectorFloat64, reference grid) (reference deformable.py:101-108):
+    D(p) = T(p) - p as a planar fp32 vector Image on `reference`'s grid.  Linear transforms, a displacement-field
+    transform, or a composite of linear members whose last-listed (first-applied) member is a displacement field."""
+    reference = as_image(reference)
+    ctx = runtime.context(reference.device)
+    A, off, field = _split_transform(transform, reference)
+    out = torch.empty((3,) + reference.shape, dtype=torch.float32, device=reference.device)
+    if A is None and field is None:
+        out.zero_()
+    elif A is None:
+        out.copy_(field)
+    else:
+        ctx.transform_to_field(reference.geom(), A, off, field, out)
+    return Image(out, reference.spacing, reference.origin, reference.direction, True)
+
+
 def resample_field(field_image, reference):
     """sitk.Resample(vector_image, reference): linear, identity transform, default 0."""
     ctx = runtime.context(field_image.device)

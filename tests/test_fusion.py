@@ -126,3 +126,22 @@ def test_overlap_correction_and_distance_map_helpers(host_api):
     assert lc.max() == 1 and (lc <= c).all()
     closed = pa.label.utils.binary_morphological_closing(imgs["A"], [1, 1, 1]).numpy()
     np.testing.assert_array_equal(closed, O.binary_closing_ball(O.Vol(a.astype(np.uint8), SPACING, ORIGIN), [1, 1, 1]).arr)
+
+
+def test_combine_labels_weights_float_and_wide_integer_labels_as_float32(host_api):
+    """The reference casts every label to sitkFloat32 before weighting (label/fusion.py:269-272): a probabilistic label of
+    0.7 contributes 0.7 w and an int16 label of 256 contributes 256 w -- neither is squeezed through uint8."""
+    pa = host_api
+    rng = np.random.default_rng(3)
+    shape, sp = (6, 9, 10), (1.0, 1.0, 1.0)
+    w = [rng.uniform(0.5, 2.0, shape).astype(np.float32) for _ in range(2)]
+    soft = [rng.uniform(0.0, 1.0, shape).astype(np.float32) for _ in range(2)]
+    aset = {f"{k}": {"DIR": {"Weight Map": pa.image_from_array(w[k], sp), "S": pa.image_from_array(soft[k], sp)}} for k in range(2)}
+    got = pa.label.combine_labels(aset, "S", threshold=0.0, smooth_sigma=1e-3)["S"].numpy()
+    want = (w[0] * soft[0] + w[1] * soft[1]) / (w[0] + w[1])
+    want = (want - want.min()) / (want.max() - want.min())          # RescaleIntensity(0, 1)
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-6)
+    wide = [np.where(rng.uniform(size=shape) > 0.5, 256, 0).astype(np.int16) for _ in range(2)]
+    aset = {f"{k}": {"DIR": {"Weight Map": pa.image_from_array(w[k], sp), "S": pa.image_from_array(wide[k], sp)}} for k in range(2)}
+    got = pa.label.combine_labels(aset, "S", threshold=0.0, smooth_sigma=1e-3)["S"].numpy()
+    assert got.max() == 1.0 and (got > 0).mean() > 0.5            # 256 did not wrap to 0

@@ -196,3 +196,68 @@ def test_demons_registration_with_direction_cosines(host_api):
     m1 = pa.registration.apply_transform(pa.image_from_array(mask, spacing, origin, tuple(R.ravel())), transform=t1,
                                          interpolator=pa.sitkNearestNeighbor)
     assert (m0.numpy() != m1.numpy()).mean() < 2e-3   # fp32 rotation of the field near voxel boundaries
+
+
+def test_initial_transform_and_fp64_field(host_api):
+    """multiscale_demons(initial_transform=...) starts from sitk.TransformToDisplacementField(T) (reference
+    deformable.py:101-108): for a linear T that is D(p) = (A - I) p + t on the fixed grid; and the drop-in returns the
+    field in the reference's type (sitkVectorFloat64) on request, with the fp32 values."""
+    pa = host_api
+    from platipy_amd.registration.utils import transform_to_displacement_field
+
+    shape, spacing, origin = (10, 14, 18), (1.0, 1.2, 2.0), (5.0, -3.0, 1.0)
+    ang = 0.04
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+    T = pa.AffineTransform(R * 1.02, (1.5, -0.7, 0.4), (12.0, 8.0, 9.0))
+    ref = pa.image_from_array(np.zeros(shape, np.float32), spacing, origin)
+    d = transform_to_displacement_field(T, ref)
+    assert d.is_vector and d.GetSize() == ref.GetSize()
+    zz, yy, xx = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing="ij")
+    P = np.stack([origin[0] + xx * spacing[0], origin[1] + yy * spacing[1], origin[2] + zz * spacing[2]])
+    A, off = T.matrix_offset()
+    want = np.einsum("rc,czyx->rzyx", A - np.eye(3), P) + off[:, None, None, None]
+    np.testing.assert_allclose(d.numpy(), want, rtol=0, atol=2e-5)
+    # a composite [linear, field]: q = A (p + F(p)) + off  ->  D = (A - I) p + off + A F
+    F = random_dvf(shape, spacing, seed=3, max_mm=2.0)
+    comp = pa.CompositeTransform([T, pa.DisplacementFieldTransform(pa.image_from_array(F, spacing, origin, is_vector=True))])
+    dc = transform_to_displacement_field(comp, ref).numpy()
+    np.testing.assert_allclose(dc, want + np.einsum("rc,czyx->rzyx", A, F.astype(np.float64)), rtol=0, atol=3e-5)
+    # through the registration: an initial translation is where the loop starts from
+    fix, mov = _pair(shape, spacing, origin, seed=400, max_mm=1.0)
+    shift = pa.AffineTransform(np.eye(3), (0.6, 0.0, 0.0))
+    flt = pa.registration.HipDemonsFilter()
+    flt.SetSmoothUpdateField(True)
+    kw = dict(registration_algorithm=flt, fixed_image=pa.image_from_array(fix, spacing, origin), moving_image=pa.image_from_array(mov, spacing, origin),
+              resolution_staging=[1], smoothing_sigmas=[0], iteration_staging=[0])
+    start = pa.registration.multiscale_demons(initial_transform=shift, **kw).numpy()     # zero iterations: only the level regulariser acts
+    assert abs(np.median(start[0]) - 0.6) < 1e-3 and np.abs(start[1:]).max() < 1e-3
+    img, tfm, dvf64 = pa.registration.fast_symmetric_forces_demons_registration(pa.image_from_array(fix, spacing, origin),
+                                                                                pa.image_from_array(mov, spacing, origin),
+                                                                                resolution_staging=[2, 1], iteration_staging=[3, 3],
+                                                                                field_dtype=torch.float64)
+    _, _, dvf32 = pa.registration.fast_symmetric_forces_demons_registration(pa.image_from_array(fix, spacing, origin),
+                                                                            pa.image_from_array(mov, spacing, origin),
+                                                                            resolution_staging=[2, 1], iteration_staging=[3, 3])
+    assert dvf64.tensor.dtype == torch.float64 and tfm.GetDisplacementField().tensor.dtype == torch.float64
+    np.testing.assert_array_equal(dvf64.numpy(), dvf32.numpy().astype(np.float64))
+
+
+def test_demons_oriented_images_with_different_origins(host_api):
+    """Non-identity direction cosines and a moving image whose origin differs from the fixed one's: in the fixed image's
+    index-aligned frame the moving grid sits at R^T (o_m - o_f) + o_f, so the run equals the identity-direction run on
+    arrays whose origins differ by that local offset."""
+    pa = host_api
+    shape, spacing = (12, 18, 26), (1.0, 1.2, 2.0)
+    fix, mov = _pair(shape, spacing, (0.0, 0.0, 0.0), seed=500, max_mm=1.5)
+    ang = 0.3
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+    o_f = np.array([3.0, -4.0, 5.0])
+    local_shift = np.array([1.2, 0.0, 2.0])                   # whole voxels of the grid: (1, 0, 1)
+    o_m = o_f + R @ local_shift
+    kw = dict(resolution_staging=[2, 1], iteration_staging=[3, 3])
+    i1, _, d1 = pa.registration.fast_symmetric_forces_demons_registration(pa.image_from_array(fix, spacing, tuple(o_f), tuple(R.ravel())),
+                                                                          pa.image_from_array(mov, spacing, tuple(o_m), tuple(R.ravel())), **kw)
+    i0, _, d0 = pa.registration.fast_symmetric_forces_demons_registration(pa.image_from_array(fix, spacing, tuple(o_f)),
+                                                                          pa.image_from_array(mov, spacing, tuple(o_f + local_shift)), **kw)
+    np.testing.assert_array_equal(i1.numpy(), i0.numpy())
+    np.testing.assert_allclose(d1.numpy(), np.einsum("rc,czyx->rzyx", R, d0.numpy().astype(np.float64)), rtol=0, atol=1e-5)

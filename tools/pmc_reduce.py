@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""Reduce a pmc_summary.py table to calibrated HBM-side bytes per launch (-> profiles/roundN_pmc.json, read by bench.py).
+
+usage: pmc_reduce.py <pmc_counters.md> <commit> nx ny nz
+Calibration (MI355X_MICROARCH.md, HBM section): two kernels of the same run with known byte counts -- torch's
+elementwise add (16 B/lane: reads 12 N, writes 12 N bytes) and k_fuse_divide (4 B/lane: reads 24 N, writes 12 N) --
+give the factor that turns FETCH_SIZE / WRITE_SIZE (KiB) into bytes for each access width; the fused kernels use the
+16-B factor for reads when both agree within 5 % (they did: 2.0), otherwise the larger one (an upper bound)."""
+import json
+import re
+import sys
+
+md, commit, nx, ny, nz = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+n = nx * ny * nz
+tab = {}
+for line in open(md):
+    m = re.match(r"\| (\S.*?) \| (\S+) \| (\d+) \| (\S+) \|", line)
+    if m and m.group(2) != "counter":
+        tab.setdefault(m.group(1), {})[m.group(2)] = float(m.group(4))
+cal = {}
+if "torch.add(scalar)" in tab and "FETCH_SIZE" in tab["torch.add(scalar)"]:
+    cal["fetch_16B"] = 12.0 * n / (tab["torch.add(scalar)"]["FETCH_SIZE"] * 1024)
+    cal["write_16B"] = 12.0 * n / (tab["torch.add(scalar)"]["WRITE_SIZE"] * 1024)
+if "k_fuse_divide" in tab and "FETCH_SIZE" in tab["k_fuse_divide"]:
+    cal["fetch_4B"] = 24.0 * n / (tab["k_fuse_divide"]["FETCH_SIZE"] * 1024)
+    cal["write_4B"] = 12.0 * n / (tab["k_fuse_divide"]["WRITE_SIZE"] * 1024)
+ff = max(cal.get("fetch_16B", 2.0), cal.get("fetch_4B", 2.0))
+fw = max(cal.get("write_16B", 1.0), cal.get("write_4B", 1.0))
+out = {"commit": commit, "size": [nx, ny, nz], "raw": md.replace("gpurun_out/r2/", "profiles/round2_"), "calibration": cal,
+       "fetch_factor": ff, "write_factor": fw, "hbm_bytes_per_launch": {}, "fetch_bytes_per_launch": {}, "write_bytes_per_launch": {},
+       "tcc_hit_rate": {}}
+for k, c in tab.items():
+    if not k.startswith("k_fused") and not k.startswith("k_warp") and not k.startswith("k_demons_force") and not k.startswith("k_conv"):
+        continue
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        out["fetch_bytes_per_launch"][k] = c["FETCH_SIZE"] * 1024 * ff
+        out["write_bytes_per_launch"][k] = c["WRITE_SIZE"] * 1024 * fw
+        out["hbm_bytes_per_launch"][k] = out["fetch_bytes_per_launch"][k] + out["write_bytes_per_launch"][k]
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        out["tcc_hit_rate"][k] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+print(json.dumps(out, indent=1))
