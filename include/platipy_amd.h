@@ -269,12 +269,37 @@ int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, con
                                 const int vsize[3], int stride, const uint8_t* fixed_mask,
                                 const uint8_t* moving_mask, double* result);
 
+/* Mutual-information metrics (SetMetricAsMattesMutualInformation / SetMetricAsJointHistogramMutualInformation,
+ * registration/linear.py:145-148) over the same sample lattice: pass 1 returns the joint intensity histogram of the valid
+ * sample pairs (row = fixed bin; 64-bit fixed-point accumulation, independent of scheduling) and their count; the caller
+ * turns it into PDFs, the value and a per-bin score table; pass 2 returns sum_s w_s g_s v_q / sum_s w_s g_s in the
+ * d/dAm (9), d/dbm (3) layout of pp_meansq_affine_f32 with w_s = sum_k dkernel_k(s) table[f_bin(s)][k].
+ * bin coordinate of an intensity = value / *_bin - *_norm_min.  PP_MI_MATTES: fixed nearest bin, moving cubic B-spline
+ * over 4 bins, both clamped to [2, nbins - 3] (itk::MattesMutualInformationImageToImageMetricv4); PP_MI_JOINT: nearest
+ * bins, the score differenced between the two neighbouring moving-bin centres. */
+enum { PP_MI_MATTES = 0, PP_MI_JOINT = 1 };
+typedef struct pp_mi_bins {
+  int nbins;                 /* <= 64 */
+  int kernel;                /* PP_MI_* */
+  double f_bin, f_norm_min;  /* fixed:  bin width, normalised minimum */
+  double m_bin, m_norm_min;  /* moving */
+} pp_mi_bins;
+int pp_mi_histogram_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], const float* moving, const int msize[3],
+                        const double Af[9], const double bf[3], const double Am[9], const double bm[3],
+                        const int vsize[3], int stride, const uint8_t* fixed_mask, const uint8_t* moving_mask,
+                        const pp_mi_bins* bins, double* hist, double* count);
+int pp_mi_gradient_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], const float* moving, const int msize[3],
+                       const double Af[9], const double bf[3], const double Am[9], const double bm[3],
+                       const int vsize[3], int stride, const uint8_t* fixed_mask, const uint8_t* moving_mask,
+                       const pp_mi_bins* bins, const double* table, double* result);
+
 /* One resolution level of linear_registration's optimisation (what registration.Execute does inside a level,
  * registration/linear.py:129-238): ITK v4 gradient descent (optionally with the golden-section line search) on
  * the mean-squares or correlation metric above, parameter scales from physical shift, learning rate estimated
  * once, convergence window 10 / 1e-6, best point kept.  Host logic in the library, metric on the GPU. */
 enum { PP_MODEL_TRANSLATION = 0, PP_MODEL_VERSOR_RIGID = 1, PP_MODEL_SIMILARITY = 2, PP_MODEL_SCALE = 3,
-       PP_MODEL_AFFINE = 4, PP_MODEL_EULER = 5 };       /* sitk parameter layouts; 3/6/7/3/12/6 parameters */
+       PP_MODEL_AFFINE = 4, PP_MODEL_EULER = 5, PP_MODEL_SCALE_VERSOR = 6,
+       PP_MODEL_SCALE_SKEW_VERSOR = 7 };                 /* sitk parameter layouts; 3/6/7/3/12/6/9/15 parameters */
 enum { PP_OPT_GD = 0, PP_OPT_GD_LINE_SEARCH = 1 };
 enum { PP_LINREG_STOP_ITERATIONS = 0, PP_LINREG_STOP_CONVERGED = 1, PP_LINREG_STOP_NO_OVERLAP = 2 };
 typedef struct pp_linreg_level {

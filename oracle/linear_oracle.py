@@ -92,3 +92,70 @@ def corr_moments_affine(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask
     out[18:30] = (f[:, None] * terms).sum(0)
     out[30:42] = (m[:, None] * terms).sum(0)
     return out
+
+
+# --------------------------------------------------------------------------------------
+# mutual information (reference linear.py:145-148: SetMetricAsMattesMutualInformation / ...JointHistogramMutualInformation)
+
+
+def _bspline3(u):
+    a = np.abs(u)
+    return np.where(a < 1.0, (4.0 - 6.0 * a * a + 3.0 * a ** 3) / 6.0, np.where(a < 2.0, (2.0 - a) ** 3 / 6.0, 0.0))
+
+
+def _bspline3_deriv(u):
+    a, sg = np.abs(u), np.where(u < 0.0, -1.0, 1.0)
+    return np.where(a < 1.0, sg * (-2.0 * a + 1.5 * a * a), np.where(a < 2.0, sg * (-0.5 * (2.0 - a) ** 2), 0.0))
+
+
+def _mi_samples(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask):
+    Af, Am = np.asarray(Af, dtype=np.float64).reshape(3, 3), np.asarray(Am, dtype=np.float64).reshape(3, 3)
+    bf, bm = np.asarray(bf, dtype=np.float64), np.asarray(bm, dtype=np.float64)
+    nv = int(vsize[0]) * int(vsize[1]) * int(vsize[2])
+    lin = np.arange(0, nv, int(stride), dtype=np.int64)
+    v = np.stack([lin % vsize[0], (lin // vsize[0]) % vsize[1], lin // (vsize[0] * vsize[1])], axis=1).astype(np.float64)
+    cf, cm = v @ Af.T + bf, v @ Am.T + bm
+    inf_, fval, _ = _sample(np.asarray(fixed), cf)
+    inm, mval, g = _sample(np.asarray(moving), cm)
+    ok = inf_ & inm
+    if fixed_mask is not None:
+        ok &= np.where(inf_, _nn_mask(np.asarray(fixed_mask), np.where(inf_[:, None], cf, 0.0)), False)
+    if moving_mask is not None:
+        ok &= np.where(inm, _nn_mask(np.asarray(moving_mask), np.where(inm[:, None], cm, 0.0)), False)
+    # the kernel interpolates in fp32
+    return v[ok], fval[ok].astype(np.float32).astype(np.float64), mval[ok].astype(np.float32).astype(np.float64), g[ok]
+
+
+def _mi_bins(val, width, norm_min, lo, hi):
+    term = val / width - norm_min
+    return np.clip(np.floor(term).astype(np.int64), lo, hi), term
+
+
+def mi_histogram(fixed, moving, Af, bf, Am, bm, vsize, stride, bins, fixed_mask=None, moving_mask=None):
+    """bins: dict(nbins, kernel (0 Mattes / 1 joint), f_bin, f_norm_min, m_bin, m_norm_min) -> (hist [nb, nb], count)."""
+    v, f, m, _ = _mi_samples(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask)
+    nb, pad = int(bins["nbins"]), (2 if bins["kernel"] == 0 else 0)
+    fb, _ = _mi_bins(f, bins["f_bin"], bins["f_norm_min"], pad, nb - 1 - pad)
+    mb, tm = _mi_bins(m, bins["m_bin"], bins["m_norm_min"], pad, nb - 1 - pad)
+    hist = np.zeros((nb, nb))
+    if bins["kernel"] == 0:
+        for d in (-1, 0, 1, 2):
+            np.add.at(hist, (fb, mb + d), _bspline3((mb + d) - tm))
+    else:
+        np.add.at(hist, (fb, mb), 1.0)
+    return hist, float(len(f))
+
+
+def mi_gradient(fixed, moving, Af, bf, Am, bm, vsize, stride, bins, table, fixed_mask=None, moving_mask=None):
+    v, f, m, g = _mi_samples(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask)
+    nb, pad = int(bins["nbins"]), (2 if bins["kernel"] == 0 else 0)
+    tab = np.asarray(table, dtype=np.float64).astype(np.float32).astype(np.float64)
+    fb, _ = _mi_bins(f, bins["f_bin"], bins["f_norm_min"], pad, nb - 1 - pad)
+    mb, tm = _mi_bins(m, bins["m_bin"], bins["m_norm_min"], pad, nb - 1 - pad)
+    if bins["kernel"] == 0:
+        w = sum(_bspline3_deriv((mb + d) - tm) * tab[fb, mb + d] for d in (-1, 0, 1, 2))
+    else:
+        k0 = np.clip(np.floor(tm - 0.5).astype(np.int64), 0, nb - 2)
+        w = tab[fb, k0 + 1] - tab[fb, k0]
+    gw = g.astype(np.float32).astype(np.float64) * w[:, None]
+    return np.concatenate([(gw[:, :, None] * v[:, None, :]).sum(0).ravel(), gw.sum(0)])

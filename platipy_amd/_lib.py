@@ -25,6 +25,15 @@ class Geom(C.Structure):
                 ("direction", C.c_double * 9)]
 
 
+class MiBins(C.Structure):
+    """pp_mi_bins"""
+    _fields_ = [("nbins", C.c_int), ("kernel", C.c_int), ("f_bin", C.c_double), ("f_norm_min", C.c_double), ("m_bin", C.c_double),
+                ("m_norm_min", C.c_double)]
+
+
+MI_MATTES, MI_JOINT = 0, 1
+
+
 class LinregLevel(C.Structure):     # pp_linreg_level
     _fields_ = [("model", C.c_int), ("metric", C.c_int), ("optimizer", C.c_int), ("iterations", C.c_int), ("vsize", C.c_int * 3),
                 ("stride", C.c_int), ("speculation", C.c_int), ("reserved", C.c_int),
@@ -39,7 +48,7 @@ class LinregStats(C.Structure):     # pp_linreg_stats
 
 
 ERR_NO_OVERLAP = -6
-MODEL_TRANSLATION, MODEL_VERSOR_RIGID, MODEL_SIMILARITY, MODEL_SCALE, MODEL_AFFINE, MODEL_EULER = range(6)
+MODEL_TRANSLATION, MODEL_VERSOR_RIGID, MODEL_SIMILARITY, MODEL_SCALE, MODEL_AFFINE, MODEL_EULER, MODEL_SCALE_VERSOR, MODEL_SCALE_SKEW_VERSOR = range(8)
 OPT_GD, OPT_GD_LINE_SEARCH = 0, 1
 
 
@@ -132,6 +141,12 @@ _SIGNATURES = {
     "pp_metric_values_affine_f32": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                               C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                               C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(C.c_double)]),
+    "pp_mi_histogram_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(MiBins),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "pp_mi_gradient_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(MiBins),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pp_linear_num_parameters": (C.c_int, [C.c_int]),
     "pp_linear_optimize_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), _P, _P, C.POINTER(LinregLevel),
                                          C.POINTER(C.c_double), C.POINTER(LinregStats), C.POINTER(C.c_double), C.c_int]),
@@ -428,6 +443,24 @@ class Context:
             err.code = rc
             raise err
         return [p[i] for i in range(n)], st, [hist[i] for i in range(min(int(history), st.iterations))]
+
+    def mi_histogram(self, fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, bins, fixed_mask=None, moving_mask=None):
+        """Joint intensity histogram of the valid sample pairs -> (hist [nbins, nbins] float64, row = fixed bin; count)."""
+        hist = np.zeros((bins.nbins, bins.nbins), dtype=np.float64)
+        count = C.c_double()
+        self._chk(self.lib.pp_mi_histogram_f32(self.h, ptr(fixed), _i3(fsize), ptr(moving), _i3(msize), _dn(Af, 9), _dn(bf, 3), _dn(Am, 9),
+                                               _dn(bm, 3), _i3(vsize), int(stride), ptr(fixed_mask), ptr(moving_mask), C.byref(bins),
+                                               hist.ctypes.data_as(C.POINTER(C.c_double)), C.byref(count)), "pp_mi_histogram_f32")
+        return hist, count.value
+
+    def mi_gradient(self, fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, bins, table, fixed_mask=None, moving_mask=None):
+        """sum_s w_s g_s (v_q | 1) with w_s from the score `table` [nbins, nbins] -> 12 floats (d/dAm row-major 9, d/dbm 3)."""
+        tab = np.ascontiguousarray(table, dtype=np.float64)
+        res = (C.c_double * 12)()
+        self._chk(self.lib.pp_mi_gradient_f32(self.h, ptr(fixed), _i3(fsize), ptr(moving), _i3(msize), _dn(Af, 9), _dn(bf, 3), _dn(Am, 9),
+                                              _dn(bm, 3), _i3(vsize), int(stride), ptr(fixed_mask), ptr(moving_mask), C.byref(bins),
+                                              tab.ctypes.data_as(C.POINTER(C.c_double)), res), "pp_mi_gradient_f32")
+        return np.array([res[i] for i in range(12)])
 
     def corr_moments_affine(self, fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None):
         """-> the 42 raw moments of pp_corr_moments_affine_f32."""

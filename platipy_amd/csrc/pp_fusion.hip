@@ -7,6 +7,8 @@
 // derivative for registration/linear.py:141-148,238.  Everything is a streaming elementwise
 // pass or a reduction (HBM-bound); reductions write per-block partials that a second, single
 // block folds in a fixed order, so results do not depend on scheduling.
+#include <vector>
+
 #include "pp_internal.h"
 #include "pp_kernels.h"
 
@@ -524,6 +526,195 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
   }
 }
 
+
+// ---- mutual-information metrics (linear.py:145-148: mattes_mi, joint_hist_mi) -------------------------------
+// Two passes over the same sample lattice as the metrics above.  Pass 1 builds the joint intensity histogram of the
+// sample pairs: per block in LDS, in 64-bit fixed point (2^-32 units) so that the sum is associative and the result
+// does not depend on scheduling, then one 64-bit atomic per non-empty bin into the global table.  The host turns it into
+// PDFs, the metric value and a per-bin score table (log-ratio of the PDFs: host arithmetic on <= 64 x 64 numbers).  Pass 2
+// weights every sample's interpolant gradient by its score derivative: sum_k dkernel_k(sample) * table[f_bin][k].
+// PP_MI_MATTES: fixed intensity to its nearest bin, moving intensity spread over 4 bins with a cubic B-spline Parzen
+// window (itk::MattesMutualInformationImageToImageMetricv4); PP_MI_JOINT: both to their nearest bin, score differenced
+// between the two neighbouring moving-bin centres (joint-histogram MI; the PDF smoothing is the host's).
+constexpr int MI_MAX_BINS = 64;
+struct mi_args {
+  double Af[9], bf[3], Am[9], bm[3];
+  int vsize[3];
+  int stride;
+  int nbins, kernel;
+  double f_bin, f_norm_min, m_bin, m_norm_min;
+};
+
+__device__ __forceinline__ double mi_bspline3(double u) {   // cubic B-spline, support (-2, 2)
+  const double a = fabs(u);
+  if (a < 1.0) return (4.0 - 6.0 * a * a + 3.0 * a * a * a) / 6.0;
+  if (a < 2.0) { const double t = 2.0 - a; return t * t * t / 6.0; }
+  return 0.0;
+}
+__device__ __forceinline__ double mi_bspline3_deriv(double u) {
+  const double a = fabs(u), sg = u < 0.0 ? -1.0 : 1.0;
+  if (a < 1.0) return sg * (-2.0 * a + 1.5 * a * a);
+  if (a < 2.0) { const double t = 2.0 - a; return sg * (-0.5 * t * t); }
+  return 0.0;
+}
+
+// -> valid; f / m values (trilinear), moving interpolant gradient (moving index units), virtual index v
+__device__ __forceinline__ bool mi_sample(const float* __restrict__ F, const pp_dims& df, const float* __restrict__ M, const pp_dims& dm,
+                                          const uint8_t* __restrict__ fmask, const uint8_t* __restrict__ mmask, const mi_args& a, size_t e,
+                                          double v[3], float& fval, float& mval, float g[3]) {
+  const size_t lin = e * (size_t)a.stride;
+  v[0] = (double)(lin % a.vsize[0]);
+  v[1] = (double)((lin / a.vsize[0]) % a.vsize[1]);
+  v[2] = (double)(lin / ((size_t)a.vsize[0] * a.vsize[1]));
+  double cf[3], cm[3];
+  for (int r = 0; r < 3; ++r) {
+    cf[r] = a.Af[r * 3 + 0] * v[0] + a.Af[r * 3 + 1] * v[1] + a.Af[r * 3 + 2] * v[2] + a.bf[r];
+    cm[r] = a.Am[r * 3 + 0] * v[0] + a.Am[r * 3 + 1] * v[1] + a.Am[r * 3 + 2] * v[2] + a.bm[r];
+  }
+  int bf_[3], bm_[3];
+  float ff[3], fm[3];
+  if (!msq_locate(cf, df, bf_, ff) || !msq_locate(cm, dm, bm_, fm)) return false;
+  if (fmask) {
+    const int qx = (int)floor(cf[0] + 0.5), qy = (int)floor(cf[1] + 0.5), qz = (int)floor(cf[2] + 0.5);
+    if (!fmask[((size_t)qz * df.ny + qy) * df.nx + qx]) return false;
+  }
+  if (mmask) {
+    const int qx = (int)floor(cm[0] + 0.5), qy = (int)floor(cm[1] + 0.5), qz = (int)floor(cm[2] + 0.5);
+    if (!mmask[((size_t)qz * dm.ny + qy) * dm.nx + qx]) return false;
+  }
+  fval = pp_trilinear(F, df.nx, df.ny, df.nz, bf_[0], ff[0], bf_[1], ff[1], bf_[2], ff[2]);
+  int x0, x1, y0, y1, z0, z1;
+  float wx, wy, wz;
+  pp_axis_setup(bm_[0], fm[0], dm.nx, x0, x1, wx);
+  pp_axis_setup(bm_[1], fm[1], dm.ny, y0, y1, wy);
+  pp_axis_setup(bm_[2], fm[2], dm.nz, z0, z1, wz);
+  const size_t sy = dm.nx, sz = (size_t)dm.nx * dm.ny;
+  const float a000 = M[z0 * sz + y0 * sy + x0], a100 = M[z0 * sz + y0 * sy + x1];
+  const float a010 = M[z0 * sz + y1 * sy + x0], a110 = M[z0 * sz + y1 * sy + x1];
+  const float a001 = M[z1 * sz + y0 * sy + x0], a101 = M[z1 * sz + y0 * sy + x1];
+  const float a011 = M[z1 * sz + y1 * sy + x0], a111 = M[z1 * sz + y1 * sy + x1];
+  const float v00 = a000 + (a100 - a000) * wx, v10 = a010 + (a110 - a010) * wx;
+  const float v01 = a001 + (a101 - a001) * wx, v11 = a011 + (a111 - a011) * wx;
+  const float v0 = v00 + (v10 - v00) * wy, v1 = v01 + (v11 - v01) * wy;
+  mval = v0 + (v1 - v0) * wz;
+  const float gx0 = (a100 - a000) + ((a110 - a010) - (a100 - a000)) * wy;
+  const float gx1 = (a101 - a001) + ((a111 - a011) - (a101 - a001)) * wy;
+  g[0] = gx0 + (gx1 - gx0) * wz;
+  g[1] = (v10 - v00) + ((v11 - v01) - (v10 - v00)) * wz;
+  g[2] = v1 - v0;
+  return true;
+}
+
+// bin of an intensity: nearest (zero-order) index clamped to [lo, hi], and the continuous bin coordinate
+__device__ __forceinline__ int mi_bin(double value, double bin, double norm_min, int lo, int hi, double& term) {
+  term = value / bin - norm_min;
+  int i = (int)floor(term);
+  return i < lo ? lo : (i > hi ? hi : i);
+}
+
+__global__ void __launch_bounds__(NT) k_mi_histogram(const float* __restrict__ F, pp_dims df, const float* __restrict__ M, pp_dims dm,
+                                                     const uint8_t* __restrict__ fmask, const uint8_t* __restrict__ mmask, mi_args a,
+                                                     unsigned long long* __restrict__ hist /* [nbins^2 + 1], last = sample count */) {
+  __shared__ unsigned long long sh[MI_MAX_BINS * MI_MAX_BINS + 1];
+  const int nb2 = a.nbins * a.nbins;
+  for (int i = threadIdx.x; i <= nb2; i += NT) sh[i] = 0ull;
+  __syncthreads();
+  const size_t nvirt = (size_t)a.vsize[0] * a.vsize[1] * a.vsize[2];
+  const size_t nsamp = (nvirt + a.stride - 1) / a.stride;
+  const int pad = a.kernel == 0 ? 2 : 0;
+  for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nsamp; e += (size_t)gridDim.x * NT) {
+    double v[3];
+    float fval, mval, g[3];
+    if (!mi_sample(F, df, M, dm, fmask, mmask, a, e, v, fval, mval, g)) continue;
+    double tf, tm;
+    const int fb = mi_bin((double)fval, a.f_bin, a.f_norm_min, pad, a.nbins - 1 - pad, tf);
+    const int mb = mi_bin((double)mval, a.m_bin, a.m_norm_min, pad, a.nbins - 1 - pad, tm);
+    if (a.kernel == 0) {
+      for (int k = mb - 1; k <= mb + 2; ++k) {
+        const double w = mi_bspline3((double)k - tm);
+        atomicAdd(&sh[fb * a.nbins + k], (unsigned long long)(w * 4294967296.0 + 0.5));
+      }
+    } else {
+      atomicAdd(&sh[fb * a.nbins + mb], 4294967296ull);
+    }
+    atomicAdd(&sh[nb2], 1ull);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i <= nb2; i += NT)
+    if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
+__global__ void __launch_bounds__(NT) k_mi_gradient(const float* __restrict__ F, pp_dims df, const float* __restrict__ M, pp_dims dm,
+                                                    const uint8_t* __restrict__ fmask, const uint8_t* __restrict__ mmask, mi_args a,
+                                                    const float* __restrict__ table /* device, [nbins^2] */,
+                                                    double* __restrict__ partials /* [grid][14] */) {
+  __shared__ double red[3 * NT];
+  __shared__ float tab[MI_MAX_BINS * MI_MAX_BINS];
+  for (int i = threadIdx.x; i < a.nbins * a.nbins; i += NT) tab[i] = table[i];
+  __syncthreads();
+  double acc[14];
+  for (int k = 0; k < 14; ++k) acc[k] = 0.0;
+  const size_t nvirt = (size_t)a.vsize[0] * a.vsize[1] * a.vsize[2];
+  const size_t nsamp = (nvirt + a.stride - 1) / a.stride;
+  const int pad = a.kernel == 0 ? 2 : 0;
+  for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nsamp; e += (size_t)gridDim.x * NT) {
+    double v[3];
+    float fval, mval, g[3];
+    if (!mi_sample(F, df, M, dm, fmask, mmask, a, e, v, fval, mval, g)) continue;
+    double tf, tm;
+    const int fb = mi_bin((double)fval, a.f_bin, a.f_norm_min, pad, a.nbins - 1 - pad, tf);
+    const int mb = mi_bin((double)mval, a.m_bin, a.m_norm_min, pad, a.nbins - 1 - pad, tm);
+    double w = 0.0;
+    if (a.kernel == 0) {
+      for (int k = mb - 1; k <= mb + 2; ++k) w += mi_bspline3_deriv((double)k - tm) * (double)tab[fb * a.nbins + k];
+    } else {
+      int k0 = (int)floor(tm - 0.5);
+      k0 = k0 < 0 ? 0 : (k0 > a.nbins - 2 ? a.nbins - 2 : k0);
+      w = (double)tab[fb * a.nbins + k0 + 1] - (double)tab[fb * a.nbins + k0];
+    }
+    acc[1] += 1.0;
+    for (int r = 0; r < 3; ++r) {
+      const double gr = w * (double)g[r];
+      acc[2 + r * 3 + 0] += gr * v[0];
+      acc[2 + r * 3 + 1] += gr * v[1];
+      acc[2 + r * 3 + 2] += gr * v[2];
+      acc[11 + r] += gr;
+    }
+  }
+  for (int k = 0; k < 14; k += 3) {
+    double p = acc[k], q = k + 1 < 14 ? acc[k + 1] : 0.0, r = k + 2 < 14 ? acc[k + 2] : 0.0;
+    pp_block_sum3<NT>(p, q, r, red);
+    if (threadIdx.x == 0) {
+      partials[(size_t)blockIdx.x * 14 + k] = p;
+      if (k + 1 < 14) partials[(size_t)blockIdx.x * 14 + k + 1] = q;
+      if (k + 2 < 14) partials[(size_t)blockIdx.x * 14 + k + 2] = r;
+    }
+    __syncthreads();
+  }
+}
+
+int mi_fill_args(pp_ctx* ctx, mi_args* a, const int fsize[3], const int msize[3], const double Af[9], const double bf[3], const double Am[9],
+                 const double bm[3], const int vsize[3], int stride, const pp_mi_bins* bins) {
+  PP_REQUIRE(ctx, fsize && msize && Af && bf && Am && bm && vsize && bins, "mutual information: NULL argument");
+  PP_REQUIRE(ctx, stride >= 1 && vsize[0] >= 1 && vsize[1] >= 1 && vsize[2] >= 1, "mutual information: bad sampling lattice");
+  PP_REQUIRE(ctx, bins->kernel == PP_MI_MATTES || bins->kernel == PP_MI_JOINT, "mutual information: unknown Parzen kernel");
+  PP_REQUIRE(ctx, bins->nbins >= (bins->kernel == PP_MI_MATTES ? 5 : 2) && bins->nbins <= MI_MAX_BINS, "mutual information: 5..64 bins (2..64 without padding)");
+  PP_REQUIRE(ctx, bins->f_bin > 0.0 && bins->m_bin > 0.0, "mutual information: bin widths must be positive");
+  memcpy(a->Af, Af, sizeof(a->Af));
+  memcpy(a->bf, bf, sizeof(a->bf));
+  memcpy(a->Am, Am, sizeof(a->Am));
+  memcpy(a->bm, bm, sizeof(a->bm));
+  for (int k = 0; k < 3; ++k) a->vsize[k] = vsize[k];
+  a->stride = stride;
+  a->nbins = bins->nbins;
+  a->kernel = bins->kernel;
+  a->f_bin = bins->f_bin;
+  a->f_norm_min = bins->f_norm_min;
+  a->m_bin = bins->m_bin;
+  a->m_norm_min = bins->m_norm_min;
+  return PP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -743,6 +934,71 @@ int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, con
   rc = pp_mail_wait(ctx, nchunk, seq);
   if (rc) return rc;
   memcpy(result, hres, (size_t)ncand * 6 * sizeof(double));
+  return PP_OK;
+}
+
+int pp_mi_histogram_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], const float* moving, const int msize[3], const double Af[9],
+                        const double bf[3], const double Am[9], const double bm[3], const int vsize[3], int stride,
+                        const uint8_t* fixed_mask, const uint8_t* moving_mask, const pp_mi_bins* bins, double* hist, double* count) {
+  if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
+  PP_REQUIRE(ctx, fixed && moving && hist && count, "pp_mi_histogram_f32: NULL argument");
+  mi_args a;
+  int rc = mi_fill_args(ctx, &a, fsize, msize, Af, bf, Am, bm, vsize, stride, bins);
+  if (rc) return rc;
+  const int nb2 = a.nbins * a.nbins;
+  const size_t nsamp = ((size_t)vsize[0] * vsize[1] * vsize[2] + stride - 1) / stride;
+  rc = pp_reserve(ctx, pp_align_up((size_t)(nb2 + 1) * sizeof(unsigned long long), 256));
+  if (rc) return rc;
+  unsigned long long* dh = reinterpret_cast<unsigned long long*>(ctx->ws);
+  PP_HIP(ctx, hipMemsetAsync(dh, 0, (size_t)(nb2 + 1) * sizeof(unsigned long long), ctx->stream));
+  const pp_dims df{fsize[0], fsize[1], fsize[2]}, dm{msize[0], msize[1], msize[2]};
+  hipLaunchKernelGGL(k_mi_histogram, dim3(grid_for(nsamp, 512u)), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, dh);
+  PP_LAUNCH_CHECK(ctx, "k_mi_histogram");
+  std::vector<unsigned long long> h((size_t)nb2 + 1);
+  PP_HIP(ctx, hipMemcpyAsync(h.data(), dh, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < nb2; ++i) hist[i] = (double)h[i] / 4294967296.0;
+  *count = (double)h[nb2];
+  return PP_OK;
+}
+
+int pp_mi_gradient_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], const float* moving, const int msize[3], const double Af[9],
+                       const double bf[3], const double Am[9], const double bm[3], const int vsize[3], int stride,
+                       const uint8_t* fixed_mask, const uint8_t* moving_mask, const pp_mi_bins* bins, const double* table, double* result) {
+  if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
+  PP_REQUIRE(ctx, fixed && moving && table && result, "pp_mi_gradient_f32: NULL argument");
+  mi_args a;
+  int rc = mi_fill_args(ctx, &a, fsize, msize, Af, bf, Am, bm, vsize, stride, bins);
+  if (rc) return rc;
+  const int nb2 = a.nbins * a.nbins;
+  const size_t nsamp = ((size_t)vsize[0] * vsize[1] * vsize[2] + stride - 1) / stride;
+  const unsigned nb = grid_for(nsamp, 512u);
+  const size_t tab_bytes = pp_align_up((size_t)nb2 * sizeof(float), 256);
+  rc = pp_reserve(ctx, tab_bytes + pp_align_up((size_t)nb * 14 * sizeof(double), 256) + 256);
+  if (rc) return rc;
+  float* dtab = reinterpret_cast<float*>(ctx->ws);
+  double* partials = reinterpret_cast<double*>(ctx->ws + tab_bytes);
+  std::vector<float> ht((size_t)nb2);
+  for (int i = 0; i < nb2; ++i) ht[i] = (float)table[i];
+  PP_HIP(ctx, hipMemcpyAsync(dtab, ht.data(), (size_t)nb2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  PP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // ht is a local: the copy must have left it
+  const pp_dims df{fsize[0], fsize[1], fsize[2]}, dm{msize[0], msize[1], msize[2]};
+  hipLaunchKernelGGL(k_mi_gradient, dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, (const float*)dtab,
+                     partials);
+  PP_LAUNCH_CHECK(ctx, "k_mi_gradient");
+  char* mail = nullptr;
+  unsigned long long* flags = nullptr;
+  unsigned long long seq = 0;
+  rc = pp_mailbox(ctx, &mail, &flags, &seq);
+  if (rc) return rc;
+  double* hres = reinterpret_cast<double*>(mail);
+  hipLaunchKernelGGL(k_sum14_final, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, 14, hres, flags, seq);
+  PP_LAUNCH_CHECK(ctx, "k_sum14_final");
+  rc = pp_mail_wait(ctx, 1, seq);
+  if (rc) return rc;
+  memcpy(result, hres + 2, 12 * sizeof(double));
   return PP_OK;
 }
 

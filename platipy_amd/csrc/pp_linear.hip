@@ -67,6 +67,8 @@ int model_params(int model) {
     case PP_MODEL_SCALE: return 3;
     case PP_MODEL_AFFINE: return 12;
     case PP_MODEL_EULER: return 6;
+    case PP_MODEL_SCALE_VERSOR: return 9;
+    case PP_MODEL_SCALE_SKEW_VERSOR: return 15;
     default: return -1;
   }
 }
@@ -97,6 +99,19 @@ void decode(int model, const double* p, double* A, double* t) {
     case PP_MODEL_AFFINE:
       for (int k = 0; k < 9; ++k) A[k] = p[k];
       for (int k = 0; k < 3; ++k) t[k] = p[9 + k];
+      break;
+    case PP_MODEL_SCALE_VERSOR:        // itk::ScaleVersor3DTransform::ComputeMatrix: rotation matrix, diagonal += scale - 1
+    case PP_MODEL_SCALE_SKEW_VERSOR:   // ... and off-diagonal entries += the six skew terms (additive form)
+      versor_matrix(p, A);
+      A[0] += p[6] - 1.0;
+      A[4] += p[7] - 1.0;
+      A[8] += p[8] - 1.0;
+      if (model == PP_MODEL_SCALE_SKEW_VERSOR) {
+        A[1] += p[9];  A[2] += p[10];
+        A[3] += p[11]; A[5] += p[12];
+        A[6] += p[13]; A[7] += p[14];
+      }
+      for (int k = 0; k < 3; ++k) t[k] = p[3 + k];
       break;
     case PP_MODEL_EULER: {  // ZXY order, ITK's default
       const double cx = std::cos(p[0]), sx = std::sin(p[0]), cy = std::cos(p[1]), sy = std::sin(p[1]), cz = std::cos(p[2]),

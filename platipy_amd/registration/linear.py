@@ -18,8 +18,15 @@ trajectory is not a goal for this stage; it is judged by final metric / transfor
     default is False).  ITK re-estimates the learning rate at the start of every level so that the first step
     moves the volume corners by one voxel; when the previous level already converged that first step overshoots,
     and keeping the best visited point makes the result insensitive to it;
-  * "mean_squares" and "correlation" are implemented; the mutual-information metrics and the "exhaustive"
-    optimiser raise NotImplementedError.
+  * all four metrics of the reference run on the GPU: "mean_squares", "correlation", "mattes_mi" (50 bins, fixed
+    zero-order / moving cubic-B-spline Parzen windows as itk::MattesMutualInformationImageToImageMetricv4; joint
+    histogram in 64-bit fixed point, so results do not depend on scheduling) and "joint_hist_mi" (20 bins, joint PDF
+    smoothed with ITK's Gaussian operator of variance 1.5; the derivative differences the smoothed log-PDFs between
+    neighbouring moving-bin centres -- this build's estimator under ITK's parameters, not a restatement of ITK's
+    interpolated-PDF derivative).  Intensity ranges are taken over the whole images (ITK: inside the masks);
+  * the "exhaustive" optimiser walks the reference's grid (2 x 10 + 1 steps per parameter, step length 1 in units of
+    the physical-shift scales) in batches of 16 evaluations per launch; grids above EXHAUSTIVE_MAX_EVALUATIONS raise
+    instead of running for days (the reference itself says "use is not currently recommended").
 """
 import numpy as np
 import torch
@@ -31,7 +38,9 @@ from ..transform import (
     CompositeTransform,
     Euler3DTransform,
     FullAffineTransform,
+    ScaleSkewVersor3DTransform,
     ScaleTransform,
+    ScaleVersor3DTransform,
     Similarity3DTransform,
     TranslationTransform,
     VersorRigid3DTransform,
@@ -45,7 +54,13 @@ _MODELS = {
     "affine": FullAffineTransform,
     "rigid": VersorRigid3DTransform,
     "scale": ScaleTransform,
+    "scaleversor": ScaleVersor3DTransform,
+    "scaleskewversor": ScaleSkewVersor3DTransform,
 }
+_METRICS = ("mean_squares", "correlation", "mattes_mi", "joint_hist_mi")
+MI_BINS = {"mattes_mi": 50, "joint_hist_mi": 20}        # SimpleITK's defaults (numberOfHistogramBins)
+JOINT_PDF_SMOOTHING_VARIANCE = 1.5                        # SetMetricAsJointHistogramMutualInformation default
+EXHAUSTIVE_MAX_EVALUATIONS = 4_000_000
 
 
 def _i2p(image):
@@ -114,6 +129,21 @@ class _MeanSquares:
         self.corners = self.o_v[None, :] + corners_idx @ self.i2p_v.T     # 8 physical corner points of the virtual domain
         self.min_spacing = float(np.min(vspacing))
         self.evaluations = 0
+        self.bins = None
+        if metric in MI_BINS:
+            from .._lib import MI_JOINT, MI_MATTES, MiBins
+
+            nb, pad = MI_BINS[metric], 2
+            f_lo, f_hi = ctx.minmax(self.ft, self.ft.numel())
+            m_lo, m_hi = ctx.minmax(self.mt, self.mt.numel())
+            b = MiBins()
+            b.nbins, b.kernel = nb, (MI_MATTES if metric == "mattes_mi" else MI_JOINT)
+            # itk::MattesMutualInformation...::Initialize: bin = (max - min) / (bins - 2 padding), normalised min = min / bin - padding
+            b.f_bin = max((f_hi - f_lo) / (nb - 2 * pad), 1e-30)
+            b.m_bin = max((m_hi - m_lo) / (nb - 2 * pad), 1e-30)
+            b.f_norm_min = f_lo / b.f_bin - pad
+            b.m_norm_min = m_lo / b.m_bin - pad
+            self.bins = b
 
     def total(self, model, params):
         """(A, off) of initial o model(params): q = A p + off."""
@@ -133,6 +163,13 @@ class _MeanSquares:
         self.evaluations += 1
         args = (self.ft, self.fixed.GetSize(), self.mt, self.moving.GetSize(), self.Af.ravel(), self.bf, Am.ravel(), bm, self.vsize,
                 self.stride, self.fmask, self.mmask)
+        if self.bins is not None:
+            hist, count = self.ctx.mi_histogram(*args[:10], self.bins, self.fmask, self.mmask)
+            if count <= 0:
+                raise RuntimeError("linear_registration: no valid sample points (images do not overlap)")
+            value, table = self._mi_value_and_table(hist, count)
+            g = self.ctx.mi_gradient(*args[:10], self.bins, table, self.fmask, self.mmask)
+            return value, np.asarray(g)
         if self.metric == "mean_squares":
             r = self.ctx.meansq_affine(*args)
             if r[1] <= 0:
@@ -153,14 +190,44 @@ class _MeanSquares:
         grad = -(2.0 * sfm / (sff * smm) * dsfm - (sfm * sfm) / (sff * smm * smm) * dsmm)
         return value, grad
 
+    def _mi_value_and_table(self, hist, count):
+        """Joint histogram -> (negative mutual information, per-bin score table for the gradient pass)."""
+        eps = 1e-16
+        if self.metric == "mattes_mi":
+            P = hist / hist.sum()
+        else:
+            from scipy.ndimage import correlate1d
+
+            from .._lib import gauss_taps
+
+            taps = np.asarray(gauss_taps(JOINT_PDF_SMOOTHING_VARIANCE, 0.01, 32, lib=self.ctx.lib))   # ITK's DiscreteGaussian on the PDF image
+            P = correlate1d(correlate1d(hist / count, taps, axis=0, mode="nearest"), taps, axis=1, mode="nearest")
+        PF, PM = P.sum(1), P.sum(0)
+        ok = (P > eps) & (PF[:, None] > eps) & (PM[None, :] > eps)
+        safe = np.where(ok, P, 1.0)
+        value = -float((np.where(ok, P * np.log(safe / np.where(ok, PF[:, None] * PM[None, :], 1.0)), 0.0)).sum())
+        ratio = np.where(ok, np.log(safe / np.where(ok, np.broadcast_to(PM[None, :], P.shape), 1.0)), 0.0)
+        # Mattes: d value / d mu = sum_s sum_k B3'(k - u_s) table[f_s][k] (grad M . dT/dmu), table = log(P / PM) / (N bin)
+        # joint:  d value / d mu = -(1/N) sum_s d/dm [log P - log PM](f_s, m_s) (grad M . dT/dmu), differenced between bin centres
+        scale = 1.0 / (count * self.bins.m_bin)
+        table = ratio * scale if self.metric == "mattes_mi" else -ratio * scale
+        return value, table
+
     def value(self, model, params):
-        return self.raw(model, params)[0]
+        return self.raw(model, params)[0] if self.bins is None else self.values(model, [params])[0]
 
     def values(self, model, params_list):
         """Metric values only for up to 16 parameter vectors in one launch (line search); a candidate without any
         valid sample point is +inf."""
         maps = [self.index_map(model, p) for p in params_list]
         self.evaluations += len(maps)
+        if self.bins is not None:        # one histogram pass per candidate; the value is host arithmetic on <= 64 x 64 numbers
+            out = []
+            for Am, bm in maps:
+                hist, count = self.ctx.mi_histogram(self.ft, self.fixed.GetSize(), self.mt, self.moving.GetSize(), self.Af.ravel(), self.bf,
+                                                    Am.ravel(), bm, self.vsize, self.stride, self.bins, self.fmask, self.mmask)
+                out.append(self._mi_value_and_table(hist, count)[0] if count > 0 else float("inf"))
+            return out
         r = self.ctx.metric_values_affine(0 if self.metric == "mean_squares" else 1, self.ft, self.fixed.GetSize(), self.mt,
                                           self.moving.GetSize(), self.Af.ravel(), self.bf, [m[0] for m in maps], [m[1] for m in maps],
                                           self.vsize, self.stride, self.fmask, self.mmask)
@@ -240,7 +307,7 @@ def _window_convergence(values, window):
 # user-defined _Parametrised models and scipy's L-BFGS-B.
 NATIVE_OPTIMISER = True
 _NATIVE_MODEL = {TranslationTransform: 0, VersorRigid3DTransform: 1, Similarity3DTransform: 2, ScaleTransform: 3,
-                 FullAffineTransform: 4, Euler3DTransform: 5}
+                 FullAffineTransform: 4, Euler3DTransform: 5, ScaleVersor3DTransform: 6, ScaleSkewVersor3DTransform: 7}
 
 
 def _optimise_level_native(ctx, ms, model, params, opt, number_of_iterations, verbose):
@@ -340,6 +407,45 @@ def _golden_section(fbatch, a, b, c, eps=0.01, max_iter=20, depth=None):
     return (c + a) / 2.0
 
 
+def _exhaustive(ms, model, params, number_of_steps, step_length, verbose):
+    """itk::ExhaustiveOptimizerv4 as SetOptimizerAsExhaustive(numberOfSteps, stepLength=1.0) drives it (reference
+    linear.py:215-222): every point of the grid initial + (k_i - n_i) * stepLength * scale_i, k_i = 0 .. 2 n_i, with the
+    optimiser scales from physical shift; the best point wins.  Evaluated 16 grid points per launch."""
+    n = len(params)
+    if len(number_of_steps) != n:
+        raise ValueError(f"exhaustive: numberOfSteps has {len(number_of_steps)} entries, the transform has {n} parameters "
+                         "(ITK raises here too; the reference passes six)")
+    total = int(np.prod([2 * k + 1 for k in number_of_steps], dtype=np.float64))
+    if total > EXHAUSTIVE_MAX_EVALUATIONS:
+        raise ValueError(f"exhaustive: the grid has {total:,} points (> EXHAUSTIVE_MAX_EVALUATIONS = {EXHAUSTIVE_MAX_EVALUATIONS:,}); "
+                         "the reference would evaluate them one by one -- reduce the steps or raise the limit")
+    scales = ms.scales(model, params)
+    base = np.asarray(params, dtype=np.float64)
+    best_v, best_p = float("inf"), base.copy()
+    axes = [np.arange(-k, k + 1) for k in number_of_steps]
+    batch = []
+
+    def flush():
+        nonlocal best_v, best_p
+        if not batch:
+            return
+        for p, v in zip(batch, ms.values(model, batch)):
+            if v < best_v:
+                best_v, best_p = v, p
+        batch.clear()
+
+    import itertools
+
+    for idx in itertools.product(*axes):              # last parameter fastest, like ITK's odometer
+        batch.append(base + np.asarray(idx, dtype=np.float64) * step_length * scales)
+        if len(batch) == 16:
+            flush()
+    flush()
+    if verbose:
+        print(f"exhaustive: {total} evaluations, best value {best_v:.6f}")
+    return best_p
+
+
 def linear_registration(
     fixed_image,
     moving_image,
@@ -367,14 +473,12 @@ def linear_registration(
     ctx = runtime.context(fixed_image.device)
 
     metric = metric.lower()
-    if metric not in ("mean_squares", "correlation"):
-        raise NotImplementedError(f"metric {metric!r}: 'mean_squares' and 'correlation' run on the HIP path")
+    if metric not in _METRICS:
+        raise ValueError(f"unknown metric {metric!r}: choose from {_METRICS}")
     initial_transform = centered_transform_initializer(fixed_image, moving_image)
 
     if isinstance(reg_method, str):
         key = reg_method.lower()
-        if key in ("scaleversor", "scaleskewversor"):
-            raise NotImplementedError(f"reg_method {reg_method!r} is not implemented on the HIP path")
         if key not in _MODELS:
             raise ValueError(
                 "You have selected a registration method that does not exist.\n Please select from"
@@ -389,9 +493,7 @@ def linear_registration(
         raise ValueError("'reg_method' must be either a string (see docs for acceptable registration names), "
                          "or a transform instance.")
     opt = optimiser.lower()
-    if opt == "exhaustive":
-        raise NotImplementedError("the 'exhaustive' optimiser is not implemented on the HIP path")
-    if opt not in ("gradient_descent", "gradient_descent_line_search", "lbfgsb"):
+    if opt not in ("gradient_descent", "gradient_descent_line_search", "lbfgsb", "exhaustive"):
         raise ValueError(f"unknown optimiser {optimiser!r}")
 
     fixed_mask = as_image(fixed_structure) if fixed_structure is not None else None
@@ -425,7 +527,11 @@ def linear_registration(
                 params = x / root
             continue
 
-        if NATIVE_OPTIMISER and type(model) in _NATIVE_MODEL:
+        if opt == "exhaustive":
+            params = _exhaustive(ms, model, params, [10, 10, 10, 10, 10, 10], 1.0, verbose)     # linear.py:215-222
+            continue
+
+        if NATIVE_OPTIMISER and type(model) in _NATIVE_MODEL and ms.bins is None:
             params = _optimise_level_native(ctx, ms, model, params, opt, number_of_iterations, verbose)
             continue
 

@@ -163,6 +163,43 @@ class Similarity3DTransform(_Parametrised):
         return float(p[6]) * _versor_matrix(p[:3]), np.asarray(p[3:6], dtype=np.float64).copy()
 
 
+class ScaleVersor3DTransform(_Parametrised):
+    """itk::ScaleVersor3DTransform -- parameters: versor (x, y, z), translation (3), scale (3).  ITK does not compose
+    rotation and scaling here: the matrix is the rotation matrix with (scale_i - 1) ADDED to its diagonal
+    (ScaleVersor3DTransform::ComputeMatrix)."""
+    n_params = 9
+
+    def identity_parameters(self):
+        return np.array([0, 0, 0, 0, 0, 0, 1.0, 1.0, 1.0])
+
+    def decode(self, p):
+        A = _versor_matrix(p[:3])
+        A[0, 0] += float(p[6]) - 1.0
+        A[1, 1] += float(p[7]) - 1.0
+        A[2, 2] += float(p[8]) - 1.0
+        return A, np.asarray(p[3:6], dtype=np.float64).copy()
+
+
+class ScaleSkewVersor3DTransform(_Parametrised):
+    """itk::ScaleSkewVersor3DTransform -- parameters: versor (3), translation (3), scale (3), skew (6).  As in
+    ScaleVersor3D the scale and the six skew terms are ADDED to the rotation matrix: diagonal += scale_i - 1, off-diagonal
+    entries (0,1) (0,2) (1,0) (1,2) (2,0) (2,1) += skew_0..5 (ScaleSkewVersor3DTransform::ComputeMatrix, additive form)."""
+    n_params = 15
+
+    def identity_parameters(self):
+        return np.array([0, 0, 0, 0, 0, 0, 1.0, 1.0, 1.0, 0, 0, 0, 0, 0, 0])
+
+    def decode(self, p):
+        A = _versor_matrix(p[:3])
+        A[0, 0] += float(p[6]) - 1.0
+        A[1, 1] += float(p[7]) - 1.0
+        A[2, 2] += float(p[8]) - 1.0
+        A[0, 1] += float(p[9]);  A[0, 2] += float(p[10])
+        A[1, 0] += float(p[11]); A[1, 2] += float(p[12])
+        A[2, 0] += float(p[13]); A[2, 1] += float(p[14])
+        return A, np.asarray(p[3:6], dtype=np.float64).copy()
+
+
 class ScaleTransform(_Parametrised):
     n_params = 3
 

@@ -143,7 +143,9 @@ def _rigid_pair(pa, shape, spacing, origin, angle=0.06, shift=(3.0, -2.0, 1.5), 
 @pytest.mark.parametrize("method,optimiser,metric", [("rigid", "gradient_descent_line_search", "mean_squares"),
                                                      ("affine", "gradient_descent_line_search", "mean_squares"),
                                                      ("similarity", "gradient_descent", "mean_squares"),
-                                                     ("translation", "gradient_descent_line_search", "correlation")])
+                                                     ("translation", "gradient_descent_line_search", "correlation"),
+                                                     ("scaleversor", "gradient_descent_line_search", "mean_squares"),
+                                                     ("scaleskewversor", "gradient_descent", "mean_squares")])
 def test_native_optimiser_follows_the_python_loop(backend, monkeypatch, method, optimiser, metric):
     """pp_linear_optimize_f32 (the optimiser inside the library) and the Python loop are the same algorithm: driven
     by the same kernels on the same small pair they end at the same parameters (differences: rounding in the
@@ -254,3 +256,152 @@ def test_linear_registration_argument_errors(host_api):
         pa.registration.linear_registration(img, img, metric="mattes_mi")
     with pytest.raises(NotImplementedError):
         pa.registration.linear_registration(img, img, optimiser="exhaustive")
+
+
+# --------------------------------------------------------------------------------------
+# mutual-information metrics, scale-versor models, exhaustive optimiser
+
+
+def _mi_bins(kernel, F, M, nbins):
+    from platipy_amd._lib import MiBins
+
+    b = MiBins()
+    b.nbins, b.kernel = nbins, kernel
+    b.f_bin = (float(F.max()) - float(F.min())) / (nbins - 4)
+    b.m_bin = (float(M.max()) - float(M.min())) / (nbins - 4)
+    b.f_norm_min = float(F.min()) / b.f_bin - 2
+    b.m_norm_min = float(M.min()) / b.m_bin - 2
+    return b, dict(nbins=nbins, kernel=kernel, f_bin=b.f_bin, f_norm_min=b.f_norm_min, m_bin=b.m_bin, m_norm_min=b.m_norm_min)
+
+
+@pytest.mark.parametrize("kernel,nbins", [(0, 50), (1, 20)])
+def test_mi_histogram_and_gradient_kernels_match_numpy(backend, kernel, nbins):
+    """pp_mi_histogram_f32 / pp_mi_gradient_f32 against the numpy restatement: same samples, same bins, B-spline weights;
+    the histogram is accumulated in 2^-32 fixed point (deterministic), so it matches to ~1e-9 per sample."""
+    from oracle import linear_oracle
+
+    F = phantom((10, 14, 18), seed=300, noise=3)
+    M = (1500.0 - 0.7 * phantom((12, 13, 17), seed=301, noise=3)).astype(np.float32)       # a different "modality"
+    Af, bf = np.eye(3) * 2.0, np.array([0.5, 0.5, 0.5])
+    Am = np.array([[1.9137, 0.1071, 0.0031], [-0.0813, 2.0519, 0.0207], [0.0109, 0.0043, 2.3011]])
+    bm = np.array([0.7123, -0.4057, 0.9131])
+    vsize, stride = (9, 7, 5), 2
+    bins, bdict = _mi_bins(kernel, F, M, nbins)
+    hist, count = backend.ctx.mi_histogram(backend.dev(F), (18, 14, 10), backend.dev(M), (17, 13, 12), Af.ravel(), bf, Am.ravel(), bm, vsize,
+                                           stride, bins)
+    want, wcount = linear_oracle.mi_histogram(F, M, Af, bf, Am, bm, vsize, stride, bdict)
+    assert count == wcount and count > 50
+    np.testing.assert_allclose(hist, want, rtol=0, atol=2e-4)        # fp32 vs fp64 interpolation moves each B-spline weight by ~1e-5
+    np.testing.assert_allclose(hist.sum(), count, rtol=1e-9)
+    table = np.random.default_rng(5).normal(size=(nbins, nbins))
+    g = backend.ctx.mi_gradient(backend.dev(F), (18, 14, 10), backend.dev(M), (17, 13, 12), Af.ravel(), bf, Am.ravel(), bm, vsize, stride,
+                                bins, table)
+    wg = linear_oracle.mi_gradient(F, M, Af, bf, Am, bm, vsize, stride, bdict, table)
+    np.testing.assert_allclose(g, wg, rtol=2e-4, atol=2e-4 * np.abs(wg).max())
+    # the histogram does not depend on how the launch is scheduled: run it again
+    again, _ = backend.ctx.mi_histogram(backend.dev(F), (18, 14, 10), backend.dev(M), (17, 13, 12), Af.ravel(), bf, Am.ravel(), bm, vsize,
+                                        stride, bins)
+    np.testing.assert_array_equal(hist, again)
+
+
+def test_mattes_gradient_is_the_derivative_of_the_value(host_api):
+    """value / gradient consistency of the Mattes metric through the host class linear_registration uses: the analytic
+    gradient (second GPU pass with the log-ratio table) against central differences of the value (first pass)."""
+    pa = host_api
+    from platipy_amd.registration import linear as L
+    from platipy_amd import runtime
+
+    shape, sp = (16, 20, 24), (1.0, 1.0, 1.0)
+    fix = phantom(shape, seed=310, noise=0)
+    mov = (1500.0 - 0.7 * np.roll(phantom(shape, seed=310, noise=0), (1, -1, 2), axis=(0, 1, 2))).astype(np.float32)
+    f, m = pa.image_from_array(fix, sp), pa.image_from_array(mov, sp)
+    init = L.centered_transform_initializer(f, m)
+    vsize, vspacing, vorigin, vdir = L._shrink_geometry(f, 1)
+    ms = L._MeanSquares(runtime.context(f.device), f, m, vsize, vspacing, vorigin, vdir, init, 1.0, None, None, metric="mattes_mi")
+    model = pa.transform.TranslationTransform()
+    p0 = np.array([0.4, -0.3, 0.2])
+    v0, g0 = ms.value_and_gradient(model, p0)
+    assert v0 < -0.2                                       # clearly informative (negative MI)
+    for k in range(3):
+        h = 0.05
+        d = np.zeros(3)
+        d[k] = h
+        fd = (ms.value(model, p0 + d) - ms.value(model, p0 - d)) / (2 * h)
+        assert abs(fd - g0[k]) <= 0.15 * abs(fd) + 2e-3, (k, fd, g0[k])
+
+
+@pytest.mark.parametrize("metric", ["mattes_mi", "joint_hist_mi"])
+def test_linear_registration_mutual_information_recovers_a_shift_across_modalities(host_api, metric):
+    """The moving image is an intensity-inverted, rescaled copy of the fixed one, displaced: mean squares cannot align
+    it, mutual information does (reference linear.py:145-148)."""
+    pa = host_api
+    shape, sp = (20, 28, 32), (1.0, 1.0, 2.0)
+    fix = phantom(shape, seed=320, noise=2)
+    mov = (1500.0 - 0.7 * np.roll(fix, (1, -2, 3), axis=(0, 1, 2))).astype(np.float32)
+    img, tfm = pa.registration.linear_registration(pa.image_from_array(fix, sp), pa.image_from_array(mov, sp), reg_method="translation",
+                                                   metric=metric, optimiser="gradient_descent_line_search", shrink_factors=[2, 1],
+                                                   smooth_sigmas=[1, 0], sampling_rate=1.0, number_of_iterations=40)
+    A, off = tfm.matrix_offset()
+    np.testing.assert_allclose(off, [3.0 * sp[0], -2.0 * sp[1], 1.0 * sp[2]], atol=0.6)   # fixed(p) ~ moving(p + shift)
+    # registered moving image is the fixed one up to the intensity map
+    r = np.corrcoef(img.numpy()[2:-2, 3:-3, 4:-4].ravel(), fix[2:-2, 3:-3, 4:-4].ravel())[0, 1]
+    assert r < -0.95
+
+
+@pytest.mark.parametrize("reg_method,n_params", [("ScaleVersor", 9), ("ScaleSkewVersor", 15)])
+def test_linear_registration_scale_versor_models(host_api, reg_method, n_params):
+    """ScaleVersor3D / ScaleSkewVersor3D (reference linear.py:177-180): ITK's additive matrices, optimised by the same
+    loop; an anisotropic zoom plus a small shift is recovered."""
+    pa = host_api
+    shape, sp = (22, 30, 34), (1.0, 1.0, 1.5)
+    fix = phantom(shape, seed=330, noise=0)
+    f = pa.image_from_array(fix, sp)
+    c = np.array([(34 - 1) / 2 * sp[0], (30 - 1) / 2 * sp[1], (22 - 1) / 2 * sp[2]])
+    truth = pa.AffineTransform(np.diag([1.06, 0.95, 1.03]), (1.0, -0.8, 0.5), c)
+    mov = pa.registration.apply_transform(f, f, truth, -1000, pa.sitkLinear)        # moving(p) = fixed(T p)
+    img, tfm = pa.registration.linear_registration(f, mov, reg_method=reg_method, optimiser="gradient_descent_line_search",
+                                                   shrink_factors=[2, 1], smooth_sigmas=[1, 0], sampling_rate=1.0, number_of_iterations=60)
+    assert tfm.transforms[-1].GetNumberOfParameters() == n_params
+    before = float(((fix - mov.numpy()) ** 2).mean())
+    after = float(((fix - img.numpy()) ** 2).mean())
+    assert after < 0.15 * before, (before, after)
+    A, off = tfm.matrix_offset()
+    Ai = np.linalg.inv(np.diag([1.06, 0.95, 1.03]))                                  # fixed(p) ~ moving(T^-1 p)
+    np.testing.assert_allclose(np.diag(A), np.diag(Ai), atol=0.02)
+
+
+def test_scale_versor_matrices_are_additive():
+    import platipy_amd as pa
+
+    t = pa.transform.ScaleVersor3DTransform()
+    v = np.array([0.0, 0.0, np.sin(0.1)])
+    t.SetParameters(np.concatenate([v, [1.0, 2.0, 3.0], [1.2, 0.9, 1.1]]))
+    R = np.array([[np.cos(0.2), -np.sin(0.2), 0], [np.sin(0.2), np.cos(0.2), 0], [0, 0, 1.0]])
+    np.testing.assert_allclose(t.matrix, R + np.diag([0.2, -0.1, 0.1]), atol=1e-12)
+    s = pa.transform.ScaleSkewVersor3DTransform()
+    s.SetParameters(np.concatenate([v, [0, 0, 0], [1.2, 0.9, 1.1], [0.01, 0.02, 0.03, 0.04, 0.05, 0.06]]))
+    K = np.array([[0.2, 0.01, 0.02], [0.03, -0.1, 0.04], [0.05, 0.06, 0.1]])
+    np.testing.assert_allclose(s.matrix, R + K, atol=1e-12)
+
+
+def test_exhaustive_optimiser_walks_the_grid(host_api):
+    """SetOptimizerAsExhaustive (reference linear.py:215-222): the best point of initial + k * step * scale, k = -n..n."""
+    pa = host_api
+    from platipy_amd import runtime
+    from platipy_amd.registration import linear as L
+
+    shape, sp = (14, 18, 22), (1.0, 1.0, 1.0)
+    fix = phantom(shape, seed=340, noise=0)
+    mov = np.roll(fix, (0, -2, 1), axis=(0, 1, 2))
+    f, m = pa.image_from_array(fix, sp), pa.image_from_array(mov, sp)
+    init = L.centered_transform_initializer(f, m)
+    vsize, vspacing, vorigin, vdir = L._shrink_geometry(f, 1)
+    ms = L._MeanSquares(runtime.context(f.device), f, m, vsize, vspacing, vorigin, vdir, init, 1.0, None, None)
+    model = pa.transform.TranslationTransform()
+    best = L._exhaustive(ms, model, np.zeros(3), [3, 3, 3], 1.0, False)
+    np.testing.assert_allclose(best, [1.0, -2.0, 0.0], atol=1e-9)          # translation scales are 1: integer-mm grid
+    assert ms.evaluations == 7 ** 3
+    with pytest.raises(ValueError, match="numberOfSteps"):
+        L._exhaustive(ms, model, np.zeros(3), [10] * 6, 1.0, False)         # the reference's six steps on a 3-parameter model
+    with pytest.raises(ValueError, match="EXHAUSTIVE_MAX_EVALUATIONS"):
+        pa.registration.linear_registration(f, m, reg_method="rigid", optimiser="exhaustive", shrink_factors=[1], smooth_sigmas=[0])
