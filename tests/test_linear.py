@@ -252,10 +252,12 @@ def test_linear_registration_argument_errors(host_api):
     img = pa.image_from_array(phantom((8, 10, 12), seed=1))
     with pytest.raises(ValueError):
         pa.registration.linear_registration(img, img, reg_method="nonsense")
-    with pytest.raises(NotImplementedError):
-        pa.registration.linear_registration(img, img, metric="mattes_mi")
-    with pytest.raises(NotImplementedError):
-        pa.registration.linear_registration(img, img, optimiser="exhaustive")
+    with pytest.raises(ValueError):
+        pa.registration.linear_registration(img, img, metric="nonsense")
+    with pytest.raises(ValueError):
+        pa.registration.linear_registration(img, img, optimiser="nonsense")
+    with pytest.raises(ValueError, match="numberOfSteps"):     # the reference's six exhaustive steps on a 7-parameter model: ITK raises too
+        pa.registration.linear_registration(img, img, optimiser="exhaustive", shrink_factors=[1], smooth_sigmas=[0])
 
 
 # --------------------------------------------------------------------------------------
