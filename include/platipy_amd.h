@@ -44,7 +44,7 @@ typedef enum {
   PP_ERR_NO_OVERLAP = -6   /* linear registration: no valid sample point at start */
 } pp_status;
 
-enum { PP_INTERP_NEAREST = 1, PP_INTERP_LINEAR = 2 }; /* = sitk.sitkNearestNeighbor / sitkLinear */
+enum { PP_INTERP_NEAREST = 1, PP_INTERP_LINEAR = 2, PP_INTERP_BSPLINE = 3 }; /* = sitk.sitkNearestNeighbor / sitkLinear / sitkBSpline */
 enum { PP_MORPH_DILATE = 0, PP_MORPH_ERODE = 1, PP_MORPH_CLOSE = 2 };
 enum { PP_DTYPE_U8 = 0, PP_DTYPE_F32 = 1 };
 
@@ -155,6 +155,10 @@ int pp_resample_f32(pp_ctx* ctx, const float* in, const pp_geom* gin, const pp_g
 int pp_resample_u8(pp_ctx* ctx, const uint8_t* in, const pp_geom* gin, const pp_geom* gout,
                    const double* affine_A, const double* affine_t, const float* field,
                    int interp, double default_value, uint8_t* out);
+/* itk::BSplineDecompositionImageFilter (spline order 3): samples -> B-spline coefficients, mirror boundaries; `out` may be
+ * `in`.  pp_resample_f32 with interp = PP_INTERP_BSPLINE expects this coefficient volume as its input
+ * (itk::BSplineInterpolateImageFunction: any sitk interpolator may reach registration/utils.py:176-190). */
+int pp_bspline_prefilter_f32(pp_ctx* ctx, const float* in, const int size[3], float* out);
 /* sitk.Resample on the vector field itself (deformable.py:130,137,185): linear, default 0. */
 int pp_resample_field_f32(pp_ctx* ctx, const float* in, const pp_geom* gin, const pp_geom* gout,
                           float* out);
@@ -183,6 +187,10 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
 int pp_weight_map_local_f32(pp_ctx* ctx, const float* target, const float* moving,
                             const int size[3], const double spacing[3], double sigma,
                             double epsilon, float* weight);
+/* compute_weight_map(vote_type="block") (label/fusion.py:179-190):
+ * w = factor * BoxMean((T - M)^2, radius)^(-|gain / 2|), box mean with ZeroFluxNeumann edges; radius in voxels (x, y, z). */
+int pp_weight_map_block_f32(pp_ctx* ctx, const float* target, const float* moving, const int size[3],
+                            const int radius[3], double factor, double gain, float* weight);
 /* sum of squared differences (vote_type="global", label/fusion.py:154-161), fp64 on host. */
 int pp_sum_sq_diff_f32(pp_ctx* ctx, const float* a, const float* b, size_t n, double* result);
 /* combine_labels accumulation (label/fusion.py:263,269-276), one atlas at a time:

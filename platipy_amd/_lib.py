@@ -16,6 +16,7 @@ DEFAULT_LIB = os.path.join(_HERE, "csrc", "libplatipy_hip.so")
 PP_OK = 0
 INTERP_NEAREST = 1
 INTERP_LINEAR = 2
+INTERP_BSPLINE = 3
 DEMONS_AUTO, DEMONS_STAGED, DEMONS_FUSED = 0, 1, 2
 ABI_VERSION = 1
 
@@ -115,11 +116,13 @@ _SIGNATURES = {
     "pp_resample_u8": (C.c_int, [_P, _P, C.POINTER(Geom), C.POINTER(Geom), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                  _P, C.c_int, C.c_double, _P]),
     "pp_resample_field_f32": (C.c_int, [_P, _P, C.POINTER(Geom), C.POINTER(Geom), _P]),
+    "pp_bspline_prefilter_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P]),
     "pp_compose_field_f32": (C.c_int, [_P, _P, _P, C.POINTER(Geom)]),
     "pp_transform_to_field_f32": (C.c_int, [_P, C.POINTER(Geom), C.POINTER(C.c_double), C.POINTER(C.c_double), _P, _P]),
     "pp_demons_force_f32": (C.c_int, [_P, _P, _P, C.POINTER(Geom), C.POINTER(DemonsParams), _P, C.POINTER(DemonsStats)]),
     "pp_demons_execute_f32": (C.c_int, [_P, _P, _P, C.POINTER(Geom), C.POINTER(DemonsParams), _P, C.POINTER(DemonsStats)]),
     "pp_weight_map_local_f32": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_double, C.c_double, _P]),
+    "pp_weight_map_block_f32": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_double, C.c_double, _P]),
     "pp_sum_sq_diff_f32": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_double)]),
     "pp_fuse_accumulate_u8": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t]),
     "pp_fuse_accumulate_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t]),
@@ -317,6 +320,10 @@ class Context:
         self._chk(fn(self.h, ptr(src), C.byref(gin), C.byref(gout), _dn(affine_A, 9), _dn(affine_t, 3), ptr(field),
                      int(interp), float(default_value), ptr(out)), "pp_resample")
 
+    def bspline_prefilter(self, src, size, out):
+        """B-spline (order 3) coefficients of a fp32 volume (`out` may be `src`)."""
+        self._chk(self.lib.pp_bspline_prefilter_f32(self.h, ptr(src), _i3(size), ptr(out)), "pp_bspline_prefilter_f32")
+
     def resample_field(self, src, gin, gout, out):
         self._chk(self.lib.pp_resample_field_f32(self.h, ptr(src), C.byref(gin), C.byref(gout), ptr(out)),
                   "pp_resample_field_f32")
@@ -348,6 +355,10 @@ class Context:
     def weight_map_local(self, target, moving, size, spacing, sigma, epsilon, out):
         self._chk(self.lib.pp_weight_map_local_f32(self.h, ptr(target), ptr(moving), _i3(size), _d3(spacing), float(sigma),
                                                    float(epsilon), ptr(out)), "pp_weight_map_local_f32")
+
+    def weight_map_block(self, target, moving, size, radius, factor, gain, weight):
+        self._chk(self.lib.pp_weight_map_block_f32(self.h, ptr(target), ptr(moving), _i3(size), _i3(radius), float(factor), float(gain),
+                                                   ptr(weight)), "pp_weight_map_block_f32")
 
     def sum_sq_diff(self, a, b, n):
         r = C.c_double()

@@ -88,6 +88,18 @@ struct op_fuse_accumulate {
   }
 };
 
+// vote_type "block" (label/fusion.py:186-190): factor * box_mean^(-|gain / 2|), as sitk.Pow(raw, -1.0) ** abs(gain / 2) evaluates it
+struct op_block_weight {
+  float* w;
+  float factor, power;
+  __device__ __forceinline__ float f(float raw) const { return factor * powf(1.0f / raw, power); }
+  __device__ __forceinline__ void four(size_t g) const {
+    const float4 v = reinterpret_cast<float4*>(w)[g];
+    reinterpret_cast<float4*>(w)[g] = make_float4(f(v.x), f(v.y), f(v.z), f(v.w));
+  }
+  __device__ __forceinline__ void one(size_t i) const { w[i] = f(w[i]); }
+};
+
 struct op_fuse_divide {
   const float *wl, *ws;
   float* out;
@@ -734,6 +746,36 @@ int pp_weight_map_local_f32(pp_ctx* ctx, const float* target, const float* movin
   if (rc) return rc;
   launch_map4(ctx, N, all_aligned16(weight), op_inv_eps{weight, (float)epsilon});
   PP_LAUNCH_CHECK(ctx, "k_map4<op_inv_eps>");
+  return PP_OK;
+}
+
+int pp_weight_map_block_f32(pp_ctx* ctx, const float* target, const float* moving, const int size[3], const int radius[3],
+                            double factor, double gain, float* weight) {
+  if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
+  PP_REQUIRE(ctx, target && moving && weight && size && radius, "pp_weight_map_block_f32: NULL argument");
+  const size_t N = pp_nvox(size);
+  PP_REQUIRE(ctx, N > 0, "pp_weight_map_block_f32: empty volume");
+  launch_map4(ctx, N, all_aligned16(target, moving, weight), op_sqdiff{target, moving, weight});
+  PP_LAUNCH_CHECK(ctx, "k_map4<op_sqdiff>");
+  // sitk.BoxMean(square, radius): the mean over a (2r+1)^3 box with ZeroFluxNeumann edges is three 1-D means
+  pp_taps taps[3];
+  for (int a = 0; a < 3; ++a) {
+    PP_REQUIRE(ctx, radius[a] >= 0 && radius[a] <= PP_MAX_RADIUS, "pp_weight_map_block_f32: box radius out of range");
+    taps[a].r = radius[a];
+    for (int k = 0; k < 2 * radius[a] + 1; ++k) taps[a].w[k] = 1.0f / (float)(2 * radius[a] + 1);
+  }
+  int rc = pp_reserve(ctx, 2 * pp_align_up(N * sizeof(float), 256));
+  if (rc) return rc;
+  pp_carver cv{ctx->ws, 0};
+  float* t1 = cv.take<float>(N);
+  float* t2 = cv.take<float>(N);
+  const pp_dims d{size[0], size[1], size[2]};
+  const int order[3] = {0, 1, 2};
+  rc = pp_smooth3_staged(ctx, weight, nullptr, weight, t1, t2, d, 1, taps, order, nullptr);
+  if (rc) return rc;
+  launch_map4(ctx, N, all_aligned16(weight), op_block_weight{weight, (float)factor, (float)fabs(gain / 2.0)});
+  PP_LAUNCH_CHECK(ctx, "k_map4<op_block_weight>");
   return PP_OK;
 }
 

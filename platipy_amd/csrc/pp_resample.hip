@@ -146,6 +146,110 @@ __device__ __forceinline__ uint8_t pp_cast_out<uint8_t>(float v) {
   return v < 0.0f ? (uint8_t)0 : (v > 255.0f ? (uint8_t)255 : (uint8_t)v);  // clamp, then truncate
 }
 
+// itk::BSplineInterpolateImageFunction, spline order 3 (sitkBSpline): 4 x 4 x 4 cubic B-spline weights on the coefficient
+// volume produced by the prefilter below; neighbour indices beyond the buffer are mirrored about the first / last voxel
+// (period 2 n - 2), as ITK's DetermineRegionOfSupport / ApplyMirrorBoundaryConditions do.
+__device__ __forceinline__ void pp_bspline3_axis(double c, int n, int idx[4], double w[4]) {
+  const double fl = floor(c);
+  const int i1 = (int)fl;
+  const double t = c - fl;
+  w[3] = (1.0 / 6.0) * t * t * t;
+  w[0] = (1.0 / 6.0) + 0.5 * t * (t - 1.0) - w[3];
+  w[2] = t + w[0] - 2.0 * w[3];
+  w[1] = 1.0 - w[0] - w[2] - w[3];
+  const int n2 = 2 * n - 2;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int i = i1 - 1 + k;
+    if (n == 1) {
+      i = 0;
+    } else {
+      if (i < 0) i = -i - n2 * ((-i) / n2);
+      else i = i - n2 * (i / n2);
+      if (i >= n) i = n2 - i;
+    }
+    idx[k] = i;
+  }
+}
+__device__ __forceinline__ float pp_bspline3_sample(const float* __restrict__ coef, const pp_dims& n, const double c[3]) {
+  int ix[4], iy[4], iz[4];
+  double wx[4], wy[4], wz[4];
+  pp_bspline3_axis(c[0], n.nx, ix, wx);
+  pp_bspline3_axis(c[1], n.ny, iy, wy);
+  pp_bspline3_axis(c[2], n.nz, iz, wz);
+  double acc = 0.0;
+  for (int kz = 0; kz < 4; ++kz) {
+    double az = 0.0;
+    for (int ky = 0; ky < 4; ++ky) {
+      const float* row = coef + ((size_t)iz[kz] * n.ny + iy[ky]) * n.nx;
+      const double ay = wx[0] * (double)row[ix[0]] + wx[1] * (double)row[ix[1]] + wx[2] * (double)row[ix[2]] + wx[3] * (double)row[ix[3]];
+      az += wy[ky] * ay;
+    }
+    acc += wz[kz] * az;
+  }
+  return (float)acc;
+}
+
+// itk::BSplineDecompositionImageFilter for spline order 3 along one axis, in place: the recursive (causal + anti-causal)
+// filter with pole sqrt(3) - 2 and gain 6 that turns samples into B-spline coefficients, mirror boundaries (Unser's
+// initialisation: the causal sum over a horizon where the pole's power falls below 1e-10, or the exact closed form on
+// short lines).  One thread per line, fp64 recursion, fp32 storage; lines are `stride` apart element to element.
+__global__ void __launch_bounds__(NT) k_bspline3_prefilter(float* __restrict__ data, pp_dims d, int axis) {
+  const int len = axis == 0 ? d.nx : (axis == 1 ? d.ny : d.nz);
+  const size_t stride = axis == 0 ? 1 : (axis == 1 ? (size_t)d.nx : (size_t)d.nx * d.ny);
+  const size_t nlines = (size_t)d.nx * d.ny * d.nz / len;
+  const double z = -0.26794919243112270647;   // sqrt(3) - 2
+  for (size_t l = (size_t)blockIdx.x * NT + threadIdx.x; l < nlines; l += (size_t)gridDim.x * NT) {
+    size_t base;
+    if (axis == 0) base = l * (size_t)d.nx;
+    else if (axis == 1) base = (l / d.nx) * (size_t)d.nx * d.ny + (l % d.nx);
+    else base = l;
+    float* p = data + base;
+    if (len == 1) continue;
+    const double lambda = (1.0 - z) * (1.0 - 1.0 / z);
+    // causal initialisation
+    double sum;
+    const int horizon = 18 < len ? 18 : len;   // ceil(log(1e-10) / log|z|) = 18
+    if (horizon < len) {
+      double zn = z;
+      sum = (double)p[0] * lambda;
+      for (int k = 1; k < horizon; ++k) {
+        sum += zn * (double)p[(size_t)k * stride] * lambda;
+        zn *= z;
+      }
+    } else {
+      const double iz = 1.0 / z;
+      double zn = z, z2n = pow(z, (double)(len - 1));
+      sum = ((double)p[0] + z2n * (double)p[(size_t)(len - 1) * stride]) * lambda;
+      z2n *= z2n * iz;
+      for (int k = 1; k <= len - 2; ++k) {
+        sum += (zn + z2n) * (double)p[(size_t)k * stride] * lambda;
+        zn *= z;
+        z2n *= iz;
+      }
+      sum /= (1.0 - zn * zn);
+    }
+    double prev = sum;
+    p[0] = (float)prev;   // stored in fp32, recursion continues in fp64
+    double cm2 = 0.0, cm1 = prev;
+    for (int k = 1; k < len; ++k) {
+      const double cur = (double)p[(size_t)k * stride] * lambda + z * prev;
+      p[(size_t)k * stride] = (float)cur;
+      cm2 = prev;
+      prev = cur;
+      cm1 = cur;
+    }
+    // anti-causal initialisation and recursion
+    double nxt = (z / (z * z - 1.0)) * (z * cm2 + cm1);
+    p[(size_t)(len - 1) * stride] = (float)nxt;
+    for (int k = len - 2; k >= 0; --k) {
+      const double cur = z * (nxt - (double)p[(size_t)k * stride]);
+      p[(size_t)k * stride] = (float)cur;
+      nxt = cur;
+    }
+  }
+}
+
 template <typename T, int INTERP, bool HASFIELD>
 __global__ void __launch_bounds__(NT) k_resample(const T* __restrict__ in, pp_dims din, const float* __restrict__ field,
                                                  T* __restrict__ out, pp_dims dout, pp_xform X, T default_value) {
@@ -167,6 +271,8 @@ __global__ void __launch_bounds__(NT) k_resample(const T* __restrict__ in, pp_di
       if (INTERP == PP_INTERP_NEAREST) {
         const int qx = (int)floor(c[0] + 0.5), qy = (int)floor(c[1] + 0.5), qz = (int)floor(c[2] + 0.5);
         res = in[((size_t)qz * din.ny + qy) * din.nx + qx];
+      } else if (INTERP == PP_INTERP_BSPLINE) {
+        if (sizeof(T) == 4) res = pp_cast_out<T>(pp_bspline3_sample(reinterpret_cast<const float*>(in), din, c));
       } else {
         const double flx = floor(c[0]), fly = floor(c[1]), flz = floor(c[2]);
         res = pp_cast_out<T>(pp_trilinear(in, din.nx, din.ny, din.nz, (int)flx, (float)(c[0] - flx), (int)fly,
@@ -237,7 +343,8 @@ int resample_any(pp_ctx* ctx, const T* in, const pp_geom* gin, const pp_geom* go
   if (rc) return rc;
   rc = pp_geom_check(ctx, gout, "output");
   if (rc) return rc;
-  PP_REQUIRE(ctx, interp == PP_INTERP_NEAREST || interp == PP_INTERP_LINEAR, "resample: interpolator must be nearest or linear");
+  PP_REQUIRE(ctx, interp == PP_INTERP_NEAREST || interp == PP_INTERP_LINEAR || (interp == PP_INTERP_BSPLINE && sizeof(T) == 4),
+             "resample: interpolator must be nearest, linear or (fp32 coefficient volumes) cubic B-spline");
   pp_xform X;
   fill_xform(gin, gout, A, t, &X);
   const pp_dims din{gin->size[0], gin->size[1], gin->size[2]};
@@ -253,6 +360,8 @@ int resample_any(pp_ctx* ctx, const T* in, const pp_geom* gin, const pp_geom* go
 #define PP_RS(I, F) hipLaunchKernelGGL((k_resample<T, I, F>), grid, block, 0, ctx->stream, in, din, field, out, dout, X, dv)
   if (interp == PP_INTERP_NEAREST) {
     if (field) PP_RS(PP_INTERP_NEAREST, true); else PP_RS(PP_INTERP_NEAREST, false);
+  } else if (interp == PP_INTERP_BSPLINE) {
+    if (field) PP_RS(PP_INTERP_BSPLINE, true); else PP_RS(PP_INTERP_BSPLINE, false);
   } else {
     if (field) PP_RS(PP_INTERP_LINEAR, true); else PP_RS(PP_INTERP_LINEAR, false);
   }
@@ -323,6 +432,22 @@ int pp_resample_u8(pp_ctx* ctx, const uint8_t* in, const pp_geom* gin, const pp_
                    const double* affine_t, const float* field, int interp, double default_value, uint8_t* out) {
   pp_device_guard dev_guard_(ctx);
   return resample_any<uint8_t>(ctx, in, gin, gout, affine_A, affine_t, field, interp, default_value, out, "k_resample<u8>");
+}
+
+int pp_bspline_prefilter_f32(pp_ctx* ctx, const float* in, const int size[3], float* out) {
+  if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
+  PP_REQUIRE(ctx, in && out && size, "pp_bspline_prefilter_f32: NULL argument");
+  PP_REQUIRE(ctx, size[0] > 0 && size[1] > 0 && size[2] > 0, "pp_bspline_prefilter_f32: empty volume");
+  const pp_dims d{size[0], size[1], size[2]};
+  const size_t N = pp_nvox(size);
+  if (in != out) PP_HIP(ctx, hipMemcpyAsync(out, in, N * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  for (int axis = 0; axis < 3; ++axis) {
+    const int len = axis == 0 ? d.nx : (axis == 1 ? d.ny : d.nz);
+    hipLaunchKernelGGL(k_bspline3_prefilter, dim3(grid_for(N / len)), dim3(NT), 0, ctx->stream, out, d, axis);
+    PP_LAUNCH_CHECK(ctx, "k_bspline3_prefilter");
+  }
+  return PP_OK;
 }
 
 int pp_resample_field_f32(pp_ctx* ctx, const float* in, const pp_geom* gin, const pp_geom* gout, float* out) {

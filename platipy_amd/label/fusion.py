@@ -50,11 +50,8 @@ def compute_weight_map(target_image, moving_image, vote_type="unweighted", vote_
     elif vt == "block":
         bs = p["blockSize"]
         bs = (bs,) * 3 if isinstance(bs, int) else tuple(bs)                         # (x, y, z) radii of sitk.BoxMean
-        sq = (t - m) ** 2
-        pad = (bs[0], bs[0], bs[1], bs[1], bs[2], bs[2])
-        padded = torch.nn.functional.pad(sq[None, None], pad, mode="replicate")     # ZeroFluxNeumann
-        raw = torch.nn.functional.avg_pool3d(padded, kernel_size=(2 * bs[2] + 1, 2 * bs[1] + 1, 2 * bs[0] + 1), stride=1)[0, 0]
-        weight = p["factor"] * torch.pow(raw, -1.0) ** abs(p["gain"] / 2.0)          # :179-190
+        weight = torch.empty_like(t)
+        ctx.weight_map_block(t, m, target_image.GetSize(), bs, p["factor"], p["gain"], weight)   # :179-190
         weight = _normalise(weight, p["normalise"])
     else:
         raise ValueError(f"unknown vote_type {vote_type!r}")

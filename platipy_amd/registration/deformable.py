@@ -7,7 +7,6 @@ Deviations, all deliberate and visible:
   * the displacement field is computed in fp32 (the reference keeps sitkVectorFloat64); the tolerance against the
     fp64 restatement is stated and tested in tests/; `field_dtype=torch.float64` returns it in the reference's type;
   * `ncores` is accepted and ignored (it set ITK's CPU thread count);
-  * B-spline interpolation (`interp_order=3`) raises NotImplementedError;
   * non-identity direction cosines (axis flips / oblique acquisitions): the registration runs in the image's
     own index-aligned frame -- every stage is linear in the field and the pyramid grids share one origin and
     one direction, so this is the same computation -- and the field is rotated back to physical (LPS)

@@ -21,11 +21,10 @@ logger = logging.getLogger(__name__)
 
 
 def _check_interp(interpolator):
-    if interpolator == sitkBSpline:
-        raise NotImplementedError("B-spline interpolation is not implemented on the HIP path (nearest and linear are)")
-    if interpolator not in (sitkNearestNeighbor, sitkLinear):
+    """sitkNearestNeighbor / sitkLinear / sitkBSpline (cubic: itk::BSplineInterpolateImageFunction, spline order 3)."""
+    if interpolator not in (sitkNearestNeighbor, sitkLinear, sitkBSpline):
         raise ValueError(f"unknown interpolator {interpolator!r}")
-    return _lib.INTERP_NEAREST if interpolator == sitkNearestNeighbor else _lib.INTERP_LINEAR
+    return {sitkNearestNeighbor: _lib.INTERP_NEAREST, sitkLinear: _lib.INTERP_LINEAR, sitkBSpline: _lib.INTERP_BSPLINE}[interpolator]
 
 
 def _split_transform(transform, reference):
@@ -84,6 +83,17 @@ def resample_image(image, reference, transform=None, interpolator=sitkLinear, de
     interp = _check_interp(interpolator)
     ctx = runtime.context(image.device)
     A, t, field = _split_transform(transform, reference)
+    if interp == _lib.INTERP_BSPLINE:
+        # coefficients first (BSplineDecompositionImageFilter), then the 4 x 4 x 4 evaluation; integer images go through fp32
+        src = (image.tensor if image.tensor.dtype == torch.float32 else image.tensor.float()).contiguous()
+        coef = torch.empty_like(src)
+        ctx.bspline_prefilter(src, image.GetSize(), coef)
+        out = torch.empty(reference.shape, dtype=torch.float32, device=src.device)
+        ctx.resample(coef, image.geom(), reference.geom(), out, affine_A=None if A is None else A.ravel(),
+                     affine_t=None if A is None else t, field=field, interp=interp, default_value=float(default_value), u8=False)
+        if image.tensor.dtype == torch.uint8:
+            out = out.clamp_(0, 255).to(torch.uint8)
+        return Image(out, reference.spacing, reference.origin, reference.direction, False)
     if image.tensor.dtype == torch.uint8:
         src, u8 = image.tensor, True
         out = torch.empty(reference.shape, dtype=torch.uint8, device=src.device)

@@ -81,8 +81,8 @@ def test_apply_transform_dtype_round_trip(host_api):
     assert got.tensor.dtype == torch.int16
     assert (np.abs(got.numpy().astype(np.int32) - want.arr.astype(np.int32)) <= 1).all()   # trunc() of values 1e-3 apart
     assert (got.numpy() != want.arr).mean() < 1e-3
-    with pytest.raises(NotImplementedError):
-        pa.registration.apply_transform(pa.image_from_array(ct, spacing, origin), transform=tfm, interpolator=pa.sitkBSpline)
+    with pytest.raises(ValueError):
+        pa.registration.apply_transform(pa.image_from_array(ct, spacing, origin), transform=tfm, interpolator=7)
 
 
 def test_apply_transform_affine_and_composite(host_api):
@@ -263,3 +263,40 @@ def test_demons_oriented_images_with_different_origins(host_api):
     np.testing.assert_allclose(i1.numpy(), i0.numpy(), rtol=0, atol=1e-3)
     assert (i1.numpy() != i0.numpy()).mean() < 1e-2
     np.testing.assert_allclose(d1.numpy(), np.einsum("rc,czyx->rzyx", R, d0.numpy().astype(np.float64)), rtol=0, atol=2e-5)
+
+
+def test_bspline_interpolation_matches_scipy(host_api):
+    """sitkBSpline (itk::BSplineInterpolateImageFunction, cubic; any sitk interpolator may reach apply_transform, reference
+    registration/utils.py:176-190): coefficient prefilter + 4x4x4 evaluation with mirror boundaries -- the same published
+    algorithm (Unser) as scipy.ndimage.map_coordinates(order=3, mode="mirror"), an implementation that shares no code
+    with this repo."""
+    from scipy import ndimage
+
+    pa = host_api
+    shape, spacing, origin = (11, 17, 23), (1.0, 1.2, 2.0), (5.0, -3.0, 1.0)
+    img = (phantom(shape, seed=8, noise=2) + 1000.0).astype(np.float32)
+    dvf = random_dvf(shape, spacing, seed=9, max_mm=3.0)
+    tfm = pa.DisplacementFieldTransform(pa.image_from_array(dvf, spacing, origin, is_vector=True))
+    got = pa.registration.apply_transform(pa.image_from_array(img, spacing, origin), transform=tfm, default_value=-7.0,
+                                          interpolator=pa.sitkBSpline).numpy()
+    zz, yy, xx = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing="ij")
+    cz, cy, cx = zz + dvf[2] / spacing[2], yy + dvf[1] / spacing[1], xx + dvf[0] / spacing[0]
+    want = ndimage.map_coordinates(img.astype(np.float64), [cz, cy, cx], order=3, mode="mirror")
+    inside = (cz >= -0.5) & (cz < shape[0] - 0.5) & (cy >= -0.5) & (cy < shape[1] - 0.5) & (cx >= -0.5) & (cx < shape[2] - 0.5)
+    assert 0.6 < inside.mean() < 1.0
+    np.testing.assert_allclose(got[inside], want[inside], rtol=0, atol=2e-3)       # fp32 coefficients of ~1000-valued data
+    assert np.all(got[~inside] == np.float32(-7.0))
+    # identity transform reproduces the samples (the interpolant passes through them)
+    same = pa.registration.apply_transform(pa.image_from_array(img, spacing, origin), interpolator=pa.sitkBSpline).numpy()
+    np.testing.assert_allclose(same, img, rtol=0, atol=2e-3)
+    # short lines take the exact boundary initialisation
+    small = (phantom((3, 5, 4), seed=3, noise=1)).astype(np.float32)
+    s2 = pa.registration.apply_transform(pa.image_from_array(small), interpolator=pa.sitkBSpline).numpy()
+    np.testing.assert_allclose(s2, small, rtol=0, atol=2e-3)
+    # and through the registration (interp_order = sitkBSpline at every resample of the loop)
+    fix, mov = _pair((12, 16, 20), (1.0, 1.0, 2.0), (0.0, 0.0, 0.0), seed=600, max_mm=1.0)
+    img3, _, d3 = pa.registration.fast_symmetric_forces_demons_registration(pa.image_from_array(fix, (1.0, 1.0, 2.0)),
+                                                                            pa.image_from_array(mov, (1.0, 1.0, 2.0)),
+                                                                            resolution_staging=[2, 1], iteration_staging=[3, 3],
+                                                                            interp_order=pa.sitkBSpline)
+    assert np.isfinite(d3.numpy()).all() and ((fix - img3.numpy()) ** 2).mean() < ((fix - mov) ** 2).mean()
