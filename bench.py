@@ -238,6 +238,69 @@ def cpu_baseline(fixed, moving, spacing, budget_s=12.0):
                       ("" if kind == "reference" else " (SimpleITK unavailable: C/OpenMP restatement stands in)")}
 
 
+class Ranks:
+    """The N > 1 skeleton of the bench (one process per GPU, launched by torch.distributed.run): process group, barrier,
+    max-over-ranks and a gather of every rank's own time.  `backend` "nccl" is RCCL on ROCm; "gloo" exists so that the
+    plumbing can be exercised without GPUs (tests/test_bench_plumbing.py) -- the timed work itself never runs on gloo."""
+
+    def __init__(self, world, device, backend=None):
+        self.world, self.device, self.dist = world, device, None
+        if world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            backend = backend or os.environ.get("PP_BENCH_BACKEND", "nccl")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(backend)
+            self.dist = dist
+        self.rank = self.dist.get_rank() if self.dist else 0
+
+    def _cdev(self):
+        return self.device if (self.dist and self.dist.get_backend() == "nccl") else "cpu"
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def max(self, x):
+        if not self.dist:
+            return float(x)
+        tt = torch.tensor([x], dtype=torch.float64, device=self._cdev())
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def gather(self, x):
+        """-> every rank's value, in rank order (on every rank)."""
+        if not self.dist:
+            return [float(x)]
+        mine = torch.tensor([x], dtype=torch.float64, device=self._cdev())
+        out = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [float(t.item()) for t in out]
+
+    def timed(self, fn, sync):
+        """Barrier + sync on both sides of fn(); -> (max over ranks, [per-rank seconds], load-imbalance fields)."""
+        self.barrier()
+        sync()
+        t0 = time.perf_counter()
+        fn()
+        sync()
+        own = time.perf_counter() - t0          # this rank's own work, before it waits for the others
+        self.barrier()
+        dt = time.perf_counter() - t0
+        per_rank = self.gather(own)
+        dt = self.max(dt)
+        mean = sum(per_rank) / len(per_rank)
+        return dt, per_rank, {"per_rank_s": per_rank, "slowest_rank": int(max(range(len(per_rank)), key=per_rank.__getitem__)),
+                              "imbalance": (max(per_rank) / mean - 1.0) if mean > 0 else 0.0}
+
+    def close(self):
+        if self.dist:
+            self.dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -263,15 +326,7 @@ def main():
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("PP_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" only to smoke-test the N > 1 path
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
+    ranks = Ranks(world, device)
 
     nx, ny, nz = args.size
     shape, spacing = (nz, ny, nx), (1.0, 1.0, 1.0)
@@ -297,14 +352,8 @@ def main():
     p.max_rms_error = 0.0                          # fixed iteration count for timing
     p.variant = {"auto": _lib.DEMONS_AUTO, "fused": _lib.DEMONS_FUSED, "staged": _lib.DEMONS_STAGED}[args.variant]
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
     def max_over_ranks(x):
-        tt = torch.tensor([x], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt.item())
+        return ranks.max(x)
 
     if args.warmup > 0:
         p.iterations = args.warmup
@@ -312,17 +361,9 @@ def main():
     torch.cuda.synchronize()
     ctx.profile_enable(not args.no_kernel_events)
     p.iterations = args.steps
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ctx.demons_execute(fixed, moving, geom, p, field, want_stats=False)
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, per_rank, balance = ranks.timed(lambda: ctx.demons_execute(fixed, moving, geom, p, field, want_stats=False), torch.cuda.synchronize)
     prof = ctx.profile_read()
     ctx.profile_enable(False)
-    if world > 1:
-        dt = max_over_ranks(dt)
 
     out = None
     if rank == 0:
@@ -391,6 +432,7 @@ def main():
             "config": {"workload": f"config 2 finest level: one fast-symmetric-forces demons iteration on a "
                                    f"{nx}x{ny}x{nz} fp32 CT-like pair per GPU, sigma_u 1.0 vox, sigma_d 1.5 mm, "
                                    f"schedule {args.variant}", "parallelism": f"1 atlas-to-target registration per GPU x{world}"},
+            "ranks": balance,
             "roofline": roofline,
             "roofline_iteration": {"achieved": iter_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": iter_gbps / HBM_PEAK_GBS,
                                    "compulsory_bytes_per_voxel": iter_bytes,
@@ -440,6 +482,8 @@ def main():
                 out["multi_atlas"] = {"atlases": world, "atlases_per_gpu": 1, "structures": 1, "seconds": dt_a,
                                       "atlases_per_min": 60.0 * world / dt_a, "fused_label_voxels": nvox_label,
                                       "dice_vs_template_label": dice_a,
+                                      "fusion_allreduce_bytes": getattr(__import__("platipy_amd").projects.multiatlas.run_segmentation,
+                                                                        "last_fusion_payload_bytes", None),
                                       "settings": "multiatlas/run.py defaults (affine GD-line-search 16/8/4 x50; demons isotropic "
                                                   "6/3/1.5 mm x150/125/100; local vote), atlases resident in HBM"}
         except Exception as e:
@@ -465,8 +509,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fixed, moving, spacing)
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -117,6 +117,11 @@ class _Dist:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t
 
+    def all_reduce_min(self, t):
+        if self.dist:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return t
+
     def all_gather(self, t):
         """-> list of world tensors shaped like t (rank order)."""
         if not self.dist:
@@ -188,6 +193,7 @@ def run_segmentation(img, settings=MUTLIATLAS_SETTINGS_DEFAULTS, atlases=None, s
     """
     out = atlas_pipeline(img, settings, None, atlases, streams_per_gpu, cardiac=False)
     run_segmentation.last_iar_removed = out["iar_removed"]
+    run_segmentation.last_fusion_payload_bytes = out["fusion_payload_bytes"]
     if return_atlas_set:
         return out["results"], out["results_prob"], out["atlas_set"]
     return out["results"], out["results_prob"]
@@ -346,16 +352,26 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
     vote_params = settings["label_fusion_settings"]["vote_params"]
     ctx = runtime.context(device)
     S, n = len(atlas_structure_list), img_crop.tensor.numel()
-    buf = torch.zeros((2 * S,) + img_crop.shape, dtype=torch.float32, device=device)   # [wsum_s, wlsum_s] per structure
+    # Payload of the one data-path collective.  When every atlas (on every rank) carries every structure the weight sum is
+    # the same for all structures, so the buffer is [sum w, sum w L_1 .. sum w L_S] = (1 + S) volumes; an atlas
+    # that lacks a structure does not vote on it (fusion.py:263-276), which needs a weight sum per structure: 2 S volumes.
+    complete = torch.tensor([1 if all(s in atlas_set[a]["DIR"] for a in my_ids for s in atlas_structure_list) else 0],
+                            dtype=torch.int32, device=device if dd.dist is None or dd.dist.get_backend() == "nccl" else "cpu")
+    shared_wsum = bool(int(dd.all_reduce_min(complete).item()))
+    buf = torch.zeros(((1 + S) if shared_wsum else 2 * S,) + img_crop.shape, dtype=torch.float32, device=device)
     for atlas_id in my_ids:
         d = atlas_set[atlas_id]["DIR"]
         d["Weight Map"] = compute_weight_map(img_crop, d["CT Image"], vote_type=vote_type, vote_params=vote_params)
         w = d["Weight Map"].tensor.contiguous()
         for k, s in enumerate(atlas_structure_list):
-            if s in d:
+            if shared_wsum:
+                ctx.fuse_accumulate(w, label_tensor(d[s]), buf[0] if k == 0 else None, buf[1 + k], n)
+            elif s in d:
                 ctx.fuse_accumulate(w, label_tensor(d[s]), buf[2 * k], buf[2 * k + 1], n)
     dd.all_reduce_sum(buf)
-    combined_label_dict = {s: finalize_probability(ctx, img_crop, buf[2 * k], buf[2 * k + 1]) for k, s in enumerate(atlas_structure_list)}
+    fusion_payload_bytes = buf.numel() * 4
+    combined_label_dict = {s: finalize_probability(ctx, img_crop, buf[0] if shared_wsum else buf[2 * k], buf[1 + k] if shared_wsum else buf[2 * k + 1])
+                           for k, s in enumerate(atlas_structure_list)}
     del buf
 
     # ---- step 6: threshold, largest component, paste back into the target's space (:373-404; cardiac :928-1004) ----
@@ -370,11 +386,16 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
         prob = combined_label_dict[s]
         binary = process_probability_image(prob, thresholds.get(s, 0.5))
         if cardiac and settings.get("return_proba_as_contours", False):      # cardiac/run.py:945-951, 964-970
-            if dd.world > 1:
-                raise NotImplementedError("return_proba_as_contours needs every atlas's contour on one rank: single-process runs only")
-            from ..label.utils import binary_encode_structure_list
-
-            prob = binary_encode_structure_list([process_probability_image(atlas_set[a]["DIR"][s], 0.5) for a in atlas_id_list])
+            # atlas k's contour in bit k + 1 (label/utils.py:219-254).  Each rank encodes its own atlases at their positions
+            # in the global list; the bit sets are disjoint, so one integer all_reduce(SUM) assembles the image everywhere
+            enc = torch.zeros(img_crop.shape, dtype=torch.int64, device=device)
+            for pos, a in enumerate(atlas_id_list):
+                if a in atlas_set and "DIR" in atlas_set[a] and s in atlas_set[a]["DIR"]:
+                    enc |= (process_probability_image(atlas_set[a]["DIR"][s], 0.5).tensor != 0).to(torch.int64) << (pos + 1)
+            if len(atlas_id_list) > 32:
+                raise ValueError("You can only encode a maximum of 32 structures with this method!")
+            dd.all_reduce_sum(enc)
+            prob = img_crop.like(enc)
             template_p = img.like(torch.zeros(img.shape, dtype=prob.tensor.dtype, device=device))
         else:
             template_p = template_prob
@@ -407,4 +428,5 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
 
     if as_cropped:
         results["CROP_IMAGE"] = img_crop
-    return {"results": results, "results_prob": results_prob, "atlas_set": atlas_set, "iar_removed": removed, "img_crop": img_crop}
+    return {"results": results, "results_prob": results_prob, "atlas_set": atlas_set, "iar_removed": removed, "img_crop": img_crop,
+            "fusion_payload_bytes": fusion_payload_bytes}

@@ -1,0 +1,59 @@
+"""bench.py's N > 1 skeleton (process group, barrier-bracketed timing, max over ranks, per-rank gather, load-imbalance
+fields) on world_size 2 over gloo -- no GPU involved: the driver's first multi-GPU run must not die on plumbing.
+The timed work itself is GPU-only (bench.py refuses to run without one); here a stand-in step with a known per-rank
+duration goes through exactly the code path `--gpus N` uses."""
+import json
+import os
+import time
+
+import pytest
+import torch
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
+                       "LOCAL_RANK": str(rank)})
+    import bench
+
+    ranks = bench.Ranks(world, torch.device("cpu"), backend="gloo")
+    try:
+        assert ranks.rank == rank
+        dt, per_rank, balance = ranks.timed(lambda: time.sleep(0.05 + 0.10 * rank), lambda: None)
+        mx = ranks.max(float(rank + 1))
+        if rank == 0:
+            json.dump({"dt": dt, "per_rank": per_rank, "balance": balance, "max": mx}, open(os.path.join(out_dir, "r.json"), "w"))
+    finally:
+        ranks.close()
+
+
+def test_ranks_skeleton_two_processes_gloo(tmp_path):
+    import torch.multiprocessing as mp
+
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = json.load(open(tmp_path / "r.json"))
+    assert r["max"] == 2.0
+    assert len(r["per_rank"]) == 2 and 0.04 < r["per_rank"][0] < 0.12 and 0.14 < r["per_rank"][1] < 0.30
+    assert r["dt"] >= max(r["per_rank"]) - 1e-3                     # the job's time is the slowest rank's (plus the barrier)
+    assert r["balance"]["slowest_rank"] == 1 and r["balance"]["imbalance"] > 0.2
+    assert r["balance"]["per_rank_s"] == r["per_rank"]
+
+
+def test_ranks_skeleton_single_process():
+    import bench
+
+    ranks = bench.Ranks(1, torch.device("cpu"))
+    dt, per_rank, balance = ranks.timed(lambda: time.sleep(0.01), lambda: None)
+    assert len(per_rank) == 1 and dt >= 0.01 and balance["imbalance"] == 0.0 and ranks.max(3.0) == 3.0
+    ranks.close()
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    import subprocess
+    import sys
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "needs a GPU" in (p.stderr + p.stdout)

@@ -92,6 +92,9 @@ def _worker(rank, world, port, out_dir):
         target, _, _, atlases = _data(pa, ids)
         mine = {k: v for k, v in atlases.items() if k in ids[rank::world]}   # a rank only needs its own share
         results, prob = pa.projects.multiatlas.run_segmentation(target, _settings(ids), atlases=mine)
+        # every atlas holds both structures: the fusion all_reduce carries [sum w, sum w L_1, sum w L_2] = 1 + S volumes
+        crop_voxels = pa.projects.multiatlas.run_segmentation.last_fusion_payload_bytes // (4 * 3)
+        assert pa.projects.multiatlas.run_segmentation.last_fusion_payload_bytes == 3 * 4 * crop_voxels and crop_voxels > 1000
         np.save(os.path.join(out_dir, f"wh_{rank}.npy"), results["WHOLEHEART"].numpy())
         np.save(os.path.join(out_dir, f"prob_{rank}.npy"), prob["WHOLEHEART"].numpy())
     finally:
@@ -222,3 +225,64 @@ def test_run_segmentation_with_iterative_atlas_removal(host_api):
     removed = pa.projects.multiatlas.run_segmentation.last_iar_removed
     assert bad in removed and len(removed) <= 3          # the IQR fence on six atlases may also drop a borderline one
     assert dice(res["WHOLEHEART"].numpy(), tmask) > 0.9
+
+
+def test_fusion_payload_with_a_structure_missing_from_one_atlas(host_api):
+    """An atlas without a structure does not vote on it (fusion.py:263-276): the weight sums then differ per structure and
+    the exchange buffer falls back to 2 S volumes; the probabilities equal combine_labels' on the same atlases."""
+    pa = host_api
+    ids = ["001", "002", "003"]
+    target, tmask, tsub, atlases = _data(pa, ids)
+    del atlases["002"]["SUBSTRUCTURE"]
+    results, prob = pa.projects.multiatlas.run_segmentation(target, _settings(ids), atlases=atlases)
+    nbytes = pa.projects.multiatlas.run_segmentation.last_fusion_payload_bytes
+    assert nbytes % (4 * 4) == 0                                   # 2 S = 4 volumes
+    assert dice(results["WHOLEHEART"].numpy(), tmask) > 0.93 and dice(results["SUBSTRUCTURE"].numpy(), tsub) > 0.5
+
+
+def _contours_worker(rank, world, port, out_dir):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world)})
+    import torch.distributed as dist
+
+    import platipy_amd as pa
+    from tests.helpers import install_emu_runtime
+    from tests.test_cardiac import _reference_test_settings, cardiac_data
+
+    install_emu_runtime()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        data = cardiac_data(pa, 2)
+        cases = list(data.keys())
+        st = _reference_test_settings(pa, cases, out_dir, ["WHOLEHEART"], False)
+        st["return_proba_as_contours"] = True
+        atl = {c: {"CT Image": data[c]["CT"], "WHOLEHEART": data[c]["WHOLEHEART"]} for c in cases[:-1][rank::world]}
+        out, prob = pa.projects.cardiac.run_cardiac_segmentation(data[cases[-1]]["CT"], settings=st, atlases=atl)
+        np.save(os.path.join(out_dir, f"enc_{rank}.npy"), prob["WHOLEHEART"].numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_return_proba_as_contours_two_ranks_gloo(tmp_path, monkeypatch):
+    """cardiac/run.py:945-970 with the atlases spread over two ranks: every rank ends with the image that encodes atlas
+    k's contour in bit k + 1 (one integer all_reduce of disjoint bit sets), equal to the single-process encoding."""
+    import torch.multiprocessing as mp
+
+    import platipy_amd as pa
+    from tests.helpers import install_emu_runtime
+    from tests.test_cardiac import _reference_test_settings, cardiac_data
+
+    port = 36500 + (os.getpid() % 2000)
+    mp.spawn(_contours_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    e0, e1 = np.load(tmp_path / "enc_0.npy"), np.load(tmp_path / "enc_1.npy")
+    np.testing.assert_array_equal(e0, e1)
+    install_emu_runtime(lambda obj, name, value: monkeypatch.setattr(obj, name, value, raising=False))
+    data = cardiac_data(pa, 2)
+    cases = list(data.keys())
+    st = _reference_test_settings(pa, cases, tmp_path, ["WHOLEHEART"], False)
+    st["return_proba_as_contours"] = True
+    atl = {c: {"CT Image": data[c]["CT"], "WHOLEHEART": data[c]["WHOLEHEART"]} for c in cases[:-1]}
+    _, prob = pa.projects.cardiac.run_cardiac_segmentation(data[cases[-1]]["CT"], settings=st, atlases=atl)
+    single = prob["WHOLEHEART"].numpy()
+    np.testing.assert_array_equal(e0, single)
+    assert set(np.unique(single)) - {0} and (single & 0b11110).max() > 0        # bits 1..4 = the four atlases
