@@ -184,17 +184,15 @@ def multi_atlas_streams_leg(ctx, shape, spacing, device, rank=0, world=1, per_gp
     return dt, dice, list(getattr(run_segmentation, "last_iar_removed", []))
 
 
-def cpu_baseline(fixed, moving, spacing, budget_s=12.0):
-    """The reference's CPU path timed beside the GPU.  SimpleITK (the reference's own arithmetic)
-    is used when importable; otherwise the oracle (C/OpenMP restatement) stands in, labelled "port"."""
-    nz, ny, nx = fixed.shape
-    cz, cy, cx = min(nz, 96), min(ny, 192), min(nx, 192)
-    sl = (slice((nz - cz) // 2, (nz - cz) // 2 + cz), slice((ny - cy) // 2, (ny - cy) // 2 + cy),
-          slice((nx - cx) // 2, (nx - cx) // 2 + cx))
-    f = fixed[sl].cpu().numpy().copy()
-    m = moving[sl].cpu().numpy().copy()
+def cpu_baseline(fixed, moving, spacing, budget_s=15.0):
+    """The reference's CPU path timed beside the GPU, on the metric's own configuration (the full bench pair, not a crop).
+    SimpleITK (the reference's own arithmetic) is used when importable; otherwise the oracle (C/OpenMP restatement, fp64
+    field like ITK) stands in, labelled "port".  A reported baseline, not a target: the GPU/CPU ratio says nothing about
+    kernel quality (the roofline fraction does) and is deliberately not computed here."""
+    f = fixed.cpu().numpy()
+    m = moving.cpu().numpy()
+    nz, ny, nx = f.shape
     nvox = f.size
-    sample = f"centre crop {cx}x{cy}x{cz} of the bench pair"
     try:
         import SimpleITK as sitk  # noqa: F401
 
@@ -229,13 +227,12 @@ def cpu_baseline(fixed, moving, spacing, budget_s=12.0):
             return time.perf_counter() - t0
 
         kind, cores = "port", O.lib().orc_num_threads()
-    run(1)  # thread pool / page-in
-    t1 = run(1)
-    n = int(max(2, min(40, budget_s / max(t1, 1e-3))))
+    t1 = run(1)                                # also pages the arrays in and starts the thread pool
+    n = int(max(1, min(10, (budget_s - t1) / max(t1, 1e-3))))
     t = run(n)
     return {"value": nvox * n / t / 1e6, "unit": "Mvoxels/s per demons iter", "cores": cores, "kind": kind,
-            "sample": f"{sample}, {n} iterations, {t:.1f} s" +
-                      ("" if kind == "reference" else " (SimpleITK unavailable: C/OpenMP restatement stands in)")}
+            "sample": f"the whole {nx}x{ny}x{nz} bench pair, {n} iteration(s) in {t:.1f} s after a 1-iteration warm-up of {t1:.1f} s" +
+                      ("" if kind == "reference" else " (SimpleITK unavailable: C/OpenMP fp64 restatement stands in)")}
 
 
 class Ranks:

@@ -292,48 +292,88 @@ int orc_gaussian_operator(double variance, double max_error, int max_kernel_widt
 /* directional FIR with ZeroFluxNeumann (clamped index) boundary; sum runs from the
  * neighbourhood's first element to its last (itk::NeighborhoodInnerProduct). */
 
+/* Row-wise form (same sums, same order: for every voxel s = 0, then s += c[k] * in[.] for k = -r .. r): the outer loops
+ * run over (z, y) rows with a static schedule, the inner loop over x is unit-stride for the y / z passes (the tap's source
+ * row is fixed per k) so it vectorises; the x pass clamps per element. */
 static void conv_axis_f32(const float* in, float* out, const int* n, int axis,
                           const double* c, int r) {
   const long nx = n[0], ny = n[1], nz = n[2];
-  const long stride = axis == 0 ? 1 : (axis == 1 ? nx : nx * ny);
-  const long len = n[axis];
-#pragma omp parallel for collapse(2) schedule(static)
-  for (long z = 0; z < nz; ++z)
-    for (long y = 0; y < ny; ++y)
-      for (long x = 0; x < nx; ++x) {
-        const long pos = axis == 0 ? x : (axis == 1 ? y : z);
-        const size_t base = (size_t)z * ny * nx + (size_t)y * nx + x;
-        double s = 0.0;
-        for (int k = -r; k <= r; ++k) {
-          long q = pos + k;
-          if (q < 0) q = 0;
-          if (q > len - 1) q = len - 1;
-          s += c[k + r] * (double)in[(long)base + (q - pos) * stride];
+#pragma omp parallel
+  {
+    double* acc = (double*)malloc(sizeof(double) * (size_t)nx);
+#pragma omp for collapse(2) schedule(static)
+    for (long z = 0; z < nz; ++z)
+      for (long y = 0; y < ny; ++y) {
+        const size_t base = ((size_t)z * ny + y) * nx;
+        for (long x = 0; x < nx; ++x) acc[x] = 0.0;
+        if (axis == 0) {
+          for (int k = -r; k <= r; ++k) {
+            const double w = c[k + r];
+            for (long x = 0; x < nx; ++x) {
+              long q = x + k;
+              if (q < 0) q = 0;
+              if (q > nx - 1) q = nx - 1;
+              acc[x] += w * (double)in[base + q];
+            }
+          }
+        } else {
+          const long pos = axis == 1 ? y : z, len = axis == 1 ? ny : nz;
+          for (int k = -r; k <= r; ++k) {
+            long q = pos + k;
+            if (q < 0) q = 0;
+            if (q > len - 1) q = len - 1;
+            const float* row = axis == 1 ? in + ((size_t)z * ny + q) * nx : in + ((size_t)q * ny + y) * nx;
+            const double w = c[k + r];
+            for (long x = 0; x < nx; ++x) acc[x] += w * (double)row[x];
+          }
         }
-        out[base] = (float)s;
+        for (long x = 0; x < nx; ++x) out[base + x] = (float)acc[x];
       }
+    free(acc);
+  }
 }
 
 static void conv_axis_f64(const double* in, double* out, const int* n, int axis,
                           const double* c, int r) {
   const long nx = n[0], ny = n[1], nz = n[2];
-  const long stride = axis == 0 ? 1 : (axis == 1 ? nx : nx * ny);
-  const long len = n[axis];
 #pragma omp parallel for collapse(2) schedule(static)
   for (long z = 0; z < nz; ++z)
-    for (long y = 0; y < ny; ++y)
-      for (long x = 0; x < nx; ++x) {
-        const long pos = axis == 0 ? x : (axis == 1 ? y : z);
-        const size_t base = (size_t)z * ny * nx + (size_t)y * nx + x;
-        double s = 0.0;
+    for (long y = 0; y < ny; ++y) {
+      const size_t base = ((size_t)z * ny + y) * nx;
+      double* acc = out + base;
+      for (long x = 0; x < nx; ++x) acc[x] = 0.0;
+      if (axis == 0) {
+        for (int k = -r; k <= r; ++k) {
+          const double w = c[k + r];
+          for (long x = 0; x < nx; ++x) {
+            long q = x + k;
+            if (q < 0) q = 0;
+            if (q > nx - 1) q = nx - 1;
+            acc[x] += w * in[base + q];
+          }
+        }
+      } else {
+        const long pos = axis == 1 ? y : z, len = axis == 1 ? ny : nz;
         for (int k = -r; k <= r; ++k) {
           long q = pos + k;
           if (q < 0) q = 0;
           if (q > len - 1) q = len - 1;
-          s += c[k + r] * in[(long)base + (q - pos) * stride];
+          const double* row = axis == 1 ? in + ((size_t)z * ny + q) * nx : in + ((size_t)q * ny + y) * nx;
+          const double w = c[k + r];
+          for (long x = 0; x < nx; ++x) acc[x] += w * row[x];
         }
-        out[base] = s;
       }
+    }
+}
+
+/* parallel copy / fill with the same static (z, y)-row partition as the passes, so pages are first touched -- and later
+ * read -- by the thread that owns the rows (NUMA placement on the many-core GPU hosts) */
+static void par_zero_f64(double* dst, size_t n) {
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)((n + 4095) / 4096); ++i) {
+    const size_t a = (size_t)i * 4096, b = a + 4096 < n ? a + 4096 : n;
+    memset(dst + a, 0, (b - a) * sizeof(double));
+  }
 }
 
 #define MAX_TAPS 4096
@@ -370,29 +410,29 @@ int orc_discrete_gaussian_f32(const float* in, float* out, const int size[3],
 int orc_smooth_field_f64(double* field, const int size[3], const double sigma_vox[3],
                          double max_error, int max_kernel_width) {
   const size_t N = (size_t)size[0] * size[1] * size[2];
-  double* tmp = (double*)malloc(N * sizeof(double));
-  double* c = (double*)malloc(sizeof(double) * MAX_TAPS);
-  if (!tmp || !c) return -2;
+  double* t1 = (double*)malloc(N * sizeof(double));
+  double* t2 = (double*)malloc(N * sizeof(double));
+  double* c[3];
+  int r[3];
+  if (!t1 || !t2) return -2;
   /* itkPDEDeformableRegistrationFilter::SmoothDisplacementField: for j = 0..D-1 (x, y, z),
    * GaussianOperator(variance = sigma_j^2, MaximumError, MaximumKernelWidth), each pass over
    * the whole field before the next. */
+  for (int axis = 0; axis < 3; ++axis) {
+    c[axis] = (double*)malloc(sizeof(double) * MAX_TAPS);
+    if (!c[axis]) return -2;
+    r[axis] = orc_gaussian_operator(sigma_vox[axis] * sigma_vox[axis], max_error, max_kernel_width, c[axis], MAX_TAPS);
+    if (r[axis] < 0) return -1;
+  }
   for (int comp = 0; comp < 3; ++comp) {
     double* f = field + comp * N;
-    double* src = f;
-    double* dst = tmp;
-    for (int axis = 0; axis < 3; ++axis) {
-      int r = orc_gaussian_operator(sigma_vox[axis] * sigma_vox[axis], max_error,
-                                    max_kernel_width, c, MAX_TAPS);
-      if (r < 0) return -1;
-      conv_axis_f64(src, dst, size, axis, c, r);
-      double* t = src;
-      src = dst;
-      dst = t;
-    }
-    if (src != f) memcpy(f, src, N * sizeof(double));
+    conv_axis_f64(f, t1, size, 0, c[0], r[0]);
+    conv_axis_f64(t1, t2, size, 1, c[1], r[1]);
+    conv_axis_f64(t2, f, size, 2, c[2], r[2]);      /* the last pass reads only t2: it lands in place */
   }
-  free(tmp);
-  free(c);
+  free(t1);
+  free(t2);
+  for (int axis = 0; axis < 3; ++axis) free(c[axis]);
   return 0;
 }
 
@@ -571,7 +611,8 @@ int orc_demons_execute(const float* fixed, const float* moving, const orc_geom* 
   float* warped = (float*)malloc(N * sizeof(float));
   double* update = (double*)malloc(3 * N * sizeof(double));
   if (!warped || !update) return -2;
-  memset(field, 0, 3 * N * sizeof(double)); /* CopyInputToOutput with no initial field */
+  par_zero_f64(field, 3 * N); /* CopyInputToOutput with no initial field */
+  par_zero_f64(update, 3 * N);   /* first touch by the threads that will own the rows */
   orc_demons_stats st;
   memset(&st, 0, sizeof(st));
   st.metric = DBL_MAX;
