@@ -139,9 +139,223 @@ __global__ void __launch_bounds__(NT) k_conv_x4(const float* __restrict__ in, co
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Register-window passes along y / z (radius <= 16) and a wavefront-shuffle pass along x (radius <= 16).
+//
+// y / z: a thread owns a column of VEC consecutive x voxels and MARCHES along the pass axis over a segment of SEG outputs,
+// keeping the last 2 RB + 1 inputs in registers: every input is loaded once (coalesced along x) and every output stored
+// once -- 8 B/voxel through HBM instead of (2r + 1) L2 re-reads.  The loop is unrolled 2 RB + 1 times so that the window
+// is renamed, not moved.  RB is a radius BUCKET >= r: taps beyond r are zero, which leaves every sum bit-identical
+// (fma(0, v, s) = s for finite v; the leading zero taps give +0, the value the sum starts from).  VEC = 4 up to bucket 8,
+// scalar columns above (the window would not fit the register file otherwise).
+template <int RB>
+struct taps_bucket {
+  float w[2 * RB + 1];
+};
+
+template <int AXIS, int RB, int VEC, bool ADD>
+__global__ void __launch_bounds__(NT) k_fir_march(const float* __restrict__ in, const float* __restrict__ add, float* __restrict__ out, pp_dims d,
+                                                  size_t cstride, taps_bucket<RB> taps, int seg, const int* __restrict__ halt) {
+  if (halt && *halt) return;
+  constexpr int W = 2 * RB + 1;
+  const size_t comp = (size_t)blockIdx.z * cstride;
+  in += comp;
+  out += comp;
+  if (ADD) add += comp;
+  const int nxv = d.nx / VEC;
+  const int len = AXIS == 1 ? d.ny : d.nz;          // pass axis
+  const int other = AXIS == 1 ? d.nz : d.ny;        // the remaining axis
+  const size_t stride = AXIS == 1 ? (size_t)d.nx : (size_t)d.nx * d.ny;
+  const size_t ostride = AXIS == 1 ? (size_t)d.nx * d.ny : (size_t)d.nx;
+  const size_t ncol = (size_t)nxv * other;
+  const size_t col = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (col >= ncol) return;
+  const int xv = (int)(col % nxv), o = (int)(col / nxv);
+  const size_t base = (size_t)o * ostride + (size_t)xv * VEC;
+  const int p0 = blockIdx.y * seg;
+  const int p1 = p0 + seg < len ? p0 + seg : len;
+  auto load = [&](int q, float (&v)[VEC]) {
+    q = q < 0 ? 0 : (q > len - 1 ? len - 1 : q);
+    const size_t a = base + (size_t)q * stride;
+    if (VEC == 4) {
+      float4 t = *reinterpret_cast<const float4*>(in + a);
+      if (ADD) {
+        const float4 u = *reinterpret_cast<const float4*>(add + a);
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[VEC - 1] = t.w;
+    } else {
+      v[0] = in[a];
+      if (ADD) v[0] += add[a];
+    }
+  };
+  float win[W][VEC];
+#pragma unroll
+  for (int k = 0; k < W - 1; ++k) load(p0 - RB + k, win[(k + 1) % W]);   // slots 1 .. W-1 hold inputs p0-RB .. p0+RB-1
+  for (int pb = p0; pb < p1; pb += W) {
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+      const int pos = pb + u;
+      if (pos < p1) {
+        // the newest input (pos + RB) goes to slot u; the oldest (pos - RB) sits in slot u + 1
+        load(pos + RB, win[u % W]);
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < W; ++k)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v] = fmaf(taps.w[k], win[(u + 1 + k) % W][v], acc[v]);
+        const size_t a = base + (size_t)pos * stride;
+        if (VEC == 4) *reinterpret_cast<float4*>(out + a) = make_float4(acc[0], acc[1], acc[2], acc[VEC - 1]);
+        else out[a] = acc[0];
+      }
+    }
+  }
+}
+
+// x pass: a lane holds four consecutive voxels of a row, a wavefront 256; the (up to 16) neighbours on either side come
+// from the adjacent lanes by wavefront shuffles, from memory only at the ends of a wavefront's span and of the row
+// (clamped: ZeroFluxNeumann).  One 16-byte load and one 16-byte store per lane.
+template <int RB, bool ADD>
+__global__ void __launch_bounds__(NT) k_fir_x_shfl(const float* __restrict__ in, const float* __restrict__ add, float* __restrict__ out, pp_dims d,
+                                                   size_t cstride, taps_bucket<RB> taps, const int* __restrict__ halt) {
+  if (halt && *halt) return;
+  constexpr int NB4 = (RB + 3) / 4;                 // neighbour strips per side
+  const size_t comp = (size_t)blockIdx.z * cstride;
+  in += comp;
+  out += comp;
+  if (ADD) add += comp;
+  const int nxv = d.nx / 4;
+  const int spans = (nxv + 63) / 64;                // wavefront spans per row
+  const size_t nrows = (size_t)d.ny * d.nz;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // block-uniform trip count: every thread runs every round (shuffles need the whole wavefront)
+  const size_t nwork = nrows * spans;
+  for (size_t w0 = (size_t)blockIdx.x * (NT / 64); w0 < nwork; w0 += (size_t)gridDim.x * (NT / 64)) {
+    const size_t wk = w0 + wave;
+    const bool live_w = wk < nwork;
+    const size_t row = live_w ? wk / spans : 0;
+    const int span = live_w ? (int)(wk % spans) : 0;
+    const int xv = span * 64 + lane;
+    const bool live = live_w && xv < nxv;
+    const size_t rb = row * (size_t)d.nx;
+    auto strip = [&](int sv, float (&v)[4]) {       // strip sv of the row, clamped element-wise at the row ends
+      if (sv >= 0 && sv < nxv) {
+        float4 t = *reinterpret_cast<const float4*>(in + rb + 4 * (size_t)sv);
+        if (ADD) {
+          const float4 u = *reinterpret_cast<const float4*>(add + rb + 4 * (size_t)sv);
+          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+        const size_t e = rb + (sv < 0 ? 0 : (size_t)d.nx - 1);
+        float t = in[e];
+        if (ADD) t += add[e];
+        v[0] = v[1] = v[2] = v[3] = t;
+      }
+    };
+    float c[4 * (2 * NB4 + 1)];                      // [left strips .. own .. right strips]
+    float own[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (live) strip(xv, own);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[4 * NB4 + j] = own[j];
+#pragma unroll
+    for (int s_ = 1; s_ <= NB4; ++s_) {
+      float l[4], r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        l[j] = __shfl_up(own[j], s_, 64);
+        r[j] = __shfl_down(own[j], s_, 64);
+      }
+      if (live && (lane < s_)) strip(xv - s_, l);                        // no lane to the left in this wavefront
+      if (live && (lane + s_ > 63 || xv + s_ >= nxv)) strip(xv + s_, r); // ... or to the right / beyond the row
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        c[4 * (NB4 - s_) + j] = l[j];
+        c[4 * (NB4 + s_) + j] = r[j];
+      }
+    }
+    if (live) {
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 2 * RB + 1; ++k) a = fmaf(taps.w[k], c[4 * NB4 + j - RB + k], a);
+        o[j] = a;
+      }
+      *reinterpret_cast<float4*>(out + rb + 4 * (size_t)xv) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+template <int RB>
+taps_bucket<RB> bucket_taps(const pp_taps& t) {
+  taps_bucket<RB> b;
+  for (int k = 0; k < 2 * RB + 1; ++k) {
+    const int kk = k - RB + t.r;                     // index into the true taps
+    b.w[k] = (kk >= 0 && kk <= 2 * t.r) ? t.w[kk] : 0.0f;
+  }
+  return b;
+}
+
+template <int AXIS, int RB, int VEC, bool ADD>
+void launch_march(pp_ctx* ctx, const float* in, const float* add, float* out, const pp_dims& d, int ncomp, const pp_taps& taps, const int* halt) {
+  const size_t cstride = (size_t)d.nx * d.ny * d.nz;
+  const int len = AXIS == 1 ? d.ny : d.nz, other = AXIS == 1 ? d.nz : d.ny;
+  const size_t ncol = (size_t)(d.nx / VEC) * other;
+  const unsigned bx = (unsigned)((ncol + NT - 1) / NT);
+  // segments: enough blocks to fill 256 CUs x 8, but not shorter than 8 windows (the 2 RB halo loads amortise)
+  int nseg = (int)((2048 + bx - 1) / bx);
+  const int min_seg = 8 * (2 * RB + 1) < 32 ? 32 : 8 * (2 * RB + 1);
+  if (nseg > (len + min_seg - 1) / min_seg) nseg = (len + min_seg - 1) / min_seg;
+  if (nseg < 1) nseg = 1;
+  const int seg = (len + nseg - 1) / nseg;
+  nseg = (len + seg - 1) / seg;
+  hipLaunchKernelGGL((k_fir_march<AXIS, RB, VEC, ADD>), dim3(bx, (unsigned)nseg, (unsigned)ncomp), dim3(NT), 0, ctx->stream, in, add, out, d,
+                     cstride, bucket_taps<RB>(taps), seg, halt);
+}
+
+template <int RB, bool ADD>
+void launch_x_shfl(pp_ctx* ctx, const float* in, const float* add, float* out, const pp_dims& d, int ncomp, const pp_taps& taps, const int* halt) {
+  const size_t cstride = (size_t)d.nx * d.ny * d.nz;
+  const size_t nwork = (size_t)d.ny * d.nz * (((size_t)d.nx / 4 + 63) / 64);
+  size_t blocks = (nwork + NT / 64 - 1) / (NT / 64);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL((k_fir_x_shfl<RB, ADD>), dim3((unsigned)blocks, 1, (unsigned)ncomp), dim3(NT), 0, ctx->stream, in, add, out, d, cstride,
+                     bucket_taps<RB>(taps), halt);
+}
+
 template <int AXIS, bool ADD>
 int launch_axis(pp_ctx* ctx, const float* in, const float* add, float* out, const pp_dims& d, int ncomp,
                 const pp_taps& taps, const int* halt, const uint8_t* need_y = nullptr, const uint8_t* need_z = nullptr) {
+  const bool al16 = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | (ADD ? reinterpret_cast<uintptr_t>(add) : 0)) % 16 == 0);
+  if (!need_y && !need_z && !getenv("PP_FIR_LEGACY")) {
+    const int r = taps.r;
+    if (AXIS != 0) {
+      const bool v4 = al16 && (d.nx % 4 == 0);
+#define PP_MARCH(RB, VEC)                                                                    \
+  do {                                                                                       \
+    launch_march<(AXIS == 0 ? 1 : AXIS), RB, VEC, ADD>(ctx, in, add, out, d, ncomp, taps, halt); \
+    PP_LAUNCH_CHECK(ctx, "k_fir_march");                                                    \
+    return PP_OK;                                                                            \
+  } while (0)
+      if (v4 && r <= 2) PP_MARCH(2, 4);
+      if (v4 && r <= 4) PP_MARCH(4, 4);
+      if (v4 && r <= 8) PP_MARCH(8, 4);
+      if (r <= 8) PP_MARCH(8, 1);
+      if (r <= 16) PP_MARCH(16, 1);
+#undef PP_MARCH
+    } else if (al16 && (d.nx % 4 == 0) && r <= 16) {
+      if (r <= 4) launch_x_shfl<4, ADD>(ctx, in, add, out, d, ncomp, taps, halt);
+      else if (r <= 8) launch_x_shfl<8, ADD>(ctx, in, add, out, d, ncomp, taps, halt);
+      else launch_x_shfl<16, ADD>(ctx, in, add, out, d, ncomp, taps, halt);
+      PP_LAUNCH_CHECK(ctx, "k_fir_x_shfl");
+      return PP_OK;
+    }
+  }
   const size_t cstride = (size_t)d.nx * d.ny * d.nz;
   if (AXIS == 0 && (d.nx % 4 == 0) && taps.r >= 3 &&
       ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | (ADD ? reinterpret_cast<uintptr_t>(add) : 0)) % 16 == 0)) {

@@ -188,6 +188,43 @@ __device__ __forceinline__ float pp_trilinear(const T* __restrict__ im, int nx, 
   return v0 + (v1 - v0) * wz;
 }
 
+// The same sample with the two x corners of each row fetched as ONE access of 2 sizeof(T) bytes from an element-aligned
+// position (global accesses run in unaligned mode on gfx950): a gather's cost is its memory instructions, and this
+// halves them.  The pair starts at min(x0, nx - 2); on the last index -- where ITK's upper corner repeats the lower one
+// -- both corners are its second element, so nothing is read past the row.  Needs nx >= 2.  Same lerps, same order.
+template <typename T>
+struct pp_pair {
+  T x, y;
+} __attribute__((packed, aligned(sizeof(T))));
+
+template <typename T>
+__device__ __forceinline__ float pp_trilinear_pairs(const T* __restrict__ im, int nx, int ny, int nz, int bx,
+                                                    float fx, int by, float fy, int bz, float fz) {
+  int x0, x1, y0, y1, z0, z1;
+  float wx, wy, wz;
+  pp_axis_setup(bx, fx, nx, x0, x1, wx);
+  pp_axis_setup(by, fy, ny, y0, y1, wy);
+  pp_axis_setup(bz, fz, nz, z0, z1, wz);
+  const bool xlast = x0 > nx - 2;
+  const size_t xs = (size_t)(xlast ? nx - 2 : x0);
+  const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+  const pp_pair<T> p00 = *reinterpret_cast<const pp_pair<T>*>(im + z0 * sz + y0 * sy + xs);
+  const pp_pair<T> p10 = *reinterpret_cast<const pp_pair<T>*>(im + z0 * sz + y1 * sy + xs);
+  const pp_pair<T> p01 = *reinterpret_cast<const pp_pair<T>*>(im + z1 * sz + y0 * sy + xs);
+  const pp_pair<T> p11 = *reinterpret_cast<const pp_pair<T>*>(im + z1 * sz + y1 * sy + xs);
+  const float a000 = (float)(xlast ? p00.y : p00.x), a100 = (float)p00.y;
+  const float a010 = (float)(xlast ? p10.y : p10.x), a110 = (float)p10.y;
+  const float a001 = (float)(xlast ? p01.y : p01.x), a101 = (float)p01.y;
+  const float a011 = (float)(xlast ? p11.y : p11.x), a111 = (float)p11.y;
+  const float v00 = a000 + (a100 - a000) * wx;
+  const float v10 = a010 + (a110 - a010) * wx;
+  const float v01 = a001 + (a101 - a001) * wx;
+  const float v11 = a011 + (a111 - a011) * wx;
+  const float v0 = v00 + (v10 - v00) * wy;
+  const float v1 = v01 + (v11 - v01) * wy;
+  return v0 + (v1 - v0) * wz;
+}
+
 // Split idx + dv (dv = displacement in voxels) into integer base and fraction without the
 // precision loss of forming the sum in fp32.
 __device__ __forceinline__ void pp_split(int idx, float dv, int& b, float& f) {

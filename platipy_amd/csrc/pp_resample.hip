@@ -19,6 +19,20 @@ namespace {
 
 constexpr int NT = 256;
 
+// Launch geometry of the per-voxel kernels: thread (x, y) of a (bx, 256 / bx) block, grid (x blocks, y blocks, z) -- no
+// 64-bit division per voxel to recover (x, y, z) from a linear index.  bx = 64 / 128 / 256 lanes along x by row length.
+struct pp_grid3 {
+  dim3 grid, block;
+};
+pp_grid3 grid3_for(int nxv, int ny, int nz) {
+  const unsigned bx = nxv <= 64 ? 64u : (nxv <= 128 ? 128u : 256u);
+  const unsigned by = NT / bx;
+  pp_grid3 g;
+  g.block = dim3(bx, by, 1);
+  g.grid = dim3((unsigned)((nxv + bx - 1) / bx), (unsigned)((ny + by - 1) / by), (unsigned)nz);
+  return g;
+}
+
 // ---------------------------------------------------------------------------------------
 // same-grid warp
 
@@ -29,11 +43,9 @@ __global__ void __launch_bounds__(NT) k_warp_same_grid(const float* __restrict__
   if (halt && *halt) return;
   const int nxv = d.nx / VEC;
   const size_t N = (size_t)d.nx * d.ny * d.nz;
-  const size_t total = N / VEC;
-  for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
-    const int x0 = (int)(e % nxv) * VEC;
-    const int y = (int)((e / nxv) % d.ny);
-    const int z = (int)(e / ((size_t)nxv * d.ny));
+  const int xv = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z;
+  if (xv < nxv && y < d.ny) {
+    const int x0 = xv * VEC;
     const size_t i = ((size_t)z * d.ny + y) * d.nx + x0;
     float dx[VEC], dy[VEC], dz[VEC], res[VEC];
     if (VEC == 4) {
@@ -56,7 +68,8 @@ __global__ void __launch_bounds__(NT) k_warp_same_grid(const float* __restrict__
       pp_split(y, dy[v] * sc.iy, by, fy);
       pp_split(z, dz[v] * sc.iz, bz, fz);
       const bool inside = pp_inside1(bx, fx, d.nx) && pp_inside1(by, fy, d.ny) && pp_inside1(bz, fz, d.nz);
-      res[v] = inside ? pp_trilinear(moving, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz) : edge;
+      res[v] = inside ? (d.nx >= 2 ? pp_trilinear_pairs(moving, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz)
+                                   : pp_trilinear(moving, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz)) : edge;
     }
     if (VEC == 4)
       *reinterpret_cast<float4*>(out + i) = make_float4(res[0], res[1], res[2], res[3]);
@@ -70,10 +83,9 @@ __global__ void __launch_bounds__(NT) k_warp_same_grid(const float* __restrict__
 __global__ void __launch_bounds__(NT) k_compose_same_grid(float* __restrict__ total, const float* __restrict__ iter,
                                                           pp_dims d, pp_warp_scale sc) {
   const size_t N = (size_t)d.nx * d.ny * d.nz;
-  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < N; i += (size_t)gridDim.x * NT) {
-    const int x = (int)(i % d.nx);
-    const int y = (int)((i / d.nx) % d.ny);
-    const int z = (int)(i / ((size_t)d.nx * d.ny));
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z;
+  if (x < d.nx && y < d.ny) {
+    const size_t i = ((size_t)z * d.ny + y) * d.nx + x;
     const float tx = total[i], ty = total[N + i], tz = total[2 * N + i];
     int bx, by, bz;
     float fx, fy, fz;
@@ -81,9 +93,15 @@ __global__ void __launch_bounds__(NT) k_compose_same_grid(float* __restrict__ to
     pp_split(y, ty * sc.iy, by, fy);
     pp_split(z, tz * sc.iz, bz, fz);
     if (pp_inside1(bx, fx, d.nx) && pp_inside1(by, fy, d.ny) && pp_inside1(bz, fz, d.nz)) {
-      total[i] = tx + pp_trilinear(iter, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz);
-      total[N + i] = ty + pp_trilinear(iter + N, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz);
-      total[2 * N + i] = tz + pp_trilinear(iter + 2 * N, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz);
+      if (d.nx >= 2) {
+        total[i] = tx + pp_trilinear_pairs(iter, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz);
+        total[N + i] = ty + pp_trilinear_pairs(iter + N, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz);
+        total[2 * N + i] = tz + pp_trilinear_pairs(iter + 2 * N, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz);
+      } else {
+        total[i] = tx + pp_trilinear(iter, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz);
+        total[N + i] = ty + pp_trilinear(iter + N, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz);
+        total[2 * N + i] = tz + pp_trilinear(iter + 2 * N, d.nx, d.ny, d.nz, bx, fx, by, fy, bz, fz);
+      }
     }
   }
 }
@@ -254,10 +272,9 @@ template <typename T, int INTERP, bool HASFIELD>
 __global__ void __launch_bounds__(NT) k_resample(const T* __restrict__ in, pp_dims din, const float* __restrict__ field,
                                                  T* __restrict__ out, pp_dims dout, pp_xform X, T default_value) {
   const size_t N = (size_t)dout.nx * dout.ny * dout.nz;
-  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < N; i += (size_t)gridDim.x * NT) {
-    const int x = (int)(i % dout.nx);
-    const int y = (int)((i / dout.nx) % dout.ny);
-    const int z = (int)(i / ((size_t)dout.nx * dout.ny));
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z;
+  if (x < dout.nx && y < dout.ny) {
+    const size_t i = ((size_t)z * dout.ny + y) * dout.nx + x;
     double ddx = 0.0, ddy = 0.0, ddz = 0.0;
     if (HASFIELD) {
       ddx = (double)field[i];
@@ -275,8 +292,10 @@ __global__ void __launch_bounds__(NT) k_resample(const T* __restrict__ in, pp_di
         if (sizeof(T) == 4) res = pp_cast_out<T>(pp_bspline3_sample(reinterpret_cast<const float*>(in), din, c));
       } else {
         const double flx = floor(c[0]), fly = floor(c[1]), flz = floor(c[2]);
-        res = pp_cast_out<T>(pp_trilinear(in, din.nx, din.ny, din.nz, (int)flx, (float)(c[0] - flx), (int)fly,
-                                          (float)(c[1] - fly), (int)flz, (float)(c[2] - flz)));
+        res = pp_cast_out<T>(din.nx >= 2 ? pp_trilinear_pairs(in, din.nx, din.ny, din.nz, (int)flx, (float)(c[0] - flx), (int)fly,
+                                                               (float)(c[1] - fly), (int)flz, (float)(c[2] - flz))
+                                         : pp_trilinear(in, din.nx, din.ny, din.nz, (int)flx, (float)(c[0] - flx), (int)fly,
+                                                        (float)(c[1] - fly), (int)flz, (float)(c[2] - flz)));
       }
     }
     out[i] = res;
@@ -288,10 +307,9 @@ __global__ void __launch_bounds__(NT) k_resample_field(const float* __restrict__
                                                        pp_dims dout, pp_xform X) {
   const size_t N = (size_t)dout.nx * dout.ny * dout.nz;
   const size_t Ni = (size_t)din.nx * din.ny * din.nz;
-  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < N; i += (size_t)gridDim.x * NT) {
-    const int x = (int)(i % dout.nx);
-    const int y = (int)((i / dout.nx) % dout.ny);
-    const int z = (int)(i / ((size_t)dout.nx * dout.ny));
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z;
+  if (x < dout.nx && y < dout.ny) {
+    const size_t i = ((size_t)z * dout.ny + y) * dout.nx + x;
     double c[3];
     pp_map_point(X, x, y, z, 0.0, 0.0, 0.0, c);
     float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
@@ -299,9 +317,15 @@ __global__ void __launch_bounds__(NT) k_resample_field(const float* __restrict__
       const double flx = floor(c[0]), fly = floor(c[1]), flz = floor(c[2]);
       const int bx = (int)flx, by = (int)fly, bz = (int)flz;
       const float fx = (float)(c[0] - flx), fy = (float)(c[1] - fly), fz = (float)(c[2] - flz);
-      r0 = pp_trilinear(in, din.nx, din.ny, din.nz, bx, fx, by, fy, bz, fz);
-      r1 = pp_trilinear(in + Ni, din.nx, din.ny, din.nz, bx, fx, by, fy, bz, fz);
-      r2 = pp_trilinear(in + 2 * Ni, din.nx, din.ny, din.nz, bx, fx, by, fy, bz, fz);
+      if (din.nx >= 2) {
+        r0 = pp_trilinear_pairs(in, din.nx, din.ny, din.nz, bx, fx, by, fy, bz, fz);
+        r1 = pp_trilinear_pairs(in + Ni, din.nx, din.ny, din.nz, bx, fx, by, fy, bz, fz);
+        r2 = pp_trilinear_pairs(in + 2 * Ni, din.nx, din.ny, din.nz, bx, fx, by, fy, bz, fz);
+      } else {
+        r0 = pp_trilinear(in, din.nx, din.ny, din.nz, bx, fx, by, fy, bz, fz);
+        r1 = pp_trilinear(in + Ni, din.nx, din.ny, din.nz, bx, fx, by, fy, bz, fz);
+        r2 = pp_trilinear(in + 2 * Ni, din.nx, din.ny, din.nz, bx, fx, by, fy, bz, fz);
+      }
     }
     out[i] = r0;
     out[N + i] = r1;
@@ -349,7 +373,8 @@ int resample_any(pp_ctx* ctx, const T* in, const pp_geom* gin, const pp_geom* go
   fill_xform(gin, gout, A, t, &X);
   const pp_dims din{gin->size[0], gin->size[1], gin->size[2]};
   const pp_dims dout{gout->size[0], gout->size[1], gout->size[2]};
-  const dim3 grid(grid_for(pp_nvox(gout->size))), block(NT);
+  const pp_grid3 g3 = grid3_for(dout.nx, dout.ny, dout.nz);
+  const dim3 grid = g3.grid, block = g3.block;
   T dv;
   if (sizeof(T) == 1) {
     const double c = default_value < 0.0 ? 0.0 : (default_value > 255.0 ? 255.0 : default_value);
@@ -395,13 +420,13 @@ int pp_warp_same_grid(pp_ctx* ctx, const float* moving, const float* field, cons
                       float edge_value, float* out, const int* halt_flag) {
   const size_t N = (size_t)d.nx * d.ny * d.nz;
   const bool vec4 = (d.nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(field) | reinterpret_cast<uintptr_t>(out)) % 16 == 0) && (N % 4 == 0);
-  const dim3 block(NT);
-  if (vec4)
-    hipLaunchKernelGGL((k_warp_same_grid<4>), dim3(grid_for(N / 4)), block, 0, ctx->stream, moving, field, out, d, sc,
-                       edge_value, halt_flag);
-  else
-    hipLaunchKernelGGL((k_warp_same_grid<1>), dim3(grid_for(N)), block, 0, ctx->stream, moving, field, out, d, sc,
-                       edge_value, halt_flag);
+  if (vec4) {
+    const pp_grid3 g3 = grid3_for(d.nx / 4, d.ny, d.nz);
+    hipLaunchKernelGGL((k_warp_same_grid<4>), g3.grid, g3.block, 0, ctx->stream, moving, field, out, d, sc, edge_value, halt_flag);
+  } else {
+    const pp_grid3 g3 = grid3_for(d.nx, d.ny, d.nz);
+    hipLaunchKernelGGL((k_warp_same_grid<1>), g3.grid, g3.block, 0, ctx->stream, moving, field, out, d, sc, edge_value, halt_flag);
+  }
   PP_LAUNCH_CHECK(ctx, "k_warp_same_grid");
   return PP_OK;
 }
@@ -462,7 +487,8 @@ int pp_resample_field_f32(pp_ctx* ctx, const float* in, const pp_geom* gin, cons
   fill_xform(gin, gout, nullptr, nullptr, &X);
   const pp_dims din{gin->size[0], gin->size[1], gin->size[2]};
   const pp_dims dout{gout->size[0], gout->size[1], gout->size[2]};
-  hipLaunchKernelGGL(k_resample_field, dim3(grid_for(pp_nvox(gout->size))), dim3(NT), 0, ctx->stream, in, din, out, dout, X);
+  const pp_grid3 g3 = grid3_for(dout.nx, dout.ny, dout.nz);
+  hipLaunchKernelGGL(k_resample_field, g3.grid, g3.block, 0, ctx->stream, in, din, out, dout, X);
   PP_LAUNCH_CHECK(ctx, "k_resample_field");
   return PP_OK;
 }
@@ -497,7 +523,8 @@ int pp_compose_field_f32(pp_ctx* ctx, float* total, const float* iter, const pp_
   if (!pp_geom_identity_dir(g)) return pp_fail(ctx, PP_ERR_UNSUPPORTED, "pp_compose_field_f32: identity direction only");
   const pp_dims d{g->size[0], g->size[1], g->size[2]};
   const pp_warp_scale sc{(float)(1.0 / g->spacing[0]), (float)(1.0 / g->spacing[1]), (float)(1.0 / g->spacing[2])};
-  hipLaunchKernelGGL(k_compose_same_grid, dim3(grid_for(pp_nvox(g->size))), dim3(NT), 0, ctx->stream, total, iter, d, sc);
+  const pp_grid3 g3 = grid3_for(d.nx, d.ny, d.nz);
+  hipLaunchKernelGGL(k_compose_same_grid, g3.grid, g3.block, 0, ctx->stream, total, iter, d, sc);
   PP_LAUNCH_CHECK(ctx, "k_compose_same_grid");
   return PP_OK;
 }

@@ -163,6 +163,18 @@ static inline void __builtin_amdgcn_raw_buffer_store_b64(hipemu_u2 v, __amdgpu_b
 // Wavefront shuffle (64 lanes).  Every thread of the block must reach the call (uniform control flow): the value is
 // exchanged through a per-block table between two block-wide yields.
 namespace hipemu { extern thread_local double t_shfl[1024]; }
+static inline float hipemu_shfl_from(float v, int delta) {   // value of lane (lane + delta), own value when that lane does not exist
+  const unsigned t = threadIdx.x;
+  ::hipemu::t_shfl[t] = (double)v;
+  ::hipemu::fiber_yield();
+  const int src = (int)(t & 63u) + delta;
+  const unsigned idx = (t & ~63u) + (unsigned)src;
+  const float r = (src >= 0 && src < 64 && idx < blockDim.x) ? (float)::hipemu::t_shfl[idx] : v;
+  ::hipemu::fiber_yield();
+  return r;
+}
+static inline float __shfl_up(float v, unsigned delta, int /*width*/ = 64) { return hipemu_shfl_from(v, -(int)delta); }
+static inline float __shfl_down(float v, unsigned delta, int /*width*/ = 64) { return hipemu_shfl_from(v, (int)delta); }
 static inline double __shfl_xor(double v, int lane_mask, int /*width*/ = 64) {
   const unsigned t = threadIdx.x;
   ::hipemu::t_shfl[t] = v;

@@ -66,6 +66,37 @@ def test_discrete_gaussian(backend, grid):
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-3)
 
 
+@pytest.mark.parametrize("shape", [(9, 14, 24), (7, 11, 18), (20, 37, 260)])
+@pytest.mark.parametrize("variance", [0.5, 2.25, 9.0, 30.0, 64.0])
+def test_fir_register_window_and_shuffle_passes_equal_the_legacy_pass(backend, shape, variance, monkeypatch):
+    """The marching (register-window) y / z passes and the wavefront-shuffle x pass add the same taps in the same order as
+    the one-output-per-thread pass they replace (zero taps pad the radius to its bucket): bit-identical volumes, for
+    radii 1..16, rows that are / are not a multiple of four voxels, and rows longer than one wavefront's span."""
+    img = phantom(shape, seed=12)
+    size = (shape[2], shape[1], shape[0])
+    out = {}
+    for legacy in ("1", None):
+        if legacy:
+            monkeypatch.setenv("PP_FIR_LEGACY", legacy)
+        else:
+            monkeypatch.delenv("PP_FIR_LEGACY", raising=False)
+        dst = backend.empty(shape)
+        backend.ctx.discrete_gaussian(backend.dev(img), dst, size, (1.0, 1.0, 1.0), (variance,) * 3, 0.01, 64, True)
+        out[legacy] = backend.host(dst).copy()
+    np.testing.assert_array_equal(out["1"], out[None])
+    f = np.stack([phantom(shape, seed=20 + c) for c in range(3)]) * np.float32(0.01)
+    res = {}
+    for legacy in ("1", None):
+        if legacy:
+            monkeypatch.setenv("PP_FIR_LEGACY", legacy)
+        else:
+            monkeypatch.delenv("PP_FIR_LEGACY", raising=False)
+        d = backend.dev(f)
+        backend.ctx.smooth_field(d, size, [np.sqrt(variance)] * 3)
+        res[legacy] = backend.host(d).copy()
+    np.testing.assert_array_equal(res["1"], res[None])
+
+
 @pytest.mark.parametrize("grid", GRIDS)
 def test_smooth_field(backend, grid):
     shape, spacing, _ = grid
