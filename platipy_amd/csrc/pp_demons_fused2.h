@@ -358,8 +358,15 @@ struct pp_warp_dims {
   int nx, ny, nz;
   unsigned nx4, sz4;   // bytes per row / per plane
 };
-__device__ __forceinline__ float fused2_warp_sample(const char* rm, const pp_warp_dims& wd, int xi, float dvx, int yi, float dvy, int zi,
-                                                    float dvz, bool lane_ok) {
+// One trilinear sample of the warp in two halves, so that the gathers of output plane n can stay in flight across the
+// x pass of the next plane: `issue` forms the addresses and starts the four 8-byte loads, `finish` lerps.
+struct pp_warp_pending {
+  float2 p00, p10, p01, p11;
+  float wx, wy, wz;
+  unsigned flags;   // bit 0: inside the buffer, bit 1: x0 is the last index
+};
+__device__ __forceinline__ void fused2_warp_issue(const char* rm, const pp_warp_dims& wd, int xi, float dvx, int yi, float dvy, int zi,
+                                                  float dvz, bool lane_ok, pp_warp_pending& g) {
   // pp_split and pp_inside1 without short-circuit control flow: `h` = floor(2 * continuous index), and the buffer test
   // [-0.5, n - 0.5) is -1 <= h <= 2n - 2.
   const bool sx = fabsf(dvx) < 1.0e6f, sy_ = fabsf(dvy) < 1.0e6f, sz_ = fabsf(dvz) < 1.0e6f;
@@ -371,7 +378,9 @@ __device__ __forceinline__ float fused2_warp_sample(const char* rm, const pp_war
                       ((unsigned)(hz + 1) <= (unsigned)(2 * wd.nz - 1));
   // pp_axis_setup, with the base index also clamped from above so that outside lanes still form valid addresses
   const int x0 = pp_clampi(bx, 0, wd.nx - 1), y0 = pp_clampi(by, 0, wd.ny - 1), z0 = pp_clampi(bz, 0, wd.nz - 1);
-  const float wx = bx < 0 ? 0.0f : fx, wy = by < 0 ? 0.0f : fy, wz = bz < 0 ? 0.0f : fz;
+  g.wx = bx < 0 ? 0.0f : fx;
+  g.wy = by < 0 ? 0.0f : fy;
+  g.wz = bz < 0 ? 0.0f : fz;
   // byte offsets of the 8 corners; the upper corner of an axis repeats the lower one on the last index (ITK's clamp).
   // 24-bit multiplies (full rate): z0 * ny + y0 < 2^24 and nx * 4 < 2^24 are checked on the host.
   const unsigned r00 = __umul24(__umul24((unsigned)z0, (unsigned)wd.ny) + (unsigned)y0, wd.nx4);
@@ -381,19 +390,32 @@ __device__ __forceinline__ float fused2_warp_sample(const char* rm, const pp_war
   // ITK's upper corner repeats the lower one) both corners are its second element and nothing is read past the row.
   const bool xlast = x0 > wd.nx - 2;
   const unsigned c0 = (unsigned)(xlast ? wd.nx - 2 : x0) * 4u;
-  const float2 p00 = pp_gld2(rm, r00 + c0), p10 = pp_gld2(rm, r10 + c0), p01 = pp_gld2(rm, r01 + c0), p11 = pp_gld2(rm, r11 + c0);
-  const float a000 = xlast ? p00.y : p00.x, a100 = p00.y;
-  const float a010 = xlast ? p10.y : p10.x, a110 = p10.y;
-  const float a001 = xlast ? p01.y : p01.x, a101 = p01.y;
-  const float a011 = xlast ? p11.y : p11.x, a111 = p11.y;
-  const float v00 = a000 + (a100 - a000) * wx;
-  const float v10 = a010 + (a110 - a010) * wx;
-  const float v01 = a001 + (a101 - a001) * wx;
-  const float v11 = a011 + (a111 - a011) * wx;
-  const float v0 = v00 + (v10 - v00) * wy;
-  const float v1 = v01 + (v11 - v01) * wy;
-  const float r = v0 + (v1 - v0) * wz;
-  return inside ? r : FLT_MAX;
+  g.p00 = pp_gld2(rm, r00 + c0);
+  g.p10 = pp_gld2(rm, r10 + c0);
+  g.p01 = pp_gld2(rm, r01 + c0);
+  g.p11 = pp_gld2(rm, r11 + c0);
+  g.flags = (inside ? 1u : 0u) | (xlast ? 2u : 0u);
+}
+__device__ __forceinline__ float fused2_warp_finish(const pp_warp_pending& g) {
+  const bool xlast = (g.flags & 2u) != 0;
+  const float a000 = xlast ? g.p00.y : g.p00.x, a100 = g.p00.y;
+  const float a010 = xlast ? g.p10.y : g.p10.x, a110 = g.p10.y;
+  const float a001 = xlast ? g.p01.y : g.p01.x, a101 = g.p01.y;
+  const float a011 = xlast ? g.p11.y : g.p11.x, a111 = g.p11.y;
+  const float v00 = a000 + (a100 - a000) * g.wx;
+  const float v10 = a010 + (a110 - a010) * g.wx;
+  const float v01 = a001 + (a101 - a001) * g.wx;
+  const float v11 = a011 + (a111 - a011) * g.wx;
+  const float v0 = v00 + (v10 - v00) * g.wy;
+  const float v1 = v01 + (v11 - v01) * g.wy;
+  const float r = v0 + (v1 - v0) * g.wz;
+  return (g.flags & 1u) ? r : FLT_MAX;
+}
+__device__ __forceinline__ float fused2_warp_sample(const char* rm, const pp_warp_dims& wd, int xi, float dvx, int yi, float dvy, int zi,
+                                                    float dvz, bool lane_ok) {
+  pp_warp_pending g;
+  fused2_warp_issue(rm, wd, xi, dvx, yi, dvy, zi, dvz, lane_ok, g);
+  return fused2_warp_finish(g);
 }
 
 // ---- kernel B, generation 2: D' = G_d * (D + U), then the next iteration's warped moving image --------
