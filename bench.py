@@ -338,7 +338,8 @@ def main():
         c = torch.empty_like(a)
         torch.cuda.synchronize()
         torch.add(a, 1.0, out=c)            # 16 B/lane: reads 12 * nvox bytes, writes 12 * nvox
-        ctx.fuse_divide(a, b, c, 3 * nvox)  # 4 B/lane: reads 24 * nvox bytes, writes 12 * nvox
+        ctx.fuse_divide(a, b, c, 3 * nvox)  # 16 B/lane (k_map4): reads 24 * nvox bytes, writes 12 * nvox
+        ctx.sum_sq_diff(a, b, 3 * nvox)     # 4 B/lane loads: reads 24 * nvox bytes
         torch.cuda.synchronize()
         del a, b, c
 

@@ -2,10 +2,11 @@
 """Reduce a pmc_summary.py table to calibrated HBM-side bytes per launch (-> profiles/roundN_pmc.json, read by bench.py).
 
 usage: pmc_reduce.py <pmc_counters.md> <commit> nx ny nz
-Calibration (MI355X_MICROARCH.md, HBM section): two kernels of the same run with known byte counts -- torch's
-elementwise add (16 B/lane: reads 12 N, writes 12 N bytes) and k_fuse_divide (4 B/lane: reads 24 N, writes 12 N) --
-give the factor that turns FETCH_SIZE / WRITE_SIZE (KiB) into bytes for each access width; the fused kernels use the
-16-B factor for reads when both agree within 5 % (they did: 2.0), otherwise the larger one (an upper bound)."""
+Calibration (MI355X_MICROARCH.md, HBM section): kernels of the same run with known byte counts -- torch's elementwise
+add and the library's fuse_divide (16 B/lane: read 12 N resp. 24 N bytes, write 12 N) and the sum-of-squared-differences
+reduction (4 B/lane loads: reads 24 N bytes, writes nothing) -- give the factor that turns FETCH_SIZE / WRITE_SIZE (KiB)
+into bytes for each access width; the fused kernels (16-B strips, 4-B and 8-B gathers) use the larger read factor, an
+upper bound when the two differ (they agree: 2.0)."""
 import json
 import re
 import sys
@@ -21,11 +22,13 @@ cal = {}
 if "torch.add(scalar)" in tab and "FETCH_SIZE" in tab["torch.add(scalar)"]:
     cal["fetch_16B"] = 12.0 * n / (tab["torch.add(scalar)"]["FETCH_SIZE"] * 1024)
     cal["write_16B"] = 12.0 * n / (tab["torch.add(scalar)"]["WRITE_SIZE"] * 1024)
-if "k_fuse_divide" in tab and "FETCH_SIZE" in tab["k_fuse_divide"]:
-    cal["fetch_4B"] = 24.0 * n / (tab["k_fuse_divide"]["FETCH_SIZE"] * 1024)
-    cal["write_4B"] = 12.0 * n / (tab["k_fuse_divide"]["WRITE_SIZE"] * 1024)
-ff = max(cal.get("fetch_16B", 2.0), cal.get("fetch_4B", 2.0))
-fw = max(cal.get("write_16B", 1.0), cal.get("write_4B", 1.0))
+if "k_map4<op_fuse_divide>" in tab and "FETCH_SIZE" in tab["k_map4<op_fuse_divide>"]:
+    cal["fetch_16B_lib"] = 24.0 * n / (tab["k_map4<op_fuse_divide>"]["FETCH_SIZE"] * 1024)
+    cal["write_16B_lib"] = 12.0 * n / (tab["k_map4<op_fuse_divide>"]["WRITE_SIZE"] * 1024)
+if "k_ssd_partial" in tab and "FETCH_SIZE" in tab["k_ssd_partial"]:
+    cal["fetch_4B"] = 24.0 * n / (tab["k_ssd_partial"]["FETCH_SIZE"] * 1024)
+ff = max(cal.get("fetch_16B", 2.0), cal.get("fetch_4B", 2.0), cal.get("fetch_16B_lib", 2.0))
+fw = max(cal.get("write_16B", 1.0), cal.get("write_16B_lib", 1.0))
 out = {"commit": commit, "size": [nx, ny, nz], "raw": md.replace("gpurun_out/r2/", "profiles/round2_"), "calibration": cal,
        "fetch_factor": ff, "write_factor": fw, "hbm_bytes_per_launch": {}, "fetch_bytes_per_launch": {}, "write_bytes_per_launch": {},
        "tcc_hit_rate": {}}

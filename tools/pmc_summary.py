@@ -9,7 +9,9 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("k_fused2_add_smooth_warp", "k_fused2_force_smooth", "k_cal_copy16", "k_cal_copy4", "k_fused_add_smooth_warp", "k_fused_force_smooth", "k_fuse_divide", "k_warp_same_grid", "k_demons_force",
+    if "op_fuse_divide" in name:
+        return "k_map4<op_fuse_divide>"
+    for key in ("k_ssd_partial", "k_fused2_add_smooth_warp", "k_fused2_force_smooth", "k_cal_copy16", "k_cal_copy4", "k_fused_add_smooth_warp", "k_fused_force_smooth", "k_fuse_divide", "k_warp_same_grid", "k_demons_force",
                 "k_conv_axis", "k_demons_finalize", "k_copy_if_odd"):
         if key in name:
             return key
