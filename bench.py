@@ -35,8 +35,12 @@ from platipy_amd import _lib  # noqa: E402
 #   contract   : SURVEY 8(d)'s figure, which counts every separable pass of the STAGED schedule as its own sweep
 #                (warp 20, force 20, smooth-update 72, add + first field pass 36, remaining field passes 48 = 196).
 #                It describes the staged kernels exactly; for the fused kernels it is reported for continuity only.
+# Generation-2 fused kernels: A reads F, M o D and D (4 + 4 + 12) and writes S = D + G_u * update (12); B reads S (12) and
+# the moving image once (4) and writes D' (12) and M o D' (4).  With PP_FUSED_SUM=0 (and generation 1) A writes the
+# smoothed update alone (20) and B reads D and U (44).  Either way an iteration moves 64 compulsory bytes per voxel.
+_SEPARATE = os.environ.get("PP_FUSED_SUM") == "0"
 COMPULSORY_BYTES = {
-    "k_fused2_force_smooth": 20, "k_fused2_add_smooth_warp": 44,
+    "k_fused2_force_smooth": 20 if _SEPARATE else 32, "k_fused2_add_smooth_warp": 44 if _SEPARATE else 32,
     "k_fused_force_smooth": 20, "k_fused_add_smooth_warp": 44,
     "k_warp_same_grid": 20, "k_demons_force": 20, "k_conv_axis x3 (update)": 72, "k_conv_axis x3 (add+field)": 84,
 }

@@ -695,8 +695,10 @@ void small_taps(const pp_taps& t, int R, pp_taps_small* s) {
 
 // z-chunk length: long chunks amortise the 2R (+3 image) halo planes, but the launch should fill the
 // chip a whole number of times.  `slots` = resident blocks of the slower kernel (256 CUs x blocks/CU).
-int fused_zchunk(const pp_dims& d, int slots, int TX, int TY, double* cost_out = nullptr) {
-  if (const char* e = getenv("PP_FUSED_ZCHUNK")) {
+int fused_zchunk(const pp_dims& d, int slots, int TX, int TY, double* cost_out = nullptr, char kernel = 0) {
+  const char* e = kernel == 'A' ? getenv("PP_FUSED_ZCHUNK_A") : (kernel == 'B' ? getenv("PP_FUSED_ZCHUNK_B") : nullptr);
+  if (!e) e = getenv("PP_FUSED_ZCHUNK");
+  if (e) {
     const int v = atoi(e);
     if (v >= 1) {
       if (cost_out) *cost_out = 0.0;
@@ -708,7 +710,7 @@ int fused_zchunk(const pp_dims& d, int slots, int TX, int TY, double* cost_out =
   // block's march instead, ~2.5 us per plane: short chunks (down to 2 planes + halo) cut that chain.
   int best = d.nz < 32 ? d.nz : 32;
   double best_cost = 1e30;
-  for (int zc = 2; zc <= 64 && zc <= d.nz; ++zc) {
+  for (int zc = 2; zc <= 128 && zc <= d.nz; ++zc) {   // (one round of 128-plane chunks beats two rounds of 64: 512 x 512 x 256, kernel A -10 %)
     const int chunks = (d.nz + zc - 1) / zc;
     if ((chunks - 1) * zc >= d.nz) continue;
     const long blocks = (long)tiles * chunks;
@@ -808,14 +810,18 @@ int launch_warp(pp_ctx* ctx, int sh, const float* D, const float* Us, const floa
   return PP_OK;
 }
 
-// ---- generation 2 (pp_demons_fused2.h): 512-thread layout only, radii 1..5, both tile shapes ----
-#define PP_BY_RADIUS2(R, CALL) ((R) == 1 ? CALL(1) : ((R) == 2 ? CALL(2) : ((R) == 3 ? CALL(3) : ((R) == 4 ? CALL(4) : CALL(5)))))
+// ---- generation 2 (pp_demons_fused2.h): 512-thread layout only, both tile shapes; kernel A for radii 1..3, kernel B 1..4
+// (beyond that the unrolled plane loop does not fit 128 registers and the first generation is faster).  SUM: see the header.
+#define PP_BY_RADIUS_A2(R, CALL) ((R) == 1 ? CALL(1) : ((R) == 2 ? CALL(2) : CALL(3)))
+#define PP_BY_RADIUS_B2(R, CALL) ((R) == 1 ? CALL(1) : ((R) == 2 ? CALL(2) : ((R) == 3 ? CALL(3) : CALL(4))))
+#define PP_A2_KERNEL(SHV, SUMV) k_fused2_force_smooth<R, SHV, (R <= PP_RING_UNROLL_MAX_R), SUMV>
+#define PP_B2_KERNEL(SHV, SUMV) k_fused2_add_smooth_warp<R, SHV, (R <= PP_RING_UNROLL_MAX_R), SUMV>
 
 template <int R>
-int occ_force2(int sh) {
+int occ_force2(int sh) {   // (the SUM variant holds six more registers; both stay in the same occupancy tier)
   int a = 0;
-  const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fused2_force_smooth<R, 1, (R <= PP_RING_UNROLL_MAX_R)>, 512, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fused2_force_smooth<R, 0, (R <= PP_RING_UNROLL_MAX_R)>, 512, 0);
+  const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(1, true), 512, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(0, true), 512, 0);
   if (e != hipSuccess) a = 2;
   (void)hipGetLastError();
   return a < 1 ? 1 : a;
@@ -823,41 +829,45 @@ int occ_force2(int sh) {
 template <int R>
 int occ_warp2(int sh) {
   int a = 0;
-  const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fused2_add_smooth_warp<R, 1, (R <= PP_RING_UNROLL_MAX_R)>, 512, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fused2_add_smooth_warp<R, 0, (R <= PP_RING_UNROLL_MAX_R)>, 512, 0);
+  const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(1, false), 512, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(0, false), 512, 0);
   if (e != hipSuccess) a = 2;
   (void)hipGetLastError();
   return a < 1 ? 1 : a;
 }
 template <int R>
-int launch_force2(pp_ctx* ctx, int sh, const float* F, const float* Mw_in, float* Us, const fused_args& fu, const pp_esm_consts& K,
-                  double* partials, const int* halt) {
+int launch_force2(pp_ctx* ctx, int sh, bool sum, const float* F, const float* Mw_in, const float* D, float* Us, const fused_args& fu,
+                  const pp_esm_consts& K, double* partials, const int* halt) {
   pp_prof_scope ps(ctx, "k_fused2_force_smooth");
-  if (sh)
-    hipLaunchKernelGGL((k_fused2_force_smooth<R, 1, (R <= PP_RING_UNROLL_MAX_R)>), dim3(8u * (unsigned)fu.per_xcd), dim3(512), 0, ctx->stream, F, Mw_in, Us, fu, K,
-                       partials, halt);
-  else
-    hipLaunchKernelGGL((k_fused2_force_smooth<R, 0, (R <= PP_RING_UNROLL_MAX_R)>), dim3(8u * (unsigned)fu.per_xcd), dim3(512), 0, ctx->stream, F, Mw_in, Us, fu, K,
-                       partials, halt);
+  const dim3 grid(8u * (unsigned)fu.per_xcd), block(512);
+  if (sum) {
+    if (sh) hipLaunchKernelGGL((PP_A2_KERNEL(1, true)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, halt);
+    else hipLaunchKernelGGL((PP_A2_KERNEL(0, true)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, halt);
+  } else {
+    if (sh) hipLaunchKernelGGL((PP_A2_KERNEL(1, false)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, halt);
+    else hipLaunchKernelGGL((PP_A2_KERNEL(0, false)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, halt);
+  }
   return PP_OK;
 }
 template <int R>
-int launch_warp2(pp_ctx* ctx, int sh, const float* D, const float* Us, const float* M, float* Dn, float* Mw_out, const fused_args& fd,
-                 const pp_warp_scale& sc, const int* halt) {
+int launch_warp2(pp_ctx* ctx, int sh, bool sum, const float* D, const float* Us, const float* M, float* Dn, float* Mw_out,
+                 const fused_args& fd, const pp_warp_scale& sc, const int* halt) {
   pp_prof_scope ps(ctx, "k_fused2_add_smooth_warp");
-  if (sh)
-    hipLaunchKernelGGL((k_fused2_add_smooth_warp<R, 1, (R <= PP_RING_UNROLL_MAX_R)>), dim3(8u * (unsigned)fd.per_xcd), dim3(512), 0, ctx->stream, D, Us, M, Dn, Mw_out,
-                       fd, sc, halt);
-  else
-    hipLaunchKernelGGL((k_fused2_add_smooth_warp<R, 0, (R <= PP_RING_UNROLL_MAX_R)>), dim3(8u * (unsigned)fd.per_xcd), dim3(512), 0, ctx->stream, D, Us, M, Dn, Mw_out,
-                       fd, sc, halt);
+  const dim3 grid(8u * (unsigned)fd.per_xcd), block(512);
+  if (sum) {
+    if (sh) hipLaunchKernelGGL((PP_B2_KERNEL(1, true)), grid, block, 0, ctx->stream, D, Us, M, Dn, Mw_out, fd, sc, halt);
+    else hipLaunchKernelGGL((PP_B2_KERNEL(0, true)), grid, block, 0, ctx->stream, D, Us, M, Dn, Mw_out, fd, sc, halt);
+  } else {
+    if (sh) hipLaunchKernelGGL((PP_B2_KERNEL(1, false)), grid, block, 0, ctx->stream, D, Us, M, Dn, Mw_out, fd, sc, halt);
+    else hipLaunchKernelGGL((PP_B2_KERNEL(0, false)), grid, block, 0, ctx->stream, D, Us, M, Dn, Mw_out, fd, sc, halt);
+  }
   return PP_OK;
 }
 
-void fused_grid(fused_args* f, const pp_dims& d, int occupancy, int sh) {
+void fused_grid(fused_args* f, const pp_dims& d, int occupancy, int sh, char kernel) {
   const int TX = sh ? tile_shape<1>::TX : tile_shape<0>::TX, TY = sh ? tile_shape<1>::TY : tile_shape<0>::TY;
   f->d = d;
-  f->zchunk = fused_zchunk(d, 256 * occupancy, TX, TY);
+  f->zchunk = fused_zchunk(d, 256 * occupancy, TX, TY, nullptr, kernel);
   f->gx = (d.nx + TX - 1) / TX;
   f->gy = (d.ny + TY - 1) / TY;
   f->gz = (d.nz + f->zchunk - 1) / f->zchunk;
@@ -1021,6 +1031,12 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   // (the second generation needs > 128 registers for kernel A from radius 4 -- sigma_u = 1 voxel gives radius 2 -- and for
   // kernel B at radius 5, i.e. voxels under 0.55 mm: measured slower than the first generation there)
   const int gen_a = (gen == 2 && ra <= 3) ? 2 : 1, gen_b = (gen == 2 && rb <= 4) ? 2 : 1;
+  // both kernels of generation 2: kernel A stores D + G_u * update and kernel B reads that one volume (three halo'd arrays
+  // instead of six; the add itself is unchanged, so the fields are bit-identical).  PP_FUSED_SUM=0 keeps them apart.
+  bool sum_mode = gen_a == 2 && gen_b == 2;
+  if (const char* e = getenv("PP_FUSED_SUM")) {
+    if (atoi(e) == 0) sum_mode = false;
+  }
   const int opt_a = ra > 3 ? 2 : opt, opt_b = rb > 3 ? 2 : opt;   // radii 4 and 5 exist in the 512-thread layout only
   fused_args fu, fd;
   int sh_a = 0, sh_b = 0;
@@ -1028,11 +1044,11 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   if (gen_a == 2) {
 #define PP_OCC_A20(RR) occ_force2<RR>(0)
 #define PP_OCC_A21(RR) occ_force2<RR>(1)
-    const int occ_a0 = PP_BY_RADIUS2(ra, PP_OCC_A20), occ_a1 = PP_BY_RADIUS2(ra, PP_OCC_A21);
+    const int occ_a0 = PP_BY_RADIUS_A2(ra, PP_OCC_A20), occ_a1 = PP_BY_RADIUS_A2(ra, PP_OCC_A21);
 #undef PP_OCC_A20
 #undef PP_OCC_A21
     sh_a = fused_shape(d, 256 * occ_a0, 256 * occ_a1);
-    fused_grid(&fu, d, sh_a ? occ_a1 : occ_a0, sh_a);
+    fused_grid(&fu, d, sh_a ? occ_a1 : occ_a0, sh_a, 'A');
   } else {
 #define PP_OCC_A0(RR, OO) occ_force_sh<RR, OO>(0)
 #define PP_OCC_A1(RR, OO) occ_force_sh<RR, OO>(1)
@@ -1041,16 +1057,16 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
 #undef PP_OCC_A0
 #undef PP_OCC_A1
     sh_a = opt_a == 2 ? fused_shape(d, 256 * occ_a0, 256 * occ_a1) : 0;
-    fused_grid(&fu, d, sh_a ? occ_a1 : occ_a0, sh_a);
+    fused_grid(&fu, d, sh_a ? occ_a1 : occ_a0, sh_a, 'A');
   }
   if (gen_b == 2) {
 #define PP_OCC_B20(RR) occ_warp2<RR>(0)
 #define PP_OCC_B21(RR) occ_warp2<RR>(1)
-    const int occ_b0 = PP_BY_RADIUS2(rb, PP_OCC_B20), occ_b1 = PP_BY_RADIUS2(rb, PP_OCC_B21);
+    const int occ_b0 = PP_BY_RADIUS_B2(rb, PP_OCC_B20), occ_b1 = PP_BY_RADIUS_B2(rb, PP_OCC_B21);
 #undef PP_OCC_B20
 #undef PP_OCC_B21
     sh_b = fused_shape(d, 256 * occ_b0, 256 * occ_b1);
-    fused_grid(&fd, d, sh_b ? occ_b1 : occ_b0, sh_b);
+    fused_grid(&fd, d, sh_b ? occ_b1 : occ_b0, sh_b, 'B');
   } else {
 #define PP_OCC_B0(RR, OO) occ_warp_sh<RR, OO>(0)
 #define PP_OCC_B1(RR, OO) occ_warp_sh<RR, OO>(1)
@@ -1059,7 +1075,7 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
 #undef PP_OCC_B0
 #undef PP_OCC_B1
     sh_b = opt_b == 2 ? fused_shape(d, 256 * occ_b0, 256 * occ_b1) : 0;
-    fused_grid(&fd, d, sh_b ? occ_b1 : occ_b0, sh_b);
+    fused_grid(&fd, d, sh_b ? occ_b1 : occ_b0, sh_b, 'B');
   }
   small_taps(tu[0], ra, &fu.wx);
   small_taps(tu[1], ra, &fu.wy);
@@ -1089,8 +1105,8 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     float* Dnext = (it & 1) ? field : D2;
     // a failed first launch must not be masked by the second one's status
     if (gen_a == 2) {
-#define PP_CALL_A2(RR) launch_force2<RR>(ctx, sh_a, fixed, mw_in, Us, fu, K, partials, halt)
-      rc = PP_BY_RADIUS2(ra, PP_CALL_A2);
+#define PP_CALL_A2(RR) launch_force2<RR>(ctx, sh_a, sum_mode, fixed, mw_in, Dcur, Us, fu, K, partials, halt)
+      rc = PP_BY_RADIUS_A2(ra, PP_CALL_A2);
 #undef PP_CALL_A2
     } else {
 #define PP_CALL_A(RR, OO) launch_force<RR, OO>(ctx, sh_a, fixed, mw_in, Us, fu, K, partials, halt)
@@ -1100,8 +1116,8 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     PP_LAUNCH_CHECK(ctx, "k_fused_force_smooth");
     if (rc) return rc;
     if (gen_b == 2) {
-#define PP_CALL_B2(RR) launch_warp2<RR>(ctx, sh_b, Dcur, (const float*)Us, moving, Dnext, mw_out, fd, sc, halt)
-      rc = PP_BY_RADIUS2(rb, PP_CALL_B2);
+#define PP_CALL_B2(RR) launch_warp2<RR>(ctx, sh_b, sum_mode, Dcur, (const float*)Us, moving, Dnext, mw_out, fd, sc, halt)
+      rc = PP_BY_RADIUS_B2(rb, PP_CALL_B2);
 #undef PP_CALL_B2
     } else {
 #define PP_CALL_B(RR, OO) launch_warp<RR, OO>(ctx, sh_b, Dcur, (const float*)Us, moving, Dnext, mw_out, fd, sc, halt)

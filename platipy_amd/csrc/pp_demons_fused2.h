@@ -419,7 +419,9 @@ __device__ __forceinline__ float fused2_warp_sample(const char* rm, const pp_war
 }
 
 // ---- kernel B, generation 2: D' = G_d * (D + U), then the next iteration's warped moving image --------
-template <int R, int SH, bool UNROLL>
+// SUM: `Us` already holds D + U (kernel A<SUM> added D at its own output voxels, where it needs no halo), `D` is not read:
+// three halo'd arrays instead of six.  The sum is the same fp32 add on the same operands, so the fields are bit-identical.
+template <int R, int SH, bool UNROLL, bool SUM>
 __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(const float* __restrict__ D, const float* __restrict__ Us,
                                                                             const float* __restrict__ M, float* __restrict__ Dn,
                                                                             float* __restrict__ Mw, fused_args a, pp_warp_scale sc,
@@ -459,20 +461,20 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
   const int zhi = pp_clampi(ze, 0, d.nz - 1);
   const int nsteps = ze - zs + 1;
 
-  float4 dl[3][G::NSL], ul[3][G::NSL];   // raw D and U strips of the plane about to be published
+  float4 dl[SUM ? 1 : 3][G::NSL], ul[3][G::NSL];   // raw D and U strips of the plane about to be published
   auto load_plane = [&](int zc) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const char* const pd = reinterpret_cast<const char*>(D + c * N + (size_t)zc * sz);
+      const char* const pd = SUM ? nullptr : reinterpret_cast<const char*>(D + c * N + (size_t)zc * sz);
       const char* const pu = reinterpret_cast<const char*>(Us + c * N + (size_t)zc * sz);
 #pragma unroll
       for (int i = 0; i < G::NSL; ++i)
         if ((i + 1) * NTH <= G::NS || st[i].slot >= 0) {
 #ifdef PP_ABL_NOLOAD
-          dl[c][i] = make_float4((float)st[i].goff * 1e-9f + (float)zc, 0.f, 1.f, 2.f);
+          if constexpr (!SUM) dl[c][i] = make_float4((float)st[i].goff * 1e-9f + (float)zc, 0.f, 1.f, 2.f);
           ul[c][i] = make_float4((float)st[i].goff * 1e-9f, 1.f, 0.f, 3.f);
 #else
-          dl[c][i] = pp_gld4(pd, st[i].goff);
+          if constexpr (!SUM) dl[c][i] = pp_gld4(pd, st[i].goff);
           ul[c][i] = pp_gld4(pu, st[i].goff);
 #endif
         }
@@ -483,9 +485,13 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
     for (int i = 0; i < G::NSL; ++i)
       if ((i + 1) * NTH <= G::NS || st[i].slot >= 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-          *reinterpret_cast<float4*>(s_u + c * G::UH * G::UW + st[i].slot) =
-              make_float4(dl[c][i].x + ul[c][i].x, dl[c][i].y + ul[c][i].y, dl[c][i].z + ul[c][i].z, dl[c][i].w + ul[c][i].w);
+        for (int c = 0; c < 3; ++c) {
+          if constexpr (SUM)
+            *reinterpret_cast<float4*>(s_u + c * G::UH * G::UW + st[i].slot) = ul[c][i];
+          else
+            *reinterpret_cast<float4*>(s_u + c * G::UH * G::UW + st[i].slot) =
+                make_float4(dl[c][i].x + ul[c][i].x, dl[c][i].y + ul[c][i].y, dl[c][i].z + ul[c][i].z, dl[c][i].w + ul[c][i].w);
+        }
         if (st[i].jm != 0xE4u) pp_strip_remap_lds<3>(s_u + st[i].slot, G::UH * G::UW, st[i].jm);   // x-border tiles only
       }
   };
@@ -573,9 +579,11 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
 }
 
 // ---- kernel A, generation 2: ESM update + 3-D Gaussian of the update -----------------------------------
-template <int R, int SH, bool UNROLL>
+// SUM: the stored volume is D + G_u * update (D read at the thread's own output voxels), what kernel B<SUM> smooths.
+template <int R, int SH, bool UNROLL, bool SUM>
 __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(const float* __restrict__ F, const float* __restrict__ Mw,
-                                                                         float* __restrict__ Us, fused_args a, pp_esm_consts K,
+                                                                         const float* __restrict__ D, float* __restrict__ Us,
+                                                                         fused_args a, pp_esm_consts K,
                                                                          double* __restrict__ partials, const int* __restrict__ halt) {
   using G = fused_geom<R, 2, SH>;
   constexpr int NTH = G::NTH, TX = G::TX, TY = G::TY, W = 2 * R + 1;
@@ -713,6 +721,20 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
       for (int k = 0; k < W; ++k) rg[c][j][k] = 0.0f;
   float v[3][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
 
+  float2 dsum[SUM ? 3 : 1];
+  const unsigned o_xy1 = (x + 1 < d.nx) ? o_xy + 4u : o_xy;
+  auto load_dsum = [&](int zo) {
+    if (zo >= z0 && zo <= zo_last && out_ok) {
+      const size_t po = (size_t)zo * sz;
+#pragma unroll
+      for (int c = 0; c < (SUM ? 3 : 1); ++c) {   // two 4-byte buffer loads: no alignment case, no branch (x + 1 == nx re-reads x)
+        const pp_rsrc rd = pp_make_rsrc(D + c * N + po);
+        dsum[c].x = pp_bld(rd, o_xy);
+        dsum[c].y = pp_bld(rd, o_xy1);
+      }
+    }
+  };
+
   // prologue: z window and border ring at the first plane, published; its ESM update in s_u
   {
     const int zc0 = pp_clampi(zs, 0, d.nz - 1);
@@ -733,6 +755,13 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     prefetch(zc0);
     __syncthreads();
     esm(zc0);
+#ifndef PP_A_PREFETCH_TOP
+    {   // step 0's image loads (see the end of the plane step)
+      const int n1 = pp_clampi(zs + 1, 0, d.nz - 1);
+      if (nsteps > 1 && n1 != zc0) prefetch(n1);
+    }
+#endif
+    if constexpr (SUM) load_dsum(zs - R);
     __syncthreads();
   }
 
@@ -743,11 +772,13 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     const bool fresh_cur = (n == 0) || (cur != pp_clampi(zi - 1, 0, d.nz - 1));
     const int nxt = pp_clampi(zi + 1, 0, d.nz - 1);
     const bool fresh_next = (n + 1 < nsteps) && (nxt != cur);
+    const int zo = zi - R;
+    const bool emit = (zo >= z0) && (zo <= zo_last) && out_ok;
     // ---- interval 1: x pass of plane `cur` (s_u -> s_x) | publish the image tile of plane `nxt` ----
-    if (fresh_next) {
-      publish();
-      prefetch(nxt);
-    }
+    if (fresh_next) publish();
+#ifdef PP_A_PREFETCH_TOP
+    if (fresh_next) prefetch(nxt);
+#endif
     if (fresh_cur) fused2_xpass<R, NXI, 3 * G::XI>(s_u, s_x, a.wx, xsrc, xdst);
     if (fresh_cur || fresh_next) __syncthreads();
     // ---- interval 2: y pass of plane `cur` (s_x -> registers) | ESM update of plane `nxt` (s_mf -> s_u) ----
@@ -758,11 +789,14 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     if (fresh_next) esm(nxt);
     float us[3][2];
     fused2_ring<R, P>(rg, v, a.wz, us);
-    const int zo = zi - R;
-    if (zo >= z0 && zo <= zo_last && out_ok) {
+    if (emit) {
       const size_t po = (size_t)zo * sz;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
+        if constexpr (SUM) {
+          us[c][0] = dsum[c].x + us[c][0];
+          us[c][1] = dsum[c].y + us[c][1];
+        }
         const pp_rsrc ro = pp_make_rsrc(Us + c * N + po);
         if (pair_ok) {
           pp_bst2(ro, o_xy, us[c][0], us[c][1]);
@@ -772,6 +806,15 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
         }
       }
     }
+    // The next step's loads go in flight here, behind this step's stores, so that no wait of this step has them
+    // pending: the image planes are consumed by the next ESM pass, D (SUM) by the next stores.
+#ifndef PP_A_PREFETCH_TOP
+    {
+      const int nxt2 = pp_clampi(zi + 2, 0, d.nz - 1);
+      if ((n + 2 < nsteps) && (nxt2 != nxt)) prefetch(nxt2);
+    }
+#endif
+    if constexpr (SUM) load_dsum(zo + 1);
     if (fresh_cur || fresh_next) __syncthreads();
   };
   fused2_plane_loop<R, UNROLL>(step, nsteps);

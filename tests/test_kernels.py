@@ -341,12 +341,15 @@ def test_fused_demons_generations_agree(backend, grid, tile, monkeypatch):
     p = _demons_params(backend.ctx, 3, spacing, _lib.DEMONS_FUSED, max_rms=0.0)
     monkeypatch.setenv("PP_FUSED_TILE", tile)
     out = {}
-    for gen in ("1", "2"):
-        monkeypatch.setenv("PP_FUSED_GEN", gen)
+    for gen in ("1", "2", "2-separate"):   # "2": kernel A stores D + U (one halo'd volume for kernel B); "2-separate": U alone
+        monkeypatch.setenv("PP_FUSED_GEN", gen[0])
+        monkeypatch.setenv("PP_FUSED_SUM", "0" if gen.endswith("separate") else "1")
         f = backend.empty((3,) + shape)
         st = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, f)
         out[gen] = (backend.host(f).copy(), st.metric, st.rms_change, st.n_pixels, st.elapsed_iterations)
     np.testing.assert_array_equal(out["1"][0], out["2"][0])
+    np.testing.assert_array_equal(out["2"][0], out["2-separate"][0])
+    assert out["2"][1:] == out["2-separate"][1:]
     # the statistics are fp32 per-thread partial sums folded in fp64: the two generations group voxels differently
     np.testing.assert_allclose(out["1"][1:3], out["2"][1:3], rtol=1e-6)
     assert out["1"][3] == out["2"][3] and out["1"][4] == out["2"][4] == 3
