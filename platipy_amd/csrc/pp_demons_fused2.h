@@ -22,6 +22,9 @@
 
 // Register budget: 4 waves per SIMD = two 512-thread blocks per CU (<= 128 VGPRs); without the bound the scheduler
 // spends up to ~170 registers on load latency it cannot use with one block per CU.
+#ifndef PP_B_DEFER
+#define PP_B_DEFER 1
+#endif
 #ifndef PP_GEN2_WAVES
 #define PP_GEN2_WAVES 4
 #endif
@@ -538,25 +541,27 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
     if (emit) {
       mw0 = dn[0][0] + dn[1][0] * dn[2][0];
       mw1 = dn[0][1] + dn[1][1] * dn[2][1];
-    } else
-#endif
-    if (emit) {
-      mw0 = fused2_warp_sample(rm, wd, x, dn[0][0] * sc.ix, y, dn[1][0] * sc.iy, zo, dn[2][0] * sc.iz, out_ok);
-      mw1 = fused2_warp_sample(rm, wd, x + 1, dn[0][1] * sc.ix, y, dn[1][1] * sc.iy, zo, dn[2][1] * sc.iz, out_ok && (x + 1 < d.nx));
     }
+#else
+    // The 8 corner loads of the two samples are issued here and consumed after the next plane's x pass (PP_B_DEFER):
+    // their latency hides behind the field stores, a barrier and the x pass instead of stalling the wave at once.
+    pp_warp_pending g0, g1;
+    if (emit) {
+      fused2_warp_issue(rm, wd, x, dn[0][0] * sc.ix, y, dn[1][0] * sc.iy, zo, dn[2][0] * sc.iz, out_ok, g0);
+      fused2_warp_issue(rm, wd, x + 1, dn[0][1] * sc.ix, y, dn[1][1] * sc.iy, zo, dn[2][1] * sc.iz, out_ok && (x + 1 < d.nx), g1);
+#if !PP_B_DEFER
+      mw0 = fused2_warp_finish(g0);
+      mw1 = fused2_warp_finish(g1);
+#endif
+    }
+#endif
     // the plane after `nxt` goes in flight behind the gathers
     if (fresh_next && nxt < zhi) load_plane(nxt + 1);
-#ifdef PP_ABL_NOSTORE
-    if (emit && out_ok && mw0 == 1.2345e-30f && dn[0][0] == 3.21e-29f && dn[1][1] == 1e-31f && dn[2][0] == 7e-33f && mw1 == 1e-30f && dn[0][1] == 2e-30f && dn[1][0] == 3e-30f && dn[2][1] == 4e-30f) {
-#else
-    if (emit && out_ok) {
-#endif
-      const size_t po = (size_t)zo * sz;
-      const pp_rsrc rw = pp_make_rsrc(Mw + po);
+    const size_t po = (size_t)zo * sz;
+    auto store_field = [&]() {
       if (pair_ok) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) pp_bst2(pp_make_rsrc(Dn + c * N + po), o_xy, dn[c][0], dn[c][1]);
-        pp_bst2(rw, o_xy, mw0, mw1);
       } else {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -564,9 +569,27 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
           pp_bst(rdn, o_xy, dn[c][0]);
           if (x + 1 < d.nx) pp_bst(rdn, o_xy + 4u, dn[c][1]);
         }
+      }
+    };
+    auto store_image = [&]() {
+      const pp_rsrc rw = pp_make_rsrc(Mw + po);
+      if (pair_ok) {
+        pp_bst2(rw, o_xy, mw0, mw1);
+      } else {
         pp_bst(rw, o_xy, mw0);
         if (x + 1 < d.nx) pp_bst(rw, o_xy + 4u, mw1);
       }
+    };
+#ifdef PP_ABL_NOSTORE
+    const bool do_store = emit && out_ok && dn[0][0] == 3.21e-29f && dn[1][1] == 1e-31f && dn[2][0] == 7e-33f && dn[0][1] == 2e-30f && dn[1][0] == 3e-30f && dn[2][1] == 4e-30f;
+#else
+    const bool do_store = emit && out_ok;
+#endif
+    if (do_store) {
+      store_field();
+#if !PP_B_DEFER || defined(PP_ABL_NOGATHER)
+      store_image();
+#endif
     }
     // ---- interval 2: x pass of plane `nxt` ----
     if (fresh_next) {
@@ -574,6 +597,13 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
       fused2_xpass_strips<R, G>(s_u, s_x, a.wx, xsrc, xdst);
       __syncthreads();
     }
+#if PP_B_DEFER && !defined(PP_ABL_NOGATHER)
+    if (emit) {
+      mw0 = fused2_warp_finish(g0);
+      mw1 = fused2_warp_finish(g1);
+    }
+    if (do_store) store_image();
+#endif
   };
   fused2_plane_loop<R, UNROLL>(step, nsteps);
 }
