@@ -50,6 +50,13 @@ __device__ __forceinline__ float2 pp_gld2(const char* base, unsigned byte_off) {
   const pp_f2u v = *reinterpret_cast<const pp_f2u*>(base + (size_t)byte_off);
   return make_float2(v.x, v.y);
 }
+// ... and the matching 8-byte store to a 4-byte-aligned position (rows of odd length: every other row starts off 8 bytes)
+__device__ __forceinline__ void pp_gst2(char* base, unsigned byte_off, float a, float b) {
+  pp_f2u v;
+  v.x = a;
+  v.y = b;
+  *reinterpret_cast<pp_f2u*>(base + (size_t)byte_off) = v;
+}
 #ifndef PP_STORE_AUX
 #define PP_STORE_AUX 0
 #endif
@@ -562,22 +569,22 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
       if (pair_ok) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) pp_bst2(pp_make_rsrc(Dn + c * N + po), o_xy, dn[c][0], dn[c][1]);
+      } else if (x + 1 < d.nx) {   // odd row length: pairs at 4-byte alignment
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pp_gst2(reinterpret_cast<char*>(Dn + c * N + po), o_xy, dn[c][0], dn[c][1]);
       } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const pp_rsrc rdn = pp_make_rsrc(Dn + c * N + po);
-          pp_bst(rdn, o_xy, dn[c][0]);
-          if (x + 1 < d.nx) pp_bst(rdn, o_xy + 4u, dn[c][1]);
-        }
+        for (int c = 0; c < 3; ++c) pp_bst(pp_make_rsrc(Dn + c * N + po), o_xy, dn[c][0]);
       }
     };
     auto store_image = [&]() {
       const pp_rsrc rw = pp_make_rsrc(Mw + po);
       if (pair_ok) {
         pp_bst2(rw, o_xy, mw0, mw1);
+      } else if (x + 1 < d.nx) {
+        pp_gst2(reinterpret_cast<char*>(Mw + po), o_xy, mw0, mw1);
       } else {
         pp_bst(rw, o_xy, mw0);
-        if (x + 1 < d.nx) pp_bst(rw, o_xy + 4u, mw1);
       }
     };
 #ifdef PP_ABL_NOSTORE
@@ -830,9 +837,10 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
         const pp_rsrc ro = pp_make_rsrc(Us + c * N + po);
         if (pair_ok) {
           pp_bst2(ro, o_xy, us[c][0], us[c][1]);
+        } else if (x + 1 < d.nx) {
+          pp_gst2(reinterpret_cast<char*>(Us + c * N + po), o_xy, us[c][0], us[c][1]);
         } else {
           pp_bst(ro, o_xy, us[c][0]);
-          if (x + 1 < d.nx) pp_bst(ro, o_xy + 4u, us[c][1]);
         }
       }
     }
