@@ -301,6 +301,7 @@ struct fused_args {
   int zchunk;
   int gx, gy, gz;   // tile grid
   int per_xcd;      // ceil(gx * gy * gz / 8)
+  int streaming;    // generation 2: non-temporal output stores (volumes far beyond the infinity cache)
   pp_taps_small wx, wy, wz;
 };
 
@@ -872,6 +873,11 @@ void fused_grid(fused_args* f, const pp_dims& d, int occupancy, int sh, char ker
   f->gy = (d.ny + TY - 1) / TY;
   f->gz = (d.nz + f->zchunk - 1) / f->zchunk;
   f->per_xcd = (int)(((size_t)f->gx * f->gy * f->gz + 7) / 8);
+  // an iteration touches 13 volumes' worth of floats (F, M, two warped images, D, D', S: 3 each); stream the outputs once
+  // that is several times the 256 MB infinity cache.  Measured (tools/kbench/run12.sh): 79 MB volumes +1.5 % slower with
+  // nt stores, 113 MB -1.5 %, 180 MB -2 %, 268 MB -2.7 %.
+  f->streaming = (size_t)d.nx * d.ny * d.nz * sizeof(float) > ((size_t)100 << 20);
+  if (const char* e = getenv("PP_FUSED_NT")) f->streaming = atoi(e) != 0;
 }
 
 int check_demons_args(pp_ctx* ctx, const pp_geom* g, const pp_demons_params* p) {

@@ -57,6 +57,8 @@ __device__ __forceinline__ void pp_gst2(char* base, unsigned byte_off, float a, 
   v.y = b;
   *reinterpret_cast<pp_f2u*>(base + (size_t)byte_off) = v;
 }
+// Cache-policy bits of the buffer stores (2 = nt, streaming) for builds that force one policy; the product chooses per
+// launch, see pp_bst2 below.
 #ifndef PP_STORE_AUX
 #define PP_STORE_AUX 0
 #endif
@@ -68,6 +70,19 @@ __device__ __forceinline__ void pp_bst2(pp_rsrc r, unsigned byte_off, float a, f
   v[0] = __builtin_bit_cast(unsigned, a);
   v[1] = __builtin_bit_cast(unsigned, b);
   __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, PP_STORE_AUX);
+}
+// Pair store with the cache policy picked per launch (a wave-uniform flag): streaming (nt) when the iteration's working set
+// is far larger than the 256 MB infinity cache -- the outputs are read next by the OTHER kernel, long after they have left
+// the caches, and need not displace the halo rows and moving-image lines that neighbouring tiles share (512 x 512 x 256:
+// -3 % per iteration) -- and cached when the next kernel can still find them there (340 x 341 x 171: nt costs 11 %).
+__device__ __forceinline__ void pp_bst2(pp_rsrc r, unsigned byte_off, float a, float b, bool streaming) {
+  pp_u2 v;
+  v[0] = __builtin_bit_cast(unsigned, a);
+  v[1] = __builtin_bit_cast(unsigned, b);
+  if (streaming)
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, 2);
+  else
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, 0);
 }
 
 // Sum of three doubles over the block: butterfly inside each wavefront (ds_bpermute shuffles, no LDS
@@ -105,10 +120,18 @@ __device__ __forceinline__ void pp_block_sum3_shfl(double& a, double& b, double&
 struct pp_f4u {
   float x, y, z, w;
 } __attribute__((aligned(4)));
+#ifdef PP_NT_LOADS   // measurement builds: streaming hint on the strip loads
+typedef float pp_v4u __attribute__((vector_size(16), aligned(4)));
+__device__ __forceinline__ float4 pp_gld4(const char* base, unsigned byte_off) {
+  const pp_v4u v = __builtin_nontemporal_load(reinterpret_cast<const pp_v4u*>(base + (size_t)byte_off));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+#else
 __device__ __forceinline__ float4 pp_gld4(const char* base, unsigned byte_off) {
   const pp_f4u v = *reinterpret_cast<const pp_f4u*>(base + (size_t)byte_off);
   return make_float4(v.x, v.y, v.z, v.w);
 }
+#endif
 
 // Strip geometry of the generation-2 kernels.  The smoothing-input tile is fetched and published as STRIPS of four
 // consecutive x voxels (one 16-byte load / LDS store per strip and array instead of four 4-byte ones): the tile's x
@@ -568,7 +591,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
     auto store_field = [&]() {
       if (pair_ok) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) pp_bst2(pp_make_rsrc(Dn + c * N + po), o_xy, dn[c][0], dn[c][1]);
+        for (int c = 0; c < 3; ++c) pp_bst2(pp_make_rsrc(Dn + c * N + po), o_xy, dn[c][0], dn[c][1], a.streaming != 0);
       } else if (x + 1 < d.nx) {   // odd row length: pairs at 4-byte alignment
 #pragma unroll
         for (int c = 0; c < 3; ++c) pp_gst2(reinterpret_cast<char*>(Dn + c * N + po), o_xy, dn[c][0], dn[c][1]);
@@ -580,7 +603,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
     auto store_image = [&]() {
       const pp_rsrc rw = pp_make_rsrc(Mw + po);
       if (pair_ok) {
-        pp_bst2(rw, o_xy, mw0, mw1);
+        pp_bst2(rw, o_xy, mw0, mw1, a.streaming != 0);
       } else if (x + 1 < d.nx) {
         pp_gst2(reinterpret_cast<char*>(Mw + po), o_xy, mw0, mw1);
       } else {
@@ -836,7 +859,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
         }
         const pp_rsrc ro = pp_make_rsrc(Us + c * N + po);
         if (pair_ok) {
-          pp_bst2(ro, o_xy, us[c][0], us[c][1]);
+          pp_bst2(ro, o_xy, us[c][0], us[c][1], a.streaming != 0);
         } else if (x + 1 < d.nx) {
           pp_gst2(reinterpret_cast<char*>(Us + c * N + po), o_xy, us[c][0], us[c][1]);
         } else {
