@@ -638,6 +638,19 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
   fused2_plane_loop<R, UNROLL>(step, nsteps);
 }
 
+// pp_esm_axis with the border rules carried by DATA instead of per-lane flags (the hoisted flag masks cost kernel A ~36
+// scalar-register reloads per plane): a neighbour slot outside the volume holds the sentinel in its warped-image half, so
+// "usable" needs no first/last-index test, and the fixed-image difference is scaled by hf = 0 on the first/last index
+// (h elsewhere).  Same operations on the same operands as pp_esm_axis; on the border the fixed term is +-0 instead of +0.
+__device__ __forceinline__ float pp_esm_axis_data(float fm, float fp, float mc, float mm, float mp, float hf, float inv_sp) {
+  const float h = 0.5f * inv_sp;
+  const bool up = (mp != FLT_MAX), um = (mm != FLT_MAX);
+  const float hi_v = up ? mp : mc, lo_v = um ? mm : mc;
+  const float wg = (hi_v - lo_v) * ((up && um) ? h : inv_sp);
+  const float fg = (fp - fm) * hf;
+  return fg + wg;
+}
+
 // ---- kernel A, generation 2: ESM update + 3-D Gaussian of the update -----------------------------------
 // SUM: the stored volume is D + G_u * update (D read at the thread's own output voxels), what kernel B<SUM> smooths.
 template <int R, int SH, bool UNROLL, bool SUM>
@@ -670,6 +683,8 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
   unsigned uflag[G::KU];  // slot in s_u | flags << 16
   unsigned own_g[G::KU];  // in-plane BYTE offset of the clamped position
   float mprev[G::KU], mcur[G::KU], mnext[G::KU], fprev[G::KU], fcur[G::KU], fnext[G::KU];
+  float hfx[G::KU], hfy[G::KU];   // fixed-gradient factor: 0 on the first/last index of the axis
+  float oov[G::KU];               // FLT_MAX for elements outside the volume (their slot publishes the sentinel), else -FLT_MAX
 #pragma unroll
   for (int k = 0; k < G::KU; ++k) {
     const int e = t + k * NTH;
@@ -689,16 +704,21 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     if (yc == 0) fl |= F_YLO;
     if (yc == d.ny - 1) fl |= F_YHI;
     uflag[k] = (unsigned)(uy * G::UWP + ux) | (fl << 16);
+    hfx[k] = (fl & (F_XLO | F_XHI)) ? 0.0f : 0.5f * K.ix;
+    hfy[k] = (fl & (F_YLO | F_YHI)) ? 0.0f : 0.5f * K.iy;
+    oov[k] = (xg != xc || yg != yc) ? FLT_MAX : -FLT_MAX;
   }
   // Border ring of the image tile (needed only in-plane): one element per low thread.
   int brd_w = -1;
   unsigned brd_g = 0;
+  float brd_oov = -FLT_MAX;
   if (t < G::NB) {
     int my, mx;
     if (t < G::MW) { my = 0; mx = t; }
     else if (t < 2 * G::MW) { my = G::MH - 1; mx = t - G::MW; }
     else { const int q = t - 2 * G::MW; my = 1 + q / 2; mx = (q & 1) ? G::MW - 1 : 0; }
     const int xc = pp_clampi(tx0 - R - 1 + mx, 0, d.nx - 1), yc = pp_clampi(ty0 - R - 1 + my, 0, d.ny - 1);
+    if (xc != tx0 - R - 1 + mx || yc != ty0 - R - 1 + my) brd_oov = FLT_MAX;
     brd_w = my * G::MWP + mx;
     brd_g = ((unsigned)yc * sy + (unsigned)xc) * 4u;
   }
@@ -723,8 +743,8 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
   auto publish = [&]() {   // window centre (mcur, fcur) + border ring -> packed image tile
 #pragma unroll
     for (int k = 0; k < G::KU; ++k)
-      if ((k + 1) * NTH <= G::NU || ((uflag[k] >> 16) & F_VALID)) s_mf[slots[k] >> 16] = make_float2(mcur[k], fcur[k]);
-    if (brd_w >= 0) s_mf[brd_w] = make_float2(bm, bf);
+      if ((k + 1) * NTH <= G::NU || ((uflag[k] >> 16) & F_VALID)) s_mf[slots[k] >> 16] = make_float2(fmaxf(mcur[k], oov[k]), fcur[k]);
+    if (brd_w >= 0) s_mf[brd_w] = make_float2(fmaxf(bm, brd_oov), bf);
   };
   auto prefetch = [&](int zc) {   // own voxels of plane zc + 2, border ring of plane zc + 1
     const size_t p2 = (size_t)pp_clampi(zc + 2, 0, d.nz - 1) * sz, p1 = (size_t)pp_clampi(zc + 1, 0, d.nz - 1) * sz;
@@ -748,8 +768,8 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
       if ((k + 1) * NTH <= G::NU || (fl & F_VALID)) {
         const int l = (int)(slots[k] & 0xffffu);
         const float2 xm = s_mf[l - 1], xp = s_mf[l + 1], ym = s_mf[l - G::MWP], yp = s_mf[l + G::MWP];
-        const float gx = pp_esm_axis(xm.y, xp.y, mcur[k], xm.x, xp.x, (fl & F_XLO) != 0, (fl & F_XHI) != 0, K.ix);
-        const float gy = pp_esm_axis(ym.y, yp.y, mcur[k], ym.x, yp.x, (fl & F_YLO) != 0, (fl & F_YHI) != 0, K.iy);
+        const float gx = pp_esm_axis_data(xm.y, xp.y, mcur[k], xm.x, xp.x, hfx[k], K.ix);
+        const float gy = pp_esm_axis_data(ym.y, yp.y, mcur[k], ym.x, yp.x, hfy[k], K.iy);
         const float gz = pp_esm_axis(fprev[k], fnext[k], mcur[k], mprev[k], mnext[k], zlo_b, zhi_b, K.iz);
         const pp_esm_out o = pp_esm_voxel(K, fcur[k], mcur[k], gx, gy, gz);
         const int u = (int)(uflag[k] & 0xffffu);
