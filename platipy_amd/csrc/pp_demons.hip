@@ -815,14 +815,14 @@ int launch_warp(pp_ctx* ctx, int sh, const float* D, const float* Us, const floa
 // (beyond that the unrolled plane loop does not fit 128 registers and the first generation is faster).  SUM: see the header.
 #define PP_BY_RADIUS_A2(R, CALL) ((R) == 1 ? CALL(1) : ((R) == 2 ? CALL(2) : CALL(3)))
 #define PP_BY_RADIUS_B2(R, CALL) ((R) == 1 ? CALL(1) : ((R) == 2 ? CALL(2) : ((R) == 3 ? CALL(3) : CALL(4))))
-#define PP_A2_KERNEL(SHV, SUMV) k_fused2_force_smooth<R, SHV, (R <= PP_RING_UNROLL_MAX_R), SUMV>
-#define PP_B2_KERNEL(SHV, SUMV) k_fused2_add_smooth_warp<R, SHV, (R <= PP_RING_UNROLL_MAX_R), SUMV>
+#define PP_A2_KERNEL(SHV, SUMV, NTV) k_fused2_force_smooth<R, SHV, (R <= PP_RING_UNROLL_MAX_R), SUMV, NTV>
+#define PP_B2_KERNEL(SHV, SUMV, NTV) k_fused2_add_smooth_warp<R, SHV, (R <= PP_RING_UNROLL_MAX_R), SUMV, NTV>
 
 template <int R>
 int occ_force2(int sh) {   // (the SUM variant holds six more registers; both stay in the same occupancy tier)
   int a = 0;
-  const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(1, true), 512, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(0, true), 512, 0);
+  const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(1, true, false), 512, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(0, true, false), 512, 0);
   if (e != hipSuccess) a = 2;
   (void)hipGetLastError();
   return a < 1 ? 1 : a;
@@ -830,8 +830,8 @@ int occ_force2(int sh) {   // (the SUM variant holds six more registers; both st
 template <int R>
 int occ_warp2(int sh) {
   int a = 0;
-  const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(1, false), 512, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(0, false), 512, 0);
+  const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(1, true, false), 512, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(0, true, false), 512, 0);
   if (e != hipSuccess) a = 2;
   (void)hipGetLastError();
   return a < 1 ? 1 : a;
@@ -841,13 +841,15 @@ int launch_force2(pp_ctx* ctx, int sh, bool sum, const float* F, const float* Mw
                   const pp_esm_consts& K, double* partials, const int* halt) {
   pp_prof_scope ps(ctx, "k_fused2_force_smooth");
   const dim3 grid(8u * (unsigned)fu.per_xcd), block(512);
-  if (sum) {
-    if (sh) hipLaunchKernelGGL((PP_A2_KERNEL(1, true)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, halt);
-    else hipLaunchKernelGGL((PP_A2_KERNEL(0, true)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, halt);
+#define PP_GO(SHV, SUMV, NTV) hipLaunchKernelGGL((PP_A2_KERNEL(SHV, SUMV, NTV)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, halt)
+  if (!sum) {   // (PP_FUSED_SUM=0, a measurement path: cached stores only)
+    if (sh) PP_GO(1, false, false); else PP_GO(0, false, false);
+  } else if (fu.streaming) {
+    if (sh) PP_GO(1, true, true); else PP_GO(0, true, true);
   } else {
-    if (sh) hipLaunchKernelGGL((PP_A2_KERNEL(1, false)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, halt);
-    else hipLaunchKernelGGL((PP_A2_KERNEL(0, false)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, halt);
+    if (sh) PP_GO(1, true, false); else PP_GO(0, true, false);
   }
+#undef PP_GO
   return PP_OK;
 }
 template <int R>
@@ -855,13 +857,15 @@ int launch_warp2(pp_ctx* ctx, int sh, bool sum, const float* D, const float* Us,
                  const fused_args& fd, const pp_warp_scale& sc, const int* halt) {
   pp_prof_scope ps(ctx, "k_fused2_add_smooth_warp");
   const dim3 grid(8u * (unsigned)fd.per_xcd), block(512);
-  if (sum) {
-    if (sh) hipLaunchKernelGGL((PP_B2_KERNEL(1, true)), grid, block, 0, ctx->stream, D, Us, M, Dn, Mw_out, fd, sc, halt);
-    else hipLaunchKernelGGL((PP_B2_KERNEL(0, true)), grid, block, 0, ctx->stream, D, Us, M, Dn, Mw_out, fd, sc, halt);
+#define PP_GO(SHV, SUMV, NTV) hipLaunchKernelGGL((PP_B2_KERNEL(SHV, SUMV, NTV)), grid, block, 0, ctx->stream, D, Us, M, Dn, Mw_out, fd, sc, halt)
+  if (!sum) {
+    if (sh) PP_GO(1, false, false); else PP_GO(0, false, false);
+  } else if (fd.streaming) {
+    if (sh) PP_GO(1, true, true); else PP_GO(0, true, true);
   } else {
-    if (sh) hipLaunchKernelGGL((PP_B2_KERNEL(1, false)), grid, block, 0, ctx->stream, D, Us, M, Dn, Mw_out, fd, sc, halt);
-    else hipLaunchKernelGGL((PP_B2_KERNEL(0, false)), grid, block, 0, ctx->stream, D, Us, M, Dn, Mw_out, fd, sc, halt);
+    if (sh) PP_GO(1, true, false); else PP_GO(0, true, false);
   }
+#undef PP_GO
   return PP_OK;
 }
 

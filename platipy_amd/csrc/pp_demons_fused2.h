@@ -71,18 +71,16 @@ __device__ __forceinline__ void pp_bst2(pp_rsrc r, unsigned byte_off, float a, f
   v[1] = __builtin_bit_cast(unsigned, b);
   __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, PP_STORE_AUX);
 }
-// Pair store with the cache policy picked per launch (a wave-uniform flag): streaming (nt) when the iteration's working set
+// Pair store with the cache policy picked per launch (a kernel template parameter): streaming (nt) when the iteration's working set
 // is far larger than the 256 MB infinity cache -- the outputs are read next by the OTHER kernel, long after they have left
 // the caches, and need not displace the halo rows and moving-image lines that neighbouring tiles share (512 x 512 x 256:
 // -3 % per iteration) -- and cached when the next kernel can still find them there (340 x 341 x 171: nt costs 11 %).
-__device__ __forceinline__ void pp_bst2(pp_rsrc r, unsigned byte_off, float a, float b, bool streaming) {
+template <bool STREAMING>
+__device__ __forceinline__ void pp_bst2s(pp_rsrc r, unsigned byte_off, float a, float b) {
   pp_u2 v;
   v[0] = __builtin_bit_cast(unsigned, a);
   v[1] = __builtin_bit_cast(unsigned, b);
-  if (streaming)
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, 2);
-  else
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, STREAMING ? 2 : 0);
 }
 
 // Sum of three doubles over the block: butterfly inside each wavefront (ds_bpermute shuffles, no LDS
@@ -454,7 +452,7 @@ __device__ __forceinline__ float fused2_warp_sample(const char* rm, const pp_war
 // ---- kernel B, generation 2: D' = G_d * (D + U), then the next iteration's warped moving image --------
 // SUM: `Us` already holds D + U (kernel A<SUM> added D at its own output voxels, where it needs no halo), `D` is not read:
 // three halo'd arrays instead of six.  The sum is the same fp32 add on the same operands, so the fields are bit-identical.
-template <int R, int SH, bool UNROLL, bool SUM>
+template <int R, int SH, bool UNROLL, bool SUM, bool NT>
 __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(const float* __restrict__ D, const float* __restrict__ Us,
                                                                             const float* __restrict__ M, float* __restrict__ Dn,
                                                                             float* __restrict__ Mw, fused_args a, pp_warp_scale sc,
@@ -591,7 +589,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
     auto store_field = [&]() {
       if (pair_ok) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) pp_bst2(pp_make_rsrc(Dn + c * N + po), o_xy, dn[c][0], dn[c][1], a.streaming != 0);
+        for (int c = 0; c < 3; ++c) pp_bst2s<NT>(pp_make_rsrc(Dn + c * N + po), o_xy, dn[c][0], dn[c][1]);
       } else if (x + 1 < d.nx) {   // odd row length: pairs at 4-byte alignment
 #pragma unroll
         for (int c = 0; c < 3; ++c) pp_gst2(reinterpret_cast<char*>(Dn + c * N + po), o_xy, dn[c][0], dn[c][1]);
@@ -603,7 +601,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
     auto store_image = [&]() {
       const pp_rsrc rw = pp_make_rsrc(Mw + po);
       if (pair_ok) {
-        pp_bst2(rw, o_xy, mw0, mw1, a.streaming != 0);
+        pp_bst2s<NT>(rw, o_xy, mw0, mw1);
       } else if (x + 1 < d.nx) {
         pp_gst2(reinterpret_cast<char*>(Mw + po), o_xy, mw0, mw1);
       } else {
@@ -653,7 +651,7 @@ __device__ __forceinline__ float pp_esm_axis_data(float fm, float fp, float mc, 
 
 // ---- kernel A, generation 2: ESM update + 3-D Gaussian of the update -----------------------------------
 // SUM: the stored volume is D + G_u * update (D read at the thread's own output voxels), what kernel B<SUM> smooths.
-template <int R, int SH, bool UNROLL, bool SUM>
+template <int R, int SH, bool UNROLL, bool SUM, bool NT>
 __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(const float* __restrict__ F, const float* __restrict__ Mw,
                                                                          const float* __restrict__ D, float* __restrict__ Us,
                                                                          fused_args a, pp_esm_consts K,
@@ -879,7 +877,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
         }
         const pp_rsrc ro = pp_make_rsrc(Us + c * N + po);
         if (pair_ok) {
-          pp_bst2(ro, o_xy, us[c][0], us[c][1], a.streaming != 0);
+          pp_bst2s<NT>(ro, o_xy, us[c][0], us[c][1]);
         } else if (x + 1 < d.nx) {
           pp_gst2(reinterpret_cast<char*>(Us + c * N + po), o_xy, us[c][0], us[c][1]);
         } else {
