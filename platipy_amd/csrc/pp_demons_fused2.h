@@ -22,6 +22,12 @@
 
 // Register budget: 4 waves per SIMD = two 512-thread blocks per CU (<= 128 VGPRs); without the bound the scheduler
 // spends up to ~170 registers on load latency it cannot use with one block per CU.
+#ifndef PP_B_XDPP
+#define PP_B_XDPP 1
+#endif
+#ifndef PP_B_XSHFL
+#define PP_B_XSHFL 1
+#endif
 #ifndef PP_B_DEFER
 #define PP_B_DEFER 1
 #endif
@@ -317,6 +323,71 @@ __device__ __forceinline__ void fused2_ypass_strips(const float* __restrict__ xs
   }
 }
 
+// x pass of kernel B in registers: a lane holds one strip (four consecutive x voxels, three components) and takes the R
+// voxels either side from the neighbouring lanes with wavefront shuffles -- strips are laid out RPW whole rows per wave
+// (strip_lanes below), so a strip's x neighbours are the adjacent lanes.  The x-passed strip goes straight to the
+// y pass's LDS buffer: no staging of the raw tile, one LDS trip and one barrier per plane less than fused2_xpass_strips.
+// Same products, same summation order.
+template <class G>
+struct strip_lanes {
+  static constexpr int RPW = 64 / G::SPR;                      // whole rows per wave
+  static_assert(G::RP == 4 && G::NSL == 1, "one halo strip either side, one strip per thread");
+  static_assert(RPW >= 1 && (G::UH + RPW - 1) / RPW <= G::NTH / 64, "the tile's rows fit the block's waves");
+};
+// Value of the previous / next lane of the wavefront (DPP wave_shr:1 / wave_shl:1, a VALU move: no LDS crossbar trip).
+// Lane 0 / lane 63 keep their own value.
+__device__ __forceinline__ float pp_lane_prev(float v) {
+#if PP_B_XDPP
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x138, 0xf, 0xf, false));
+#else
+  return __shfl_up(v, 1);
+#endif
+}
+__device__ __forceinline__ float pp_lane_next(float v) {
+#if PP_B_XDPP
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x130, 0xf, 0xf, false));
+#else
+  return __shfl_down(v, 1);
+#endif
+}
+__device__ __forceinline__ float pp_pick4(float ax, float ay, float az, float aw, unsigned i) {   // (selects on scalars: no vector indexing)
+  const float lo = (i & 1u) ? ay : ax, hi = (i & 1u) ? aw : az;
+  return (i & 2u) ? hi : lo;
+}
+template <int R, class G>
+__device__ __forceinline__ void fused2_xpass_shfl(const float4 (&strip)[3], unsigned jm, bool has_out, int xoff, float* __restrict__ xs,
+                                                  const pp_taps_small& wx) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float sx_ = strip[c].x, sy_ = strip[c].y, sz_ = strip[c].z, sw_ = strip[c].w;
+    float own[4] = {sx_, sy_, sz_, sw_};
+    if (jm != 0xE4u) {   // strips that leave the volume in x (x-border tiles only): every position takes its clamped voxel
+      own[0] = pp_pick4(sx_, sy_, sz_, sw_, jm & 3u);
+      own[1] = pp_pick4(sx_, sy_, sz_, sw_, (jm >> 2) & 3u);
+      own[2] = pp_pick4(sx_, sy_, sz_, sw_, (jm >> 4) & 3u);
+      own[3] = pp_pick4(sx_, sy_, sz_, sw_, (jm >> 6) & 3u);
+    }
+    float in[4 + 2 * R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) in[q] = pp_lane_prev(own[4 - R + q]);          // left neighbour's last R voxels
+#pragma unroll
+    for (int q = 0; q < 4; ++q) in[R + q] = own[q];
+#pragma unroll
+    for (int q = 0; q < R; ++q) in[R + 4 + q] = pp_lane_next(own[q]);        // right neighbour's first R voxels
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 2 * R + 1; ++k) acc = fmaf(wx.h[k < R ? R - k : k - R], in[j + k], acc);
+      o[j] = acc;
+    }
+    if (has_out) *reinterpret_cast<float4*>(xs + c * G::UH * G::TX + xoff) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // z window: slot P receives the newest plane; the dot runs oldest -> newest like zring::dot.
 template <int R, int P>
 __device__ __forceinline__ void fused2_ring_step(float (&rg)[3][2][2 * R + 1], const float (&v)[3][2], const pp_taps_small& wz,
@@ -459,9 +530,10 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
                                                                             const int* __restrict__ halt) {
   using G = strip_geom<R, SH, 0>;
   constexpr int NTH = G::NTH, TX = G::TX, TY = G::TY, W = 2 * R + 1;
-  __shared__ __attribute__((aligned(16))) float smem[G::SZ_X + G::SZ_U];
+  constexpr bool XS = (PP_B_XSHFL != 0) && SUM;   // x pass in registers (wavefront shuffles), y-pass buffer double-buffered
+  __shared__ __attribute__((aligned(16))) float smem[XS ? 2 * G::SZ_X : G::SZ_X + G::SZ_U];
   float* const s_x = smem;
-  float* const s_u = smem + G::SZ_X;
+  float* const s_u = smem + G::SZ_X;   // (XS: the second y-pass buffer)
   if (halt && *halt) return;
   int tx0, ty0, z0;
   unsigned rank;
@@ -474,10 +546,22 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
   const size_t N = (size_t)sz * d.nz;
 
   pp_strip st[G::NSL];
-#pragma unroll
-  for (int i = 0; i < G::NSL; ++i) st[i] = pp_strip_setup(t + i * NTH, G::NS, G::SPR, G::UW, tx0 - G::RP, ty0 - R, d);
   int xsrc[G::NXI], xdst[G::NXI];
-  fused2_xpass_strips_setup<G>(t, xsrc, xdst);
+  bool xs_out = false;   // XS: this lane's strip lies in the tile's columns (not a halo strip) -> it stores an x-pass result
+  int xs_off = 0;
+  if constexpr (XS) {
+    constexpr int RPW = strip_lanes<G>::RPW;
+    const int lane = t & 63, riw = lane / G::SPR, sx = lane - riw * G::SPR;
+    const int uy = (t >> 6) * RPW + riw;
+    const bool valid = riw < RPW && uy < G::UH;
+    st[0] = pp_strip_setup(valid ? uy * G::SPR + sx : G::NS, G::NS, G::SPR, G::UW, tx0 - G::RP, ty0 - R, d);
+    xs_out = valid && sx >= 1 && sx <= G::SPR - 2;
+    xs_off = uy * TX + 4 * (sx - 1);
+  } else {
+#pragma unroll
+    for (int i = 0; i < G::NSL; ++i) st[i] = pp_strip_setup(t + i * NTH, G::NS, G::SPR, G::UW, tx0 - G::RP, ty0 - R, d);
+    fused2_xpass_strips_setup<G>(t, xsrc, xdst);
+  }
   const int yb = cy * TX + 2 * cx;
   const int x = tx0 + 2 * cx, y = ty0 + cy;
   const bool out_ok = (y < d.ny) && (x < d.nx);
@@ -540,12 +624,20 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
   {
     const int zc0 = pp_clampi(zs, 0, d.nz - 1);
     load_plane(zc0);
-    publish();
-    if (zc0 < zhi) load_plane(zc0 + 1);
-    __syncthreads();
-    fused2_xpass_strips<R, G>(s_u, s_x, a.wx, xsrc, xdst);
-    __syncthreads();
+    if constexpr (XS) {
+      const float4 s3[3] = {ul[0][0], ul[1][0], ul[2][0]};
+      fused2_xpass_shfl<R, G>(s3, st[0].jm, xs_out, xs_off, s_x, a.wx);
+      if (zc0 < zhi) load_plane(zc0 + 1);
+      __syncthreads();
+    } else {
+      publish();
+      if (zc0 < zhi) load_plane(zc0 + 1);
+      __syncthreads();
+      fused2_xpass_strips<R, G>(s_u, s_x, a.wx, xsrc, xdst);
+      __syncthreads();
+    }
   }
+  int ybuf = 0;   // XS: the buffer that holds the current plane's x-pass result
 
   auto step = [&](int n, auto phase_tag) {
     constexpr int P = decltype(phase_tag)::value;
@@ -557,9 +649,16 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
     // ---- interval 1: y pass of plane `cur` (reads s_x) | publish plane `nxt` (writes s_u) ----
     if (fresh_cur) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) fused2_ypass_strips<R, G>(s_x, c, yb, a.wy, v[c]);
+      for (int c = 0; c < 3; ++c) fused2_ypass_strips<R, G>(XS ? smem + ybuf * G::SZ_X : s_x, c, yb, a.wy, v[c]);
     }
-    if (fresh_next) publish();
+    if constexpr (XS) {
+      if (fresh_next) {   // x pass of plane `nxt` in registers, into the other buffer
+        const float4 s3[3] = {ul[0][0], ul[1][0], ul[2][0]};
+        fused2_xpass_shfl<R, G>(s3, st[0].jm, xs_out, xs_off, smem + (ybuf ^ 1) * G::SZ_X, a.wx);
+      }
+    } else {
+      if (fresh_next) publish();
+    }
     float dn[3][2];
     fused2_ring<R, P>(rg, v, a.wz, dn);
     const int zo = zi - R;
@@ -619,11 +718,15 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
       store_image();
 #endif
     }
-    // ---- interval 2: x pass of plane `nxt` ----
+    // ---- interval 2: x pass of plane `nxt` (XS: already done above; one barrier hands the buffers over) ----
     if (fresh_next) {
       __syncthreads();
-      fused2_xpass_strips<R, G>(s_u, s_x, a.wx, xsrc, xdst);
-      __syncthreads();
+      if constexpr (XS) {
+        ybuf ^= 1;
+      } else {
+        fused2_xpass_strips<R, G>(s_u, s_x, a.wx, xsrc, xdst);
+        __syncthreads();
+      }
     }
 #if PP_B_DEFER && !defined(PP_ABL_NOGATHER)
     if (emit) {

@@ -175,6 +175,17 @@ static inline float hipemu_shfl_from(float v, int delta) {   // value of lane (l
 }
 static inline float __shfl_up(float v, unsigned delta, int /*width*/ = 64) { return hipemu_shfl_from(v, -(int)delta); }
 static inline float __shfl_down(float v, unsigned delta, int /*width*/ = 64) { return hipemu_shfl_from(v, (int)delta); }
+// DPP whole-wave shifts by one lane (the two controls csrc/ uses): 0x138 = wave_shr:1 (value of lane - 1), 0x130 = wave_shl:1.
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
+  (void)old;
+  float f;
+  memcpy(&f, &src, 4);
+  // (a float carries any 32-bit pattern through the table unchanged: it is only copied)
+  const float r = ctrl == 0x138 ? hipemu_shfl_from(f, -1) : hipemu_shfl_from(f, 1);
+  int out;
+  memcpy(&out, &r, 4);
+  return out;
+}
 static inline double __shfl_xor(double v, int lane_mask, int /*width*/ = 64) {
   const unsigned t = threadIdx.x;
   ::hipemu::t_shfl[t] = v;
