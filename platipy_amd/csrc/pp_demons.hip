@@ -1033,7 +1033,8 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   // kernel generation: 2 (pp_demons_fused2.h) unless the volume exceeds its 32-bit gather offsets / 24-bit row arithmetic,
   // rows are shorter than one strip, the 256-thread layout was asked for, or PP_FUSED_GEN=1 selects the first generation
   // (kept for A/B measurements).
-  const bool gen2_ok = N * sizeof(float) < ((size_t)1 << 32) && (size_t)d.ny * d.nz < ((size_t)1 << 24) && d.nx >= 4 && d.nx < (1 << 22);
+  const bool gen2_ok = N * sizeof(float) < ((size_t)1 << 32) && (size_t)d.ny * d.nz < ((size_t)1 << 24) && d.nx >= 4 && d.nx < (1 << 22) &&
+                       d.ny < (1 << 22) && d.nz < (1 << 22);   // (every axis below the warp's 2^23-voxel displacement clamp)
   int gen = (gen2_ok && opt == 2) ? 2 : 1;
   if (const char* e = getenv("PP_FUSED_GEN")) {
     if (atoi(e) == 1) gen = 1;

@@ -469,15 +469,17 @@ struct pp_warp_pending {
 };
 __device__ __forceinline__ void fused2_warp_issue(const char* rm, const pp_warp_dims& wd, int xi, float dvx, int yi, float dvy, int zi,
                                                   float dvz, bool lane_ok, pp_warp_pending& g) {
-  // pp_split and pp_inside1 without short-circuit control flow: `h` = floor(2 * continuous index), and the buffer test
-  // [-0.5, n - 0.5) is -1 <= h <= 2n - 2.
-  const bool sx = fabsf(dvx) < 1.0e6f, sy_ = fabsf(dvy) < 1.0e6f, sz_ = fabsf(dvz) < 1.0e6f;
-  const float flx = floorf(dvx), fly = floorf(dvy), flz = floorf(dvz);
-  const int bx = sx ? xi + (int)flx : -0x40000000, by = sy_ ? yi + (int)fly : -0x40000000, bz = sz_ ? zi + (int)flz : -0x40000000;
-  const float fx = sx ? dvx - flx : 0.0f, fy = sy_ ? dvy - fly : 0.0f, fz = sz_ ? dvz - flz : 0.0f;
-  const int hx = 2 * bx + (fx >= 0.5f ? 1 : 0), hy = 2 * by + (fy >= 0.5f ? 1 : 0), hz = 2 * bz + (fz >= 0.5f ? 1 : 0);
-  const bool inside = lane_ok & ((unsigned)(hx + 1) <= (unsigned)(2 * wd.nx - 1)) & ((unsigned)(hy + 1) <= (unsigned)(2 * wd.ny - 1)) &
-                      ((unsigned)(hz + 1) <= (unsigned)(2 * wd.nz - 1));
+  // pp_split and pp_inside1 in straight-line form.  The displacement is clamped to +-2^23 voxels first (one v_med3; also
+  // catches NaN): beyond that the sample is outside any volume this kernel takes (nx, ny, nz < 2^22) either way, and the
+  // integer conversions below stay defined.  ITK's buffer test [-0.5, n - 0.5) on the continuous index is
+  // 0 <= round-half-up index <= n - 1, and the round-half-up index is base + (frac >= 0.5).
+  const float LIM = 8388608.0f;
+  const float cvx = fminf(fmaxf(dvx, -LIM), LIM), cvy = fminf(fmaxf(dvy, -LIM), LIM), cvz = fminf(fmaxf(dvz, -LIM), LIM);
+  const float flx = floorf(cvx), fly = floorf(cvy), flz = floorf(cvz);
+  const int bx = xi + (int)flx, by = yi + (int)fly, bz = zi + (int)flz;
+  const float fx = cvx - flx, fy = cvy - fly, fz = cvz - flz;
+  const int nx_ = bx + (fx >= 0.5f ? 1 : 0), ny_ = by + (fy >= 0.5f ? 1 : 0), nz_ = bz + (fz >= 0.5f ? 1 : 0);
+  const bool inside = lane_ok & ((unsigned)nx_ < (unsigned)wd.nx) & ((unsigned)ny_ < (unsigned)wd.ny) & ((unsigned)nz_ < (unsigned)wd.nz);
   // pp_axis_setup, with the base index also clamped from above so that outside lanes still form valid addresses
   const int x0 = pp_clampi(bx, 0, wd.nx - 1), y0 = pp_clampi(by, 0, wd.ny - 1), z0 = pp_clampi(bz, 0, wd.nz - 1);
   g.wx = bx < 0 ? 0.0f : fx;
