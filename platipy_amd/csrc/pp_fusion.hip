@@ -462,6 +462,51 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
       if (!fmask[((size_t)qz * df.ny + qy) * df.nx + qx]) continue;
     }
     const double fd = msq_trilinear_pairs(F, df.nx, df.ny, df.nz, bf_[0], ff[0], bf_[1], ff[1], bf_[2], ff[2]);
+    if constexpr (CH >= 16) {
+    // Straight-line over the candidates: every candidate forms a valid (clamped) address and gathers unconditionally, and
+    // "inside / masked" only selects what is accumulated -- so a group of four candidates has no branches and the gathers of the
+    // next candidates are in flight while this one is interpolated (a thread's candidates used to be a serial chain of
+    // dependent cache misses).  Adding 0.0 for a rejected candidate leaves the sums bit-identical.
+#pragma unroll
+    for (int j0 = 0; j0 < CH; j0 += 4) {
+    if (j0 < nc) {   // (block-uniform: whole groups of four beyond the batch are skipped; inside a group no branches)
+#pragma unroll
+    for (int j = j0; j < j0 + 4; ++j) {
+      double cm[3];
+      for (int r = 0; r < 3; ++r)
+        cm[r] = a.Am[c0 + j][r * 3 + 0] * v[0] + a.Am[c0 + j][r * 3 + 1] * v[1] + a.Am[c0 + j][r * 3 + 2] * v[2] + a.bm[c0 + j][r];
+      bool ok = (j < nc) & (cm[0] >= -0.5) & (cm[0] < dm.nx - 0.5) & (cm[1] >= -0.5) & (cm[1] < dm.ny - 0.5) & (cm[2] >= -0.5) &
+                (cm[2] < dm.nz - 0.5);
+      int bm_[3];
+      float fm[3];
+      for (int r = 0; r < 3; ++r) {
+        const double cc = ok ? cm[r] : 0.0;
+        const double fl = floor(cc);
+        bm_[r] = (int)fl;
+        fm[r] = (float)(cc - fl);
+      }
+      if (mmask) {   // (uniform)
+        const int qx = ok ? (int)floor(cm[0] + 0.5) : 0, qy = ok ? (int)floor(cm[1] + 0.5) : 0, qz = ok ? (int)floor(cm[2] + 0.5) : 0;
+        ok = ok & (mmask[((size_t)qz * dm.ny + qy) * dm.nx + qx] != 0);
+      }
+      const double md = dm.nx >= 2 ? (double)pp_trilinear_pairs(M, dm.nx, dm.ny, dm.nz, bm_[0], fm[0], bm_[1], fm[1], bm_[2], fm[2])
+                                   : (double)msq_trilinear_pairs(M, dm.nx, dm.ny, dm.nz, bm_[0], fm[0], bm_[1], fm[1], bm_[2], fm[2]);
+      if (MODE == 0) {
+        const double diff = fd - md;
+        acc[j * NV + 0] += ok ? diff * diff : 0.0;
+        acc[j * NV + 1] += ok ? 1.0 : 0.0;
+      } else {
+        acc[j * NV + 0] += ok ? 1.0 : 0.0;
+        acc[j * NV + 1] += ok ? fd : 0.0;
+        acc[j * NV + 2] += ok ? md : 0.0;
+        acc[j * NV + 3] += ok ? fd * fd : 0.0;
+        acc[j * NV + 4] += ok ? md * md : 0.0;
+        acc[j * NV + 5] += ok ? fd * md : 0.0;
+      }
+    }
+    }
+    }
+    } else {   // few candidates per thread: the branchy form measured faster (tools/bench_metric.py)
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       double cm[3];
@@ -489,6 +534,7 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
           acc[j * NV + 5] += fd * md;
         }
       }
+    }
     }
   }
   // one wide tree for all ROW accumulators (8 barrier rounds instead of 8 per triple): red[f][thread]
@@ -943,11 +989,12 @@ int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, con
   a.stride = stride;
   const size_t nsamp = ((size_t)vsize[0] * vsize[1] * vsize[2] + stride - 1) / stride;
   const pp_dims df{fsize[0], fsize[1], fsize[2]}, dm{msize[0], msize[1], msize[2]};
-  // Candidates per thread: 16 on big lattices (HBM/L2-bound: the candidates of a sample share cache lines), 4 on small
-  // ones (latency-bound: a thread's candidates are a serial chain of dependent gathers, so spread them over blocks).
+  // Candidates per thread: 16 on big lattices (HBM/L2-bound: the candidates of a sample share cache lines; the straight-line
+  // form of the kernel keeps several candidates' gathers in flight), 4 for batches of up to four and on small lattices
+  // (latency-bound: spread the candidates over blocks).
   constexpr int CH0 = 16, CH0S = 4, CH1 = 4;
   const bool small = metric == 0 && nsamp < 150000;
-  const int ch = metric == 0 ? (small ? CH0S : CH0) : CH1, nv = metric == 0 ? 2 : 6;
+  const int ch = metric == 0 ? (small || ncand <= 4 ? CH0S : CH0) : CH1, nv = metric == 0 ? 2 : 6;
   const int nchunk = (ncand + ch - 1) / ch;
   const unsigned nb = grid_for(nsamp, 1024u);
   const size_t row = (size_t)ch * nv;
@@ -963,7 +1010,7 @@ int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, con
   rc = pp_mailbox(ctx, &mail, &flags, &seq);
   if (rc) return rc;
   double* hres = reinterpret_cast<double*>(mail);      // 16 x 6 doubles = 768 B of the payload area
-  if (metric == 0 && small)
+  if (metric == 0 && ch == CH0S)
     hipLaunchKernelGGL((k_metric_values<0, CH0S>), dim3(nb, nchunk), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask,
                        moving_mask, a, ncand, partials, ticket, hres, flags, seq);
   else if (metric == 0)
