@@ -562,18 +562,23 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
   __syncthreads();
   if (!is_last) return;
   __threadfence();
+  // Every column of the chunk's rows at once: thread (part, col) adds rows part, part + NPARTS, ... of its column (a
+  // coalesced read per row), then one thread per column adds the NPARTS partial sums in order.  Fixed tree, independent
+  // of the arrival order; one barrier instead of a block-wide tree per three columns.
   const double* rows = partials + (size_t)blockIdx.y * gridDim.x * ROW;
-  for (int k = 0; k < nc * NV; k += 3) {
-    double p = 0.0, q = 0.0, r = 0.0;
-    for (unsigned i = threadIdx.x; i < gridDim.x; i += NT) {
-      p += rows[(size_t)i * ROW + k];
-      if (k + 1 < ROW) q += rows[(size_t)i * ROW + k + 1];
-      if (k + 2 < ROW) r += rows[(size_t)i * ROW + k + 2];
-    }
-    pp_block_sum3<NT>(p, q, r, red);
-    if (threadIdx.x == 0) {
-      const double out[3] = {p, q, r};
-      for (int u = 0; u < 3 && k + u < nc * NV; ++u) result[(c0 + (k + u) / NV) * 6 + (k + u) % NV] = out[u];
+  constexpr int NPARTS = NT / ROW;
+  {
+    const int col = (int)threadIdx.x % ROW, part = (int)threadIdx.x / ROW;
+    double p = 0.0;
+    if (part < NPARTS)
+      for (unsigned i = (unsigned)part; i < gridDim.x; i += NPARTS) p += rows[(size_t)i * ROW + col];
+    __syncthreads();   // (red still holds the block's own tree)
+    if (part < NPARTS) red[part * ROW + col] = p;
+    __syncthreads();
+    if ((int)threadIdx.x < nc * NV) {
+      double tot = 0.0;
+      for (int q = 0; q < NPARTS; ++q) tot += red[q * ROW + threadIdx.x];
+      result[(c0 + (int)threadIdx.x / NV) * 6 + (int)threadIdx.x % NV] = tot;
     }
     __syncthreads();
   }
