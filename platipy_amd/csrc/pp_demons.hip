@@ -838,10 +838,11 @@ int occ_warp2(int sh) {
 }
 template <int R>
 int launch_force2(pp_ctx* ctx, int sh, bool sum, const float* F, const float* Mw_in, const float* D, float* Us, const fused_args& fu,
-                  const pp_esm_consts& K, double* partials, const int* halt) {
+                  const pp_esm_consts& K, double* partials, pp_dev_stats* st, const double* prev, int nprev, double max_rms) {
   pp_prof_scope ps(ctx, "k_fused2_force_smooth");
   const dim3 grid(8u * (unsigned)fu.per_xcd), block(512);
-#define PP_GO(SHV, SUMV, NTV) hipLaunchKernelGGL((PP_A2_KERNEL(SHV, SUMV, NTV)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, halt)
+#define PP_GO(SHV, SUMV, NTV) \
+  hipLaunchKernelGGL((PP_A2_KERNEL(SHV, SUMV, NTV)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, st, prev, nprev, max_rms)
   if (!sum) {   // (PP_FUSED_SUM=0, a measurement path: cached stores only)
     if (sh) PP_GO(1, false, false); else PP_GO(0, false, false);
   } else if (fu.streaming) {
@@ -1095,7 +1096,7 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   small_taps(td[1], rb, &fd.wy);
   small_taps(td[2], rb, &fd.wz);
   const size_t nblk = (size_t)fu.gx * fu.gy * fu.gz;
-  const size_t need = 2 * pp_align_up(N * 4, 256) + 2 * pp_align_up(3 * N * 4, 256) + pp_align_up(3 * nblk * 8, 256) + 256;
+  const size_t need = 2 * pp_align_up(N * 4, 256) + 2 * pp_align_up(3 * N * 4, 256) + 2 * pp_align_up(3 * nblk * 8, 256) + 256;
   rc = pp_reserve(ctx, need);
   if (rc) return rc;
   pp_carver cv{ctx->ws, 0};
@@ -1104,6 +1105,7 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   float* Us = cv.take<float>(3 * N);
   float* D2 = cv.take<float>(3 * N);
   double* partials = cv.take<double>(3 * nblk);
+  double* partials2 = cv.take<double>(3 * nblk);   // generation-2 kernel A alternates: it folds the previous launch's sums itself
   pp_dev_stats* dst = cv.take<pp_dev_stats>(1);
   const int* halt = &dst->halt;
   PP_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(pp_dev_stats), ctx->stream));
@@ -1116,7 +1118,9 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     float* Dnext = (it & 1) ? field : D2;
     // a failed first launch must not be masked by the second one's status
     if (gen_a == 2) {
-#define PP_CALL_A2(RR) launch_force2<RR>(ctx, sh_a, sum_mode, fixed, mw_in, Dcur, Us, fu, K, partials, halt)
+      double* const pcur = (it & 1) ? partials2 : partials;
+      const double* const pprev = (it & 1) ? partials : partials2;
+#define PP_CALL_A2(RR) launch_force2<RR>(ctx, sh_a, sum_mode, fixed, mw_in, Dcur, Us, fu, K, pcur, dst, pprev, it > 0 ? (int)nblk : 0, max_rms)
       rc = PP_BY_RADIUS_A2(ra, PP_CALL_A2);
 #undef PP_CALL_A2
     } else {
@@ -1137,8 +1141,12 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     }
     PP_LAUNCH_CHECK(ctx, "k_fused_add_smooth_warp");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_demons_finalize, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nblk, dst, max_rms);
-    PP_LAUNCH_CHECK(ctx, "k_demons_finalize");
+    // end of the iteration: generation-2 kernel A does it at the start of the next launch, the last iteration's here
+    if (gen_a != 2 || it == p->iterations - 1) {
+      const double* const pfin = (gen_a == 2 && (it & 1)) ? partials2 : partials;
+      hipLaunchKernelGGL(k_demons_finalize, dim3(1), dim3(NT), 0, ctx->stream, pfin, (int)nblk, dst, max_rms);
+      PP_LAUNCH_CHECK(ctx, "k_demons_finalize");
+    }
   }
   hipLaunchKernelGGL(k_copy_if_odd, dim3(grid_for(3 * N)), dim3(NT), 0, ctx->stream, field, (const float*)D2, 3 * N,
                      (const pp_dev_stats*)dst);

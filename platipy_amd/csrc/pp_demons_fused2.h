@@ -760,7 +760,8 @@ template <int R, int SH, bool UNROLL, bool SUM, bool NT>
 __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(const float* __restrict__ F, const float* __restrict__ Mw,
                                                                          const float* __restrict__ D, float* __restrict__ Us,
                                                                          fused_args a, pp_esm_consts K,
-                                                                         double* __restrict__ partials, const int* __restrict__ halt) {
+                                                                         double* __restrict__ partials, pp_dev_stats* __restrict__ st,
+                                                                         const double* __restrict__ prev, int nprev, double max_rms) {
   using G = fused_geom<R, 2, SH>;
   constexpr int NTH = G::NTH, TX = G::TX, TY = G::TY, W = 2 * R + 1;
   constexpr int NXI = (3 * G::XI + NTH - 1) / NTH;
@@ -769,7 +770,41 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
   float2* const s_mf = reinterpret_cast<float2*>(smem);
   float* const s_u = smem + SZ_IMG2;
   float* const s_x = smem + SZ_IMG2 + G::SZ_U;
-  if (halt && *halt) return;
+  if (st->halt) return;   // (written by an earlier launch)
+  // End of the PREVIOUS iteration, folded into this launch instead of a one-block kernel of its own (k_demons_finalize:
+  // 5 us plus a launch gap per iteration, a fifth of an iteration on the coarse pyramid levels): every block adds the
+  // previous launch's per-tile sums in the same fixed order, so all of them reach the same FiniteDifferenceImageFilter::Halt()
+  // decision; block 0 publishes the statistics.  Kernel B of this iteration reads the flag after this launch has completed.
+  if (nprev > 0) {
+    __shared__ int s_halt;
+    double fa = 0.0, fb = 0.0, fc = 0.0;
+    for (int i = threadIdx.x; i < nprev; i += NTH) {
+      fa += prev[3 * (size_t)i + 0];
+      fb += prev[3 * (size_t)i + 1];
+      fc += prev[3 * (size_t)i + 2];
+    }
+    pp_block_sum3_shfl<NTH>(fa, fb, fc, reinterpret_cast<double*>(smem));
+    if (threadIdx.x == 0) {
+      double rms = st->rms;   // (kept when nothing was counted; block 0 then leaves it untouched as well)
+      if (fc > 0.0) rms = sqrt(fb / fc);
+      const int h = max_rms > rms ? 1 : 0;   // Halt(): m_MaximumRMSError > m_RMSChange
+      s_halt = h;
+      if (blockIdx.x == 0) {
+        st->ssd = fa;
+        st->ssc = fb;
+        st->npx = (long long)fc;
+        if (fc > 0.0) {
+          st->metric = fa / fc;
+          st->rms = rms;
+        }
+        st->elapsed += 1;
+        if (h) st->halt = 1;
+      }
+    }
+    __syncthreads();
+    if (s_halt) return;
+    __syncthreads();   // smem is reused below
+  }
   int tx0, ty0, z0;
   unsigned rank;
   if (!fused_tile(a, TX, TY, tx0, ty0, z0, rank)) return;
