@@ -6,8 +6,38 @@
 // arrived the round restarts.  Blocks are independent, so a pool of OS threads executes different
 // blocks in parallel; `__shared__` is `static thread_local`, i.e. private to the OS thread and thus
 // to the block it is currently running.
+//
+// On x86-64 the fibers switch with a dozen instructions (callee-saved registers + stack pointer); glibc's swapcontext
+// makes a signal-mask system call per switch, which dominated the suite once the kernels used wavefront shuffles (two
+// yields each).  Other hosts keep ucontext.
 #include <hip/hip_runtime.h>
 #include <ucontext.h>
+
+#if defined(__x86_64__)
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl hipemu_switch
+    .type hipemu_switch, @function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch, .-hipemu_switch
+)");
+#endif
 
 #include <condition_variable>
 #include <mutex>
@@ -25,7 +55,11 @@ constexpr size_t STACK_BYTES = 256 * 1024;
 struct Worker {
   std::vector<Fiber> fibers;
   std::vector<char*> stacks;
+#if defined(__x86_64__)
+  void* sched_sp = nullptr;
+#else
   ucontext_t sched;
+#endif
   const std::function<void()>* body = nullptr;
 };
 
@@ -35,7 +69,12 @@ void fiber_entry() {
   Fiber* f = t_current;
   (*t_worker->body)();
   f->done = true;
+#if defined(__x86_64__)
+  hipemu_switch(&f->sp, t_worker->sched_sp);   // never resumed
+  __builtin_trap();
+#else
   swapcontext(&f->ctx, &t_worker->sched);
+#endif
 }
 
 void run_block(Worker& w, dim3 grid, dim3 block, unsigned long b, const std::function<void()>& body) {
@@ -50,11 +89,22 @@ void run_block(Worker& w, dim3 grid, dim3 block, unsigned long b, const std::fun
     f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
     f.bid = bidx;
     f.done = false;
+#if defined(__x86_64__)
+    // initial frame: six zeroed callee-saved registers, then the entry point as hipemu_switch's return address, then a
+    // null "return address" of the entry point itself (it never returns), so that it starts with rsp = 16 n + 8 as the
+    // ABI has it at any function entry.
+    void** sp = reinterpret_cast<void**>(reinterpret_cast<uintptr_t>(w.stacks[t] + STACK_BYTES) & ~(uintptr_t)15);
+    *--sp = nullptr;
+    *--sp = reinterpret_cast<void*>(&fiber_entry);
+    for (int k = 0; k < 6; ++k) *--sp = nullptr;
+    f.sp = sp;
+#else
     getcontext(&f.ctx);
     f.ctx.uc_stack.ss_sp = w.stacks[t];
     f.ctx.uc_stack.ss_size = STACK_BYTES;
     f.ctx.uc_link = &w.sched;
     makecontext(&f.ctx, fiber_entry, 0);
+#endif
   }
   unsigned live = n;
   while (live) {
@@ -63,7 +113,11 @@ void run_block(Worker& w, dim3 grid, dim3 block, unsigned long b, const std::fun
       Fiber& f = w.fibers[t];
       if (f.done) continue;
       t_current = &f;
+#if defined(__x86_64__)
+      hipemu_switch(&w.sched_sp, f.sp);
+#else
       swapcontext(&w.sched, &f.ctx);
+#endif
       if (f.done) --live;
     }
   }
@@ -74,7 +128,11 @@ void run_block(Worker& w, dim3 grid, dim3 block, unsigned long b, const std::fun
 
 void fiber_yield() {
   Fiber* f = t_current;
+#if defined(__x86_64__)
+  hipemu_switch(&f->sp, t_worker->sched_sp);
+#else
   swapcontext(&f->ctx, &t_worker->sched);
+#endif
 }
 
 void launch(dim3 grid, dim3 block, const std::function<void()>& body) {

@@ -48,7 +48,11 @@ static inline uchar4 make_uchar4(unsigned char a, unsigned char b, unsigned char
 
 namespace hipemu {
 struct Fiber {
+#if defined(__x86_64__)
+  void* sp = nullptr;   // saved stack pointer (hand-written context switch: no signal-mask system call per yield)
+#else
   ucontext_t ctx;
+#endif
   dim3 tid, bid;
   bool done = false;
 };
