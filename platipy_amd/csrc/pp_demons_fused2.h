@@ -124,18 +124,10 @@ __device__ __forceinline__ void pp_block_sum3_shfl(double& a, double& b, double&
 struct pp_f4u {
   float x, y, z, w;
 } __attribute__((aligned(4)));
-#ifdef PP_NT_LOADS   // measurement builds: streaming hint on the strip loads
-typedef float pp_v4u __attribute__((vector_size(16), aligned(4)));
-__device__ __forceinline__ float4 pp_gld4(const char* base, unsigned byte_off) {
-  const pp_v4u v = __builtin_nontemporal_load(reinterpret_cast<const pp_v4u*>(base + (size_t)byte_off));
-  return make_float4(v[0], v[1], v[2], v[3]);
-}
-#else
 __device__ __forceinline__ float4 pp_gld4(const char* base, unsigned byte_off) {
   const pp_f4u v = *reinterpret_cast<const pp_f4u*>(base + (size_t)byte_off);
   return make_float4(v.x, v.y, v.z, v.w);
 }
-#endif
 
 // Strip geometry of the generation-2 kernels.  The smoothing-input tile is fetched and published as STRIPS of four
 // consecutive x voxels (one 16-byte load / LDS store per strip and array instead of four 4-byte ones): the tile's x
@@ -973,12 +965,10 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     prefetch(zc0);
     __syncthreads();
     esm(zc0);
-#ifndef PP_A_PREFETCH_TOP
     {   // step 0's image loads (see the end of the plane step)
       const int n1 = pp_clampi(zs + 1, 0, d.nz - 1);
       if (nsteps > 1 && n1 != zc0) prefetch(n1);
     }
-#endif
     if constexpr (SUM) load_dsum(zs - R);
     __syncthreads();
   }
@@ -994,9 +984,6 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     const bool emit = (zo >= z0) && (zo <= zo_last) && out_ok;
     // ---- interval 1: x pass of plane `cur` (s_u -> s_x) | publish the image tile of plane `nxt` ----
     if (fresh_next) publish();
-#ifdef PP_A_PREFETCH_TOP
-    if (fresh_next) prefetch(nxt);
-#endif
     if (fresh_cur) fused2_xpass<R, NXI, 3 * G::XI>(s_u, s_x, a.wx, xsrc, xdst);
     if (fresh_cur || fresh_next) __syncthreads();
     // ---- interval 2: y pass of plane `cur` (s_x -> registers) | ESM update of plane `nxt` (s_mf -> s_u) ----
@@ -1027,12 +1014,10 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     }
     // The next step's loads go in flight here, behind this step's stores, so that no wait of this step has them
     // pending: the image planes are consumed by the next ESM pass, D (SUM) by the next stores.
-#ifndef PP_A_PREFETCH_TOP
     {
       const int nxt2 = pp_clampi(zi + 2, 0, d.nz - 1);
       if ((n + 2 < nsteps) && (nxt2 != nxt)) prefetch(nxt2);
     }
-#endif
     if constexpr (SUM) load_dsum(zo + 1);
     if (fresh_cur || fresh_next) __syncthreads();
   };
