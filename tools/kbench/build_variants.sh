@@ -19,4 +19,5 @@ while [ $# -ge 2 ]; do
 done
 wait
 /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o tools/kbench/kbench tools/kbench/kbench.cpp -ldl 2>&1 | grep -v hip-link || true
+/opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o tools/kbench/sbench tools/kbench/sbench.cpp -ldl 2>&1 | grep -v hip-link || true
 ls -la tools/kbench/variants
