@@ -356,6 +356,24 @@ def test_fused_demons_generations_agree(backend, grid, tile, monkeypatch):
     assert np.abs(out["2"][0]).max() > 0.1
 
 
+def test_fused_demons_store_policy_does_not_change_the_field(backend, monkeypatch):
+    """Generation 2 stores its outputs with a non-temporal hint on volumes far beyond the infinity cache (a template
+    parameter chosen per launch); forcing either policy on a small grid gives the same bits, statistics included."""
+    shape, spacing, origin = GRIDS[0]
+    fix = phantom(shape, seed=40)
+    dv = random_dvf(shape, spacing, seed=41, max_mm=2.5)
+    mov = O.warp_image(O.Vol(fix, spacing, origin), dv.astype(np.float64), edge_value=-1000.0).arr.astype(np.float32)
+    p = _demons_params(backend.ctx, 3, spacing, _lib.DEMONS_FUSED, max_rms=0.0)
+    out = {}
+    for nt in ("0", "1"):
+        monkeypatch.setenv("PP_FUSED_NT", nt)
+        f = backend.empty((3,) + shape)
+        st = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, f)
+        out[nt] = (backend.host(f).copy(), st.metric, st.rms_change, st.n_pixels, st.elapsed_iterations)
+    np.testing.assert_array_equal(out["0"][0], out["1"][0])
+    assert out["0"][1:] == out["1"][1:]
+
+
 @pytest.mark.parametrize("zchunk", [1, 2, 3, 5, 100])
 def test_fused_demons_is_independent_of_the_z_chunking(backend, zchunk, monkeypatch):
     """The fused schedule splits z into chunks (halo planes recomputed at the seams); any chunk length, shorter
