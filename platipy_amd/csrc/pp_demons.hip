@@ -122,6 +122,63 @@ __global__ void __launch_bounds__(NT) k_demons_force(const float* __restrict__ F
   }
 }
 
+// The same update, four consecutive x voxels per thread (rows 16-byte aligned: nx % 4 == 0): the centre row and its four
+// y / z neighbour rows arrive as one 16-byte load each, the two x neighbours beyond the quad as scalars -- 14 loads for
+// four voxels instead of 56.  Same operations per voxel, so U is bit-identical; the partial sums group differently.
+__global__ void __launch_bounds__(NT) k_demons_force4(const float* __restrict__ F, const float* __restrict__ Mw,
+                                                      float* __restrict__ U, pp_dims d, pp_esm_consts K,
+                                                      double* __restrict__ partials, const int* __restrict__ halt) {
+  __shared__ double red[3 * NT];
+  if (halt && *halt) return;
+  const size_t N = (size_t)d.nx * d.ny * d.nz;
+  const size_t sy = d.nx, sz = (size_t)d.nx * d.ny;
+  const size_t nxq = (size_t)d.nx / 4, NQ = N / 4;
+  double a_ssd = 0.0, a_ssc = 0.0, a_n = 0.0;
+  for (size_t q = (size_t)blockIdx.x * NT + threadIdx.x; q < NQ; q += (size_t)gridDim.x * NT) {
+    const int x = (int)(q % nxq) * 4;
+    const int y = (int)((q / nxq) % d.ny);
+    const int z = (int)(q / (nxq * d.ny));
+    const size_t i = ((size_t)z * d.ny + y) * d.nx + x;
+    const size_t ym = y > 0 ? i - sy : i, yp = y < d.ny - 1 ? i + sy : i;
+    const size_t zm = z > 0 ? i - sz : i, zp = z < d.nz - 1 ? i + sz : i;
+    const float4 fc4 = *reinterpret_cast<const float4*>(F + i), mc4 = *reinterpret_cast<const float4*>(Mw + i);
+    const float4 fym4 = *reinterpret_cast<const float4*>(F + ym), fyp4 = *reinterpret_cast<const float4*>(F + yp);
+    const float4 fzm4 = *reinterpret_cast<const float4*>(F + zm), fzp4 = *reinterpret_cast<const float4*>(F + zp);
+    const float4 mym4 = *reinterpret_cast<const float4*>(Mw + ym), myp4 = *reinterpret_cast<const float4*>(Mw + yp);
+    const float4 mzm4 = *reinterpret_cast<const float4*>(Mw + zm), mzp4 = *reinterpret_cast<const float4*>(Mw + zp);
+    const size_t ixm = x > 0 ? i - 1 : i, ixp = x + 4 < d.nx ? i + 4 : i + 3;
+    const float fxm = F[ixm], fxp = F[ixp], mxm = Mw[ixm], mxp = Mw[ixp];
+    const float fc[6] = {fxm, fc4.x, fc4.y, fc4.z, fc4.w, fxp}, mc[6] = {mxm, mc4.x, mc4.y, mc4.z, mc4.w, mxp};
+    const float fym[4] = {fym4.x, fym4.y, fym4.z, fym4.w}, fyp[4] = {fyp4.x, fyp4.y, fyp4.z, fyp4.w};
+    const float fzm[4] = {fzm4.x, fzm4.y, fzm4.z, fzm4.w}, fzp[4] = {fzp4.x, fzp4.y, fzp4.z, fzp4.w};
+    const float mym[4] = {mym4.x, mym4.y, mym4.z, mym4.w}, myp[4] = {myp4.x, myp4.y, myp4.z, myp4.w};
+    const float mzm[4] = {mzm4.x, mzm4.y, mzm4.z, mzm4.w}, mzp[4] = {mzp4.x, mzp4.y, mzp4.z, mzp4.w};
+    float ux[4], uy[4], uz[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float gx = pp_esm_axis(fc[v], fc[v + 2], mc[v + 1], mc[v], mc[v + 2], x + v == 0, x + v == d.nx - 1, K.ix);
+      const float gy = pp_esm_axis(fym[v], fyp[v], mc[v + 1], mym[v], myp[v], y == 0, y == d.ny - 1, K.iy);
+      const float gz = pp_esm_axis(fzm[v], fzp[v], mc[v + 1], mzm[v], mzp[v], z == 0, z == d.nz - 1, K.iz);
+      const pp_esm_out o = pp_esm_voxel(K, fc[v + 1], mc[v + 1], gx, gy, gz);
+      ux[v] = o.ux;
+      uy[v] = o.uy;
+      uz[v] = o.uz;
+      a_ssd += (double)o.sq_speed;
+      a_ssc += (double)o.sq_update;
+      a_n += (double)o.counted;
+    }
+    *reinterpret_cast<float4*>(U + i) = make_float4(ux[0], ux[1], ux[2], ux[3]);
+    *reinterpret_cast<float4*>(U + N + i) = make_float4(uy[0], uy[1], uy[2], uy[3]);
+    *reinterpret_cast<float4*>(U + 2 * N + i) = make_float4(uz[0], uz[1], uz[2], uz[3]);
+  }
+  pp_block_sum3<NT>(a_ssd, a_ssc, a_n, red);
+  if (threadIdx.x == 0) {
+    partials[3 * (size_t)blockIdx.x + 0] = a_ssd;
+    partials[3 * (size_t)blockIdx.x + 1] = a_ssc;
+    partials[3 * (size_t)blockIdx.x + 2] = a_n;
+  }
+}
+
 // End of an iteration: fold the per-block partial sums (fixed order -> deterministic), publish
 // metric / RMS change, count the iteration and apply FiniteDifferenceImageFilter::Halt().
 __global__ void __launch_bounds__(NT) k_demons_finalize(const double* __restrict__ partials, int nblocks,
@@ -159,6 +216,13 @@ __global__ void __launch_bounds__(NT) k_copy_if_odd(float* __restrict__ dst, con
                                                     const pp_dev_stats* __restrict__ st) {
   if ((st->elapsed & 1) == 0) return;
   for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) dst[i] = alt[i];
+}
+
+// k_demons_force4's precondition: whole 16-byte quads per row, 16-byte aligned volumes
+bool force_vec4(const pp_dims& d, const float* f, const float* m, const float* u) {
+  const size_t N = (size_t)d.nx * d.ny * d.nz;
+  return d.nx % 4 == 0 && N % 4 == 0 &&
+         ((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(u)) % 16 == 0);
 }
 
 unsigned grid_for(size_t work, unsigned cap = 65535u * 4u) {
@@ -931,7 +995,10 @@ int pp_demons_force_f32(pp_ctx* ctx, const float* fixed, const float* warped, co
   pp_esm_consts K;
   esm_consts(g, p, &K);
   PP_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(pp_dev_stats), ctx->stream));
-  hipLaunchKernelGGL(k_demons_force, dim3(nb), dim3(NT), 0, ctx->stream, fixed, warped, update, d, K, partials, (const int*)nullptr);
+  if (force_vec4(d, fixed, warped, update))
+    hipLaunchKernelGGL(k_demons_force4, dim3(nb), dim3(NT), 0, ctx->stream, fixed, warped, update, d, K, partials, (const int*)nullptr);
+  else
+    hipLaunchKernelGGL(k_demons_force, dim3(nb), dim3(NT), 0, ctx->stream, fixed, warped, update, d, K, partials, (const int*)nullptr);
   PP_LAUNCH_CHECK(ctx, "k_demons_force");
   hipLaunchKernelGGL(k_demons_finalize, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, dst, -1.0);
   PP_LAUNCH_CHECK(ctx, "k_demons_finalize");
@@ -1000,7 +1067,10 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
       if (rc) return rc;
       {
         pp_prof_scope ps(ctx, "k_demons_force");
-        hipLaunchKernelGGL(k_demons_force, dim3(nb), dim3(NT), 0, ctx->stream, fixed, (const float*)Mw, U, d, K, partials, halt);
+        if (force_vec4(d, fixed, Mw, U))
+          hipLaunchKernelGGL(k_demons_force4, dim3(nb), dim3(NT), 0, ctx->stream, fixed, (const float*)Mw, U, d, K, partials, halt);
+        else
+          hipLaunchKernelGGL(k_demons_force, dim3(nb), dim3(NT), 0, ctx->stream, fixed, (const float*)Mw, U, d, K, partials, halt);
       }
       PP_LAUNCH_CHECK(ctx, "k_demons_force");
       if (p->smooth_update) {
