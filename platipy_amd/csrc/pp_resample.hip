@@ -14,6 +14,7 @@
 //    contraction off, so nearest-neighbour decisions match the fp64 restatement bit for bit.
 #include "pp_internal.h"
 #include "pp_kernels.h"
+#include "pp_warp_sample.h"
 
 namespace {
 
@@ -35,6 +36,47 @@ pp_grid3 grid3_for(int nxv, int ny, int nz) {
 
 // ---------------------------------------------------------------------------------------
 // same-grid warp
+
+// Straight-line version (pp_warp_sample.h): no branch per sample, 32-bit offsets, and the 4 x VEC corner loads of a thread
+// are all issued before the first interpolation.  Same arithmetic as k_warp_same_grid below, which stays for volumes
+// outside the helper's preconditions.
+template <int VEC>
+__global__ void __launch_bounds__(NT) k_warp_same_grid_sl(const float* __restrict__ moving, const float* __restrict__ field,
+                                                          float* __restrict__ out, pp_dims d, pp_warp_scale sc, float edge,
+                                                          const int* __restrict__ halt) {
+  if (halt && *halt) return;
+  const int nxv = d.nx / VEC;
+  const size_t N = (size_t)d.nx * d.ny * d.nz;
+  const int xv = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z;
+  if (xv < nxv && y < d.ny) {
+    const int x0 = xv * VEC;
+    const size_t i = ((size_t)z * d.ny + y) * d.nx + x0;
+    float dx[VEC], dy[VEC], dz[VEC], res[VEC];
+    if (VEC == 4) {
+      const float4 a = *reinterpret_cast<const float4*>(field + i);
+      const float4 b = *reinterpret_cast<const float4*>(field + N + i);
+      const float4 c = *reinterpret_cast<const float4*>(field + 2 * N + i);
+      dx[0] = a.x; dx[1] = a.y; dx[2] = a.z; dx[3] = a.w;
+      dy[0] = b.x; dy[1] = b.y; dy[2] = b.z; dy[3] = b.w;
+      dz[0] = c.x; dz[1] = c.y; dz[2] = c.z; dz[3] = c.w;
+    } else {
+      dx[0] = field[i];
+      dy[0] = field[N + i];
+      dz[0] = field[2 * N + i];
+    }
+    const pp_warp_dims wd{d.nx, d.ny, d.nz, (unsigned)d.nx * 4u, (unsigned)d.nx * (unsigned)d.ny * 4u};
+    const char* const rm = reinterpret_cast<const char*>(moving);
+    pp_warp_pending g[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) fused2_warp_issue(rm, wd, x0 + v, dx[v] * sc.ix, y, dy[v] * sc.iy, z, dz[v] * sc.iz, true, g[v]);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) res[v] = fused2_warp_finish_edge(g[v], edge);
+    if (VEC == 4)
+      *reinterpret_cast<float4*>(out + i) = make_float4(res[0], res[1], res[2], res[3]);
+    else
+      out[i] = res[0];
+  }
+}
 
 template <int VEC>
 __global__ void __launch_bounds__(NT) k_warp_same_grid(const float* __restrict__ moving, const float* __restrict__ field,
@@ -420,12 +462,21 @@ int pp_warp_same_grid(pp_ctx* ctx, const float* moving, const float* field, cons
                       float edge_value, float* out, const int* halt_flag) {
   const size_t N = (size_t)d.nx * d.ny * d.nz;
   const bool vec4 = (d.nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(field) | reinterpret_cast<uintptr_t>(out)) % 16 == 0) && (N % 4 == 0);
+  // preconditions of the straight-line sample (pp_warp_sample.h)
+  const bool sl = N * sizeof(float) < ((size_t)1 << 32) && (size_t)d.ny * d.nz < ((size_t)1 << 24) && d.nx >= 2 && d.nx < (1 << 22) &&
+                  d.ny < (1 << 22) && d.nz < (1 << 22) && getenv("PP_WARP_LEGACY") == nullptr;
   if (vec4) {
     const pp_grid3 g3 = grid3_for(d.nx / 4, d.ny, d.nz);
-    hipLaunchKernelGGL((k_warp_same_grid<4>), g3.grid, g3.block, 0, ctx->stream, moving, field, out, d, sc, edge_value, halt_flag);
+    if (sl)
+      hipLaunchKernelGGL((k_warp_same_grid_sl<4>), g3.grid, g3.block, 0, ctx->stream, moving, field, out, d, sc, edge_value, halt_flag);
+    else
+      hipLaunchKernelGGL((k_warp_same_grid<4>), g3.grid, g3.block, 0, ctx->stream, moving, field, out, d, sc, edge_value, halt_flag);
   } else {
     const pp_grid3 g3 = grid3_for(d.nx, d.ny, d.nz);
-    hipLaunchKernelGGL((k_warp_same_grid<1>), g3.grid, g3.block, 0, ctx->stream, moving, field, out, d, sc, edge_value, halt_flag);
+    if (sl)
+      hipLaunchKernelGGL((k_warp_same_grid_sl<1>), g3.grid, g3.block, 0, ctx->stream, moving, field, out, d, sc, edge_value, halt_flag);
+    else
+      hipLaunchKernelGGL((k_warp_same_grid<1>), g3.grid, g3.block, 0, ctx->stream, moving, field, out, d, sc, edge_value, halt_flag);
   }
   PP_LAUNCH_CHECK(ctx, "k_warp_same_grid");
   return PP_OK;
