@@ -161,3 +161,18 @@ def sphere_case(i, shape=(30, 64, 64)):
     sub = (zz - (nz // 2 + i)) ** 2 + (yy - (ny // 2 - 2 + i)) ** 2 + (xx - (nx // 2 - 2)) ** 2 <= (nx * 5 // 128 + 1) ** 2
     ct = np.where(m, 1.0, -1000.0).astype(np.float32)
     return ct, m.astype(np.uint8), sub.astype(np.uint8), (0.9 + i * 0.01, 0.9 + i * 0.01, 2.5 + i * 0.01)
+
+
+def record_stats(name, stats):
+    """Keep a test's MEASURED error statistics: one JSON per test under
+    $PP_STATS_DIR (default gpurun_out/parity_stats/, which gpurun merges back); the builder commits the collected
+    file under profiles/.  Never fails a test."""
+    import json
+
+    d = os.environ.get("PP_STATS_DIR", os.path.join(ROOT, "gpurun_out", "parity_stats"))
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name + ".json"), "w") as fh:
+            json.dump(stats, fh, indent=1, sort_keys=True, default=float)
+    except OSError:
+        pass

@@ -154,12 +154,18 @@ def _ref_vol(size, spacing, origin, direction):
 
 
 def Resample(image, *args):
-    """The three call shapes the reference's loop uses: (image, reference_image), (image, transform[, interpolator]) and
+    """The call shapes the reference uses: (image, reference_image[, transform, interpolator, default]), (image, transform[, interpolator]) and
     (image, size, transform, interpolator, origin, spacing, direction, default_value, pixel_id)."""
     transform, interp, default = None, sitkLinear, 0.0
-    if len(args) >= 1 and isinstance(args[0], Image):
+    if len(args) >= 1 and isinstance(args[0], Image):      # (image, reference_image[, transform[, interpolator[, default]]])
         ref = _ref_vol(args[0].GetSize(), args[0].GetSpacing(), args[0].GetOrigin(), args[0].GetDirection())
         ref_img = args[0]
+        if len(args) > 1:
+            transform = args[1]
+        if len(args) > 2:
+            interp = args[2]
+        if len(args) > 3:
+            default = args[3]
     elif len(args) >= 1 and isinstance(args[0], Transform):
         transform = args[0]
         interp = args[1] if len(args) > 1 else sitkLinear
@@ -198,3 +204,62 @@ def SmoothingRecursiveGaussian(image, sigma):
         out = _O.recursive_gaussian_vec(_O.Vol(_vol(image).arr.astype(np.float64), image.GetSpacing(), image.GetOrigin(), image.GetDirection()), sig)
         return _like(np.ascontiguousarray(np.moveaxis(out.arr, 0, -1)), image, True)
     return _like(_O.recursive_gaussian(_vol(image), sig).arr, image, False)
+
+
+def Version_VersionString():
+    return __version__
+
+
+class Version:
+    VersionString = staticmethod(Version_VersionString)
+
+
+class FastSymmetricForcesDemonsRegistrationFilter:
+    """The filter protocol of deformable.py:244-257,149 on the oracle's restatement (SimpleITK 2.3.1 defaults)."""
+
+    def __init__(self):
+        self._f = _O.DemonsFilter()
+
+    def SetNumberOfIterations(self, n):
+        self._f.SetNumberOfIterations(n)
+
+    def SetStandardDeviations(self, s):
+        self._f.SetStandardDeviations(s)
+
+    def GetStandardDeviations(self):
+        return self._f.GetStandardDeviations()
+
+    def SetSmoothUpdateField(self, b):
+        self._f.SetSmoothUpdateField(b)
+
+    def SetSmoothDisplacementField(self, b):
+        self._f.SetSmoothDisplacementField(b)
+
+    def SetMaximumRMSError(self, v):
+        self._f.SetMaximumRMSError(v)
+
+    def SetNumberOfThreads(self, n):
+        pass
+
+    def GetElapsedIterations(self):
+        return self._f.GetElapsedIterations()
+
+    def GetMetric(self):
+        return self._f.GetMetric()
+
+    def GetRMSChange(self):
+        return self._f.GetRMSChange()
+
+    def Execute(self, fixed, moving):
+        out = self._f.Execute(_vol(fixed), _vol(moving))
+        return _like(np.ascontiguousarray(np.moveaxis(out.arr, 0, -1)).astype(np.float64), fixed, True)
+
+
+def SignedMaurerDistanceMap(image, insideIsPositive=False, squaredDistance=True, useImageSpacing=False):
+    if squaredDistance or not useImageSpacing:
+        raise TypeError("test double: only squaredDistance=False, useImageSpacing=True (the reference's call, projection.py:80-82)")
+    return _like(_O.maurer_distance_map(_vol(image), signed=True, inside_positive=bool(insideIsPositive)).arr.astype(np.float32), image, False)
+
+
+def LabelContour(image, fullyConnected=False, backgroundValue=0):
+    return _like(_O.label_contour(_vol(image)).arr.astype(image._a.dtype), image, False)

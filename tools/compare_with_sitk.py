@@ -7,6 +7,10 @@ exactly as platipy does (registration/deformable.py:244-257,149; registration/ut
 label/fusion.py:163-169), and reports max / RMS differences against oracle/ (and platipy_amd if a GPU is
 present).  It needs none of platipy's own files.  If SimpleITK is missing it says so and exits non-zero --
 it never passes silently.
+
+  python tools/compare_with_sitk.py                                   # report differences, stage by stage
+  python tools/compare_with_sitk.py --emit tests/golden/sitk_2.3.1.npz  # write the reference vectors (tools/sitk_vectors.py);
+                                                                        # tests/test_golden.py picks the file up
 """
 import os
 import sys
@@ -151,4 +155,12 @@ def main():
 
 
 if __name__ == "__main__":
+    if "--emit" in sys.argv:      # tools/compare_with_sitk.py --emit tests/golden/sitk_<version>.npz : the one-command hand-off
+        from tools import sitk_vectors
+
+        dest = sys.argv[sys.argv.index("--emit") + 1]
+        sitk_vectors.emit(sitk, dest)
+        print(f"wrote {dest} (SimpleITK {sitk.Version.VersionString()}); commit it: tests/test_golden.py then holds the oracle "
+              "and the product to it")
+        sys.exit(0)
     sys.exit(main())

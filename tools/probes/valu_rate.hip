@@ -1,0 +1,133 @@
+// tools/probes/valu_rate.hip -- measured issue rates of the instruction classes the fused demons kernels are made of
+// (measurement tooling).  Each kernel runs ITER iterations of 16 independent dependency chains of one instruction in
+// every lane, 512-thread blocks, `bpc` blocks per CU (4 waves per SIMD at bpc = 2), and reports wave-instructions per
+// cycle per SIMD at the measured wall time and the clock read from the device properties.
+//   hipcc -O3 --offload-arch=gfx950 -o valu_rate valu_rate.hip && ./valu_rate
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
+constexpr int ITER = 4096;
+
+template <int KIND>
+__global__ void __launch_bounds__(512) k_rate(float* out, float a, float b) {
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = a * (float)(threadIdx.x + i);
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 p[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = f2{v[2 * i], v[2 * i + 1]};
+  const f2 pa = f2{a, a}, pb = f2{b, b};
+  for (int it = 0; it < ITER; ++it) {
+    if constexpr (KIND == 0) {   // v_fma_f32
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
+    } else if constexpr (KIND == 1) {   // v_pk_fma_f32 (two fmas per lane)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pa), "v"(pb));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pa), "v"(pb));
+    } else if constexpr (KIND == 2) {   // v_cndmask_b32 with vcc
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(a) : "vcc");
+    } else if constexpr (KIND == 3) {   // DPP move (wave_shr:1)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v[i]));
+    } else if constexpr (KIND == 4) {   // v_mul_f32
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+    } else if constexpr (KIND == 5) {   // v_pk_mul_f32
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pa));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pa));
+    } else if constexpr (KIND == 6) {   // v_cmp_neq_f32 to an SGPR pair + v_cndmask from it (the select idiom)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        asm volatile("v_cmp_neq_f32 s[20:21], %0, %1\n\tv_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(v[i]) : "v"(a) : "s20", "s21");
+    } else if constexpr (KIND == 7) {   // v_rcp_f32 (transcendental)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_rcp_f32 %0, %0" : "+v"(v[i]));
+    } else if constexpr (KIND == 8) {   // 1 dependent chain only (latency): 16 dependent fmas
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[0]) : "v"(a), "v"(b));
+    } else if constexpr (KIND == 9) {   // s_and_b64 (SALU) interleaved 1:1 with v_fma
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_and_b64 s[20:21], s[20:21], exec" : "+v"(v[i]) : "v"(a), "v"(b) : "s20", "s21");
+    } else if constexpr (KIND == 10) {  // v_pk_add_f32
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pa));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pa));
+    } else if constexpr (KIND == 11) {  // v_med3_f32 / v_max_f32 class
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+    } else if constexpr (KIND == 12) {  // v_cvt_i32_f32 + v_floor
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_floor_f32 %0, %0" : "+v"(v[i]));
+    } else if constexpr (KIND == 13) {  // integer v_add_u32
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+    } else if constexpr (KIND == 14) {  // v_mul_u32_u24
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+    }
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += v[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += p[i].x + p[i].y;
+  if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+template <int KIND>
+void run(const char* name, int n_per_iter, int cus, double ghz, float* out) {
+  for (int bpc = 1; bpc <= 4; bpc *= 2) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_rate<KIND>, dim3(cus * bpc), dim3(512), 0, 0, out, 1.0001f, 0.5f);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_rate<KIND>, dim3(cus * bpc), dim3(512), 0, 0, out, 1.0001f, 0.5f);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    // wave-instructions per SIMD: blocks per CU * 8 waves / 4 SIMDs * ITER * n_per_iter
+    const double wi = (double)bpc * 2.0 * ITER * n_per_iter;
+    const double cyc = ms * 1e-3 * ghz * 1e9;
+    printf("%-28s waves/SIMD %d : %.3f ms  -> %.2f cycles per wave-instruction per SIMD (at %.2f GHz)\n", name, bpc * 2, ms, cyc / wi, ghz);
+  }
+}
+
+int main() {
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  const double ghz = prop.clockRate * 1e-6;
+  printf("device %s, %d CUs, clockRate %.3f GHz\n", prop.name, cus, ghz);
+  float* out;
+  CK(hipMalloc(&out, 4096));
+  run<0>("v_fma_f32", 16, cus, ghz, out);
+  run<1>("v_pk_fma_f32", 16, cus, ghz, out);
+  run<4>("v_mul_f32", 16, cus, ghz, out);
+  run<5>("v_pk_mul_f32", 16, cus, ghz, out);
+  run<10>("v_pk_add_f32", 16, cus, ghz, out);
+  run<2>("v_cndmask_b32 (vcc)", 16, cus, ghz, out);
+  run<6>("v_cmp + v_cndmask (sgpr)", 16, cus, ghz, out);
+  run<3>("v_mov_b32_dpp wave_shr:1", 16, cus, ghz, out);
+  run<7>("v_rcp_f32", 16, cus, ghz, out);
+  run<11>("v_max_f32", 16, cus, ghz, out);
+  run<12>("v_floor_f32", 16, cus, ghz, out);
+  run<13>("v_add_u32", 16, cus, ghz, out);
+  run<14>("v_mul_u32_u24", 16, cus, ghz, out);
+  run<8>("v_fma_f32 dependent chain", 16, cus, ghz, out);
+  run<9>("v_fma_f32 + s_and_b64", 32, cus, ghz, out);
+  return 0;
+}
