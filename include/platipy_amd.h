@@ -180,6 +180,13 @@ int pp_demons_force_f32(pp_ctx* ctx, const float* fixed, const float* warped, co
  * loop on device, field starting from zero.  stats may be NULL (then fully asynchronous). */
 int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, const pp_geom* g,
                           const pp_demons_params* p, float* field, pp_demons_stats* stats);
+/* What an sitkIterationEvent observer of the filter reads after every iteration -- registration_method.AddCommand(
+ * sitk.sitkIterationEvent, ...) printing GetElapsedIterations() / GetMetric() (deformable.py:260-264,
+ * registration/utils.py:36-41).  The loop runs on the device without host round trips, so the per-iteration values are kept
+ * in a device ring by the kernel that closes each iteration and read back here: entry k = GetMetric() / GetRMSChange() after
+ * iteration k + 1 of the LAST pp_demons_execute_f32 on this ctx.  Returns the number of iterations that ran (entries written:
+ * min(that, cap)), or a negative pp_status.  Synchronises the stream. */
+int pp_demons_history(pp_ctx* ctx, double* metric, double* rms_change, int cap);
 
 /* ---- label fusion ------------------------------------------------------------------ */
 /* compute_weight_map(vote_type="local") (label/fusion.py:148-169):

@@ -121,6 +121,7 @@ _SIGNATURES = {
     "pp_transform_to_field_f32": (C.c_int, [_P, C.POINTER(Geom), C.POINTER(C.c_double), C.POINTER(C.c_double), _P, _P]),
     "pp_demons_force_f32": (C.c_int, [_P, _P, _P, C.POINTER(Geom), C.POINTER(DemonsParams), _P, C.POINTER(DemonsStats)]),
     "pp_demons_execute_f32": (C.c_int, [_P, _P, _P, C.POINTER(Geom), C.POINTER(DemonsParams), _P, C.POINTER(DemonsStats)]),
+    "pp_demons_history": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "pp_weight_map_local_f32": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_double, C.c_double, _P]),
     "pp_weight_map_block_f32": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_double, C.c_double, _P]),
     "pp_sum_sq_diff_f32": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_double)]),
@@ -350,6 +351,14 @@ class Context:
         self._chk(self.lib.pp_demons_execute_f32(self.h, ptr(fixed), ptr(moving), C.byref(geom), C.byref(params), ptr(field),
                                                  C.byref(st) if want_stats else None), "pp_demons_execute_f32")
         return st if want_stats else None
+
+    def demons_history(self, cap=4096):
+        """-> [(metric, rms_change)] per iteration of the last demons_execute on this context (an sitkIterationEvent
+        observer's view of the filter, deformable.py:260-264)."""
+        m, r = (C.c_double * cap)(), (C.c_double * cap)()
+        n = self.lib.pp_demons_history(self.h, m, r, cap)
+        self._chk(n if n < 0 else 0, "pp_demons_history")
+        return [(m[k], r[k]) for k in range(min(n, cap))]
 
     # -- fusion ---------------------------------------------------------------------
     def weight_map_local(self, target, moving, size, spacing, sigma, epsilon, out):

@@ -156,6 +156,20 @@ int pp_ticket(pp_ctx* ctx, unsigned** out) {
   return PP_OK;
 }
 
+int pp_history_buffer(pp_ctx* ctx, double** out) {
+  if (!ctx->hist) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 2 * sizeof(double) * ((size_t)PP_HIST_CAP + 1)) != hipSuccess || !p) {
+      (void)hipGetLastError();
+      return pp_fail(ctx, PP_ERR_ALLOC, "iteration-history buffer allocation failed");
+    }
+    ctx->hist = static_cast<double*>(p);
+    ctx->hist_cap = PP_HIST_CAP;
+  }
+  *out = ctx->hist;
+  return PP_OK;
+}
+
 extern "C" {
 
 int pp_abi_version(void) { return PP_ABI_VERSION; }
@@ -183,6 +197,7 @@ void pp_destroy(pp_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->ticket) (void)hipFree(ctx->ticket);
+  if (ctx->hist) (void)hipFree(ctx->hist);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   if (ctx->prof) {

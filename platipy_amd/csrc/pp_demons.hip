@@ -31,7 +31,27 @@ struct pp_dev_stats {
   double metric, rms;
   int elapsed;
   int halt;
+  double* hist;   // {metric, RMS change} of iteration k at hist[2k], hist[2k + 1] (what an sitkIterationEvent observer reads)
+  int hist_cap;
 };
+
+// One iteration's statistics into the history ring (called by the thread that publishes them, before elapsed is bumped).
+__device__ __forceinline__ void pp_stats_record(pp_dev_stats* st) {
+  if (st->hist && st->elapsed < st->hist_cap) {   // hist[0] = entries recorded, entry k at hist[2 + 2k], hist[3 + 2k]
+    st->hist[2 + 2 * st->elapsed] = st->metric;
+    st->hist[3 + 2 * st->elapsed] = st->rms;
+    st->hist[0] = (double)(st->elapsed + 1);
+  }
+}
+
+__global__ void k_stats_init(pp_dev_stats* st, double* hist, int hist_cap) {
+  pp_dev_stats z;
+  z.ssd = 0.0; z.ssc = 0.0; z.npx = 0; z.metric = 0.0; z.rms = 0.0; z.elapsed = 0; z.halt = 0;
+  z.hist = hist;
+  z.hist_cap = hist_cap;
+  if (hist) hist[0] = 0.0;
+  *st = z;
+}
 
 struct pp_esm_consts {
   float ix, iy, iz;     // 1 / spacing; the central-difference factor 0.5 / spacing is exactly half of it
@@ -200,6 +220,7 @@ __global__ void __launch_bounds__(NT) k_demons_finalize(const double* __restrict
       st->metric = a / c;
       st->rms = sqrt(b / c);
     }
+    pp_stats_record(st);
     st->elapsed += 1;
     if (max_rms > st->rms) st->halt = 1;  // Halt(): m_MaximumRMSError > m_RMSChange
   }
@@ -390,7 +411,23 @@ __device__ __forceinline__ float ld_off(const float* base, unsigned byte_off) {
 }
 
 // per-voxel flags packed beside the LDS slots
-constexpr unsigned F_CNT = 1u, F_XLO = 2u, F_XHI = 4u, F_YLO = 8u, F_YHI = 16u, F_VALID = 32u;
+constexpr unsigned F_CNT = 1u, F_XLO = 2u, F_XHI = 4u, F_YLO = 8u, F_YHI = 16u, F_VALID = 32u, F_OOV = 64u;
+
+// Measurement builds only (-DPP_TRACE, tools/kbench): shader-clock stamps of one block's waves at the barriers of the
+// plane loop, read back through pp_debug_trace_read.  Product builds compile none of it.
+#ifdef PP_TRACE
+constexpr int PP_TRACE_STEPS = 140, PP_TRACE_SLOTS = 6;
+__device__ unsigned pp_trace_buf[2][8][PP_TRACE_STEPS][PP_TRACE_SLOTS];
+#define PP_TRACE_MARK(on, kern, step, slot)                                                     \
+  do {                                                                                          \
+    if ((on) && (threadIdx.x & 63u) == 0 && (step) >= 0 && (step) < PP_TRACE_STEPS)             \
+      pp_trace_buf[kern][threadIdx.x >> 6][step][slot] = (unsigned)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define PP_TRACE_MARK(on, kern, step, slot) \
+  do {                                      \
+  } while (0)
+#endif
 
 // ---- kernel A: ESM update + 3-D Gaussian of the update ---------------------------------
 #ifndef PP_FUSED_DEFAULT_OPT
@@ -1042,6 +1079,9 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   esm_consts(g, p, &K);
   const pp_warp_scale sc{(float)(1.0 / g->spacing[0]), (float)(1.0 / g->spacing[1]), (float)(1.0 / g->spacing[2])};
   const double max_rms = p->max_rms_error > 0.0 ? p->max_rms_error : -1.0;
+  double* hist = nullptr;   // per-iteration {metric, RMS change}: read back by pp_demons_history
+  rc = pp_history_buffer(ctx, &hist);
+  if (rc) return rc;
 
   if (variant == PP_DEMONS_STAGED) {
     const unsigned nb = grid_for(N, 8192);
@@ -1057,7 +1097,8 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     pp_dev_stats* dst = cv.take<pp_dev_stats>(1);
     const int* halt = &dst->halt;
     const int order[3] = {0, 1, 2};
-    PP_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(pp_dev_stats), ctx->stream));
+    hipLaunchKernelGGL(k_stats_init, dim3(1), dim3(1), 0, ctx->stream, dst, hist, ctx->hist_cap);
+    PP_LAUNCH_CHECK(ctx, "k_stats_init");
     PP_HIP(ctx, hipMemsetAsync(field, 0, 3 * N * sizeof(float), ctx->stream));
     for (int it = 0; it < p->iterations; ++it) {
       {
@@ -1104,7 +1145,8 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   // kernel generation: 2 (pp_demons_fused2.h) unless the volume exceeds its 32-bit gather offsets / 24-bit row arithmetic,
   // rows are shorter than one strip, the 256-thread layout was asked for, or PP_FUSED_GEN=1 selects the first generation
   // (kept for A/B measurements).
-  const bool gen2_ok = N * sizeof(float) < ((size_t)1 << 32) && (size_t)d.ny * d.nz < ((size_t)1 << 24) && d.nx >= 4 && d.nx < (1 << 22) &&
+  const bool gen2_ok = 3 * N * sizeof(float) < ((size_t)1 << 32) &&   // (a whole 3-component field under one buffer resource)
+                       (size_t)d.ny * d.nz < ((size_t)1 << 24) && d.nx >= 4 && d.nx < (1 << 22) &&
                        d.ny < (1 << 22) && d.nz < (1 << 22);   // (every axis below the warp's 2^23-voxel displacement clamp)
   int gen = (gen2_ok && opt == 2) ? 2 : 1;
   if (const char* e = getenv("PP_FUSED_GEN")) {
@@ -1178,7 +1220,8 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   double* partials2 = cv.take<double>(3 * nblk);   // generation-2 kernel A alternates: it folds the previous launch's sums itself
   pp_dev_stats* dst = cv.take<pp_dev_stats>(1);
   const int* halt = &dst->halt;
-  PP_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(pp_dev_stats), ctx->stream));
+  hipLaunchKernelGGL(k_stats_init, dim3(1), dim3(1), 0, ctx->stream, dst, hist, ctx->hist_cap);
+  PP_LAUNCH_CHECK(ctx, "k_stats_init");
   PP_HIP(ctx, hipMemsetAsync(field, 0, 3 * N * sizeof(float), ctx->stream));
   for (int it = 0; it < p->iterations; ++it) {
     // D = 0 warps the moving image onto itself exactly, so iteration 0 reads it directly.
@@ -1224,5 +1267,37 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   if (stats) return read_stats(ctx, dst, stats);
   return PP_OK;
 }
+
+int pp_demons_history(pp_ctx* ctx, double* metric, double* rms_change, int cap) {
+  if (!ctx || cap < 0 || (cap > 0 && (!metric || !rms_change))) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
+  if (!ctx->hist) return 0;   // no Execute has run on this context
+  double head[2];
+  int rc = pp_read_back(ctx, ctx->hist, head, sizeof(head));
+  if (rc) return rc;
+  const int n = (int)head[0];
+  const int take = n < cap ? n : cap;
+  constexpr int CH = 4096 / (2 * (int)sizeof(double));   // entries per staged read-back
+  double buf[2 * CH];
+  for (int k = 0; k < take; k += CH) {
+    const int m = take - k < CH ? take - k : CH;
+    rc = pp_read_back(ctx, ctx->hist + 2 + 2 * (size_t)k, buf, 2 * sizeof(double) * (size_t)m);
+    if (rc) return rc;
+    for (int i = 0; i < m; ++i) {
+      metric[k + i] = buf[2 * i];
+      rms_change[k + i] = buf[2 * i + 1];
+    }
+  }
+  return n;
+}
+
+#ifdef PP_TRACE
+int pp_debug_trace_read(unsigned* out, int cap) {
+  const int n = 2 * 8 * PP_TRACE_STEPS * PP_TRACE_SLOTS;
+  if (cap < n) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_trace_buf), sizeof(unsigned) * n) != hipSuccess) return -2;
+  return n;
+}
+#endif
 
 }  // extern "C"

@@ -55,6 +55,16 @@ __device__ __forceinline__ void pp_gst2(char* base, unsigned byte_off, float a, 
   v.y = b;
   *reinterpret_cast<pp_f2u*>(base + (size_t)byte_off) = v;
 }
+// The same load with a wave-uniform byte offset in the instruction's scalar-offset operand: one resource per ARRAY is
+// built once per block and a plane / component is a 32-bit scalar (PP_SOFF=1, the default; callers guarantee that the whole
+// array spans < 2^32 bytes).  Rebuilding a 64-bit base + resource per plane and array cost kernel A ~45 scalar instructions
+// per plane and both kernels the scalar registers whose spills (v_readlane) sat in the plane loop.
+#ifndef PP_SOFF
+#define PP_SOFF 1
+#endif
+__device__ __forceinline__ float pp_blds(pp_rsrc r, unsigned byte_off, unsigned s_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, s_off, 0));
+}
 // Cache-policy bits of the buffer stores (2 = nt, streaming) for builds that force one policy; the product chooses per
 // launch, see pp_bst2 below.
 #ifndef PP_STORE_AUX
@@ -79,6 +89,17 @@ __device__ __forceinline__ void pp_bst2s(pp_rsrc r, unsigned byte_off, float a, 
   v[0] = __builtin_bit_cast(unsigned, a);
   v[1] = __builtin_bit_cast(unsigned, b);
   __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, STREAMING ? 2 : 0);
+}
+
+template <bool STREAMING>
+__device__ __forceinline__ void pp_bst2ss(pp_rsrc r, unsigned byte_off, unsigned s_off, float a, float b) {
+  pp_u2 v;
+  v[0] = __builtin_bit_cast(unsigned, a);
+  v[1] = __builtin_bit_cast(unsigned, b);
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, s_off, STREAMING ? 2 : 0);
+}
+__device__ __forceinline__ void pp_bsts(pp_rsrc r, unsigned byte_off, unsigned s_off, float a) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a), r, byte_off, s_off, PP_STORE_AUX);
 }
 
 // Sum of three doubles over the block: butterfly inside each wavefront (ds_bpermute shuffles, no LDS
@@ -348,10 +369,11 @@ __device__ __forceinline__ void fused2_xpass_shfl(const float4 (&strip)[3], unsi
     const float sx_ = strip[c].x, sy_ = strip[c].y, sz_ = strip[c].z, sw_ = strip[c].w;
     float own[4] = {sx_, sy_, sz_, sw_};
     if (jm != 0xE4u) {   // strips that leave the volume in x (x-border tiles only): every position takes its clamped voxel
-      own[0] = pp_pick4(sx_, sy_, sz_, sw_, jm & 3u);
-      own[1] = pp_pick4(sx_, sy_, sz_, sw_, (jm >> 2) & 3u);
-      own[2] = pp_pick4(sx_, sy_, sz_, sw_, (jm >> 4) & 3u);
-      own[3] = pp_pick4(sx_, sy_, sz_, sw_, (jm >> 6) & 3u);
+      const unsigned j = pp_opaque(jm);   // (the eight selects' predicates are formed here, not hoisted as 16 scalar registers)
+      own[0] = pp_pick4(sx_, sy_, sz_, sw_, j & 3u);
+      own[1] = pp_pick4(sx_, sy_, sz_, sw_, (j >> 2) & 3u);
+      own[2] = pp_pick4(sx_, sy_, sz_, sw_, (j >> 4) & 3u);
+      own[3] = pp_pick4(sx_, sy_, sz_, sw_, (j >> 6) & 3u);
     }
     float in[4 + 2 * R];
 #pragma unroll
@@ -487,6 +509,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
   const unsigned o_xy = ((unsigned)y * sy + (unsigned)x) * 4u;
   const pp_warp_dims wd{d.nx, d.ny, d.nz, (unsigned)d.nx * 4u, sz * 4u};
   const char* const rm = reinterpret_cast<const char*>(M);
+  const pp_rsrc r_dn = pp_make_rsrc(Dn), r_mw = pp_make_rsrc(Mw);   // one resource per output array (PP_SOFF)
 
   const int zs = z0 - R;
   const int zo_last = (z0 + a.zchunk - 1 < d.nz - 1) ? z0 + a.zchunk - 1 : d.nz - 1;
@@ -557,6 +580,8 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
   }
   int ybuf = 0;   // XS: the buffer that holds the current plane's x-pass result
 
+  const bool trace_on = (rank == (unsigned)(a.gx * (a.gy / 2) + a.gx / 2));   // (PP_TRACE builds: an interior tile, first z-chunk)
+  (void)trace_on;
   auto step = [&](int n, auto phase_tag) {
     constexpr int P = decltype(phase_tag)::value;
     const int zi = zs + n;
@@ -564,6 +589,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
     const bool fresh_cur = (n == 0) || (cur != pp_clampi(zi - 1, 0, d.nz - 1));
     const int nxt = pp_clampi(zi + 1, 0, d.nz - 1);
     const bool fresh_next = (n + 1 < nsteps) && (nxt != cur);
+    PP_TRACE_MARK(trace_on, 1, n, 0);
     // ---- interval 1: y pass of plane `cur` (reads s_x) | publish plane `nxt` (writes s_u) ----
     if (fresh_cur) {
 #pragma unroll
@@ -603,26 +629,34 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
     // the plane after `nxt` goes in flight behind the gathers
     if (fresh_next && nxt < zhi) load_plane(nxt + 1);
     const size_t po = (size_t)zo * sz;
+    const unsigned po4 = (unsigned)zo * sz * 4u, N4 = (unsigned)N * 4u;   // (3 N * 4 < 2^32: checked on the host)
     auto store_field = [&]() {
       if (pair_ok) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) pp_bst2s<NT>(pp_make_rsrc(Dn + c * N + po), o_xy, dn[c][0], dn[c][1]);
+        for (int c = 0; c < 3; ++c) {
+          if constexpr (PP_SOFF != 0) pp_bst2ss<NT>(r_dn, o_xy, c * N4 + po4, dn[c][0], dn[c][1]);
+          else pp_bst2s<NT>(pp_make_rsrc(Dn + c * N + po), o_xy, dn[c][0], dn[c][1]);
+        }
       } else if (x + 1 < d.nx) {   // odd row length: pairs at 4-byte alignment
 #pragma unroll
         for (int c = 0; c < 3; ++c) pp_gst2(reinterpret_cast<char*>(Dn + c * N + po), o_xy, dn[c][0], dn[c][1]);
       } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) pp_bst(pp_make_rsrc(Dn + c * N + po), o_xy, dn[c][0]);
+        for (int c = 0; c < 3; ++c) {
+          if constexpr (PP_SOFF != 0) pp_bsts(r_dn, o_xy, c * N4 + po4, dn[c][0]);
+          else pp_bst(pp_make_rsrc(Dn + c * N + po), o_xy, dn[c][0]);
+        }
       }
     };
     auto store_image = [&]() {
-      const pp_rsrc rw = pp_make_rsrc(Mw + po);
       if (pair_ok) {
-        pp_bst2s<NT>(rw, o_xy, mw0, mw1);
+        if constexpr (PP_SOFF != 0) pp_bst2ss<NT>(r_mw, o_xy, po4, mw0, mw1);
+        else pp_bst2s<NT>(pp_make_rsrc(Mw + po), o_xy, mw0, mw1);
       } else if (x + 1 < d.nx) {
         pp_gst2(reinterpret_cast<char*>(Mw + po), o_xy, mw0, mw1);
       } else {
-        pp_bst(rw, o_xy, mw0);
+        if constexpr (PP_SOFF != 0) pp_bsts(r_mw, o_xy, po4, mw0);
+        else pp_bst(pp_make_rsrc(Mw + po), o_xy, mw0);
       }
     };
 #ifdef PP_ABL_NOSTORE
@@ -637,8 +671,10 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
 #endif
     }
     // ---- interval 2: x pass of plane `nxt` (XS: already done above; one barrier hands the buffers over) ----
+    PP_TRACE_MARK(trace_on, 1, n, 1);
     if (fresh_next) {
       __syncthreads();
+      PP_TRACE_MARK(trace_on, 1, n, 2);
       if constexpr (XS) {
         ybuf ^= 1;
       } else {
@@ -653,6 +689,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
     }
     if (do_store) store_image();
 #endif
+    PP_TRACE_MARK(trace_on, 1, n, 3);
   };
   fused2_plane_loop<R, UNROLL>(step, nsteps);
 }
@@ -713,6 +750,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
           st->metric = fa / fc;
           st->rms = rms;
         }
+        pp_stats_record(st);
         st->elapsed += 1;
         if (h) st->halt = 1;
       }
@@ -730,6 +768,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
   const int cx = t % G::LX, cy = t / G::LX;
   const unsigned sy = d.nx, sz = (unsigned)d.nx * d.ny;
   const size_t N = (size_t)sz * d.nz;
+  const pp_rsrc r_f = pp_make_rsrc(F), r_mw = pp_make_rsrc(Mw), r_d = pp_make_rsrc(D), r_us = pp_make_rsrc(Us);   // (PP_SOFF)
 
   // Owned smoothing-input voxels.  Image values are fetched at the clamped position, so out-of-volume halo slots
   // replicate the edge update (ZeroFluxNeumann on the smoothing input).
@@ -737,8 +776,9 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
   unsigned uflag[G::KU];  // slot in s_u | flags << 16
   unsigned own_g[G::KU];  // in-plane BYTE offset of the clamped position
   float mprev[G::KU], mcur[G::KU], mnext[G::KU], fprev[G::KU], fcur[G::KU], fnext[G::KU];
-  float hfx[G::KU], hfy[G::KU];   // fixed-gradient factor: 0 on the first/last index of the axis
-  float oov[G::KU];               // FLT_MAX for elements outside the volume (their slot publishes the sentinel), else -FLT_MAX
+  // (border rules are carried by data -- a slot outside the volume publishes the sentinel in its warped-image half, the
+  // fixed-gradient factor is 0 on a first/last index -- and both are derived from the flag bits where they are used: only
+  // blocks on the volume's x/y border ever need them, and nine registers held them for every block.)
 #pragma unroll
   for (int k = 0; k < G::KU; ++k) {
     const int e = t + k * NTH;
@@ -757,10 +797,8 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     if (xc == d.nx - 1) fl |= F_XHI;
     if (yc == 0) fl |= F_YLO;
     if (yc == d.ny - 1) fl |= F_YHI;
+    if (xg != xc || yg != yc) fl |= F_OOV;
     uflag[k] = (unsigned)(uy * G::UWP + ux) | (fl << 16);
-    hfx[k] = (fl & (F_XLO | F_XHI)) ? 0.0f : 0.5f * K.ix;
-    hfy[k] = (fl & (F_YLO | F_YHI)) ? 0.0f : 0.5f * K.iy;
-    oov[k] = (xg != xc || yg != yc) ? FLT_MAX : -FLT_MAX;
   }
   // Border ring of the image tile (needed only in-plane): one element per low thread.
   int brd_w = -1;
@@ -797,23 +835,39 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
   auto publish = [&]() {   // window centre (mcur, fcur) + border ring -> packed image tile
 #pragma unroll
     for (int k = 0; k < G::KU; ++k)
-      if ((k + 1) * NTH <= G::NU || ((uflag[k] >> 16) & F_VALID)) s_mf[slots[k] >> 16] = make_float2(fmaxf(mcur[k], oov[k]), fcur[k]);
+      if ((k + 1) * NTH <= G::NU || ((uflag[k] >> 16) & F_VALID)) {
+        const float oov = ((pp_opaque(uflag[k]) >> 16) & F_OOV) ? FLT_MAX : -FLT_MAX;
+        s_mf[slots[k] >> 16] = make_float2(fmaxf(mcur[k], oov), fcur[k]);
+      }
     if (brd_w >= 0) s_mf[brd_w] = make_float2(fmaxf(bm, brd_oov), bf);
   };
   auto prefetch = [&](int zc) {   // own voxels of plane zc + 2, border ring of plane zc + 1
     const size_t p2 = (size_t)pp_clampi(zc + 2, 0, d.nz - 1) * sz, p1 = (size_t)pp_clampi(zc + 1, 0, d.nz - 1) * sz;
-    const pp_rsrc rm2 = pp_make_rsrc(Mw + p2), rf2 = pp_make_rsrc(F + p2);
+    if constexpr (PP_SOFF != 0) {
+      const unsigned s2 = (unsigned)p2 * 4u, s1 = (unsigned)p1 * 4u;
 #pragma unroll
-    for (int k = 0; k < G::KU; ++k) {
-      min_[k] = pp_bld(rm2, own_g[k]);
-      fin_[k] = pp_bld(rf2, own_g[k]);
-    }
-    if (brd_w >= 0) {
-      bm_n = pp_bld(pp_make_rsrc(Mw + p1), brd_g);
-      bf_n = pp_bld(pp_make_rsrc(F + p1), brd_g);
+      for (int k = 0; k < G::KU; ++k) {
+        min_[k] = pp_blds(r_mw, own_g[k], s2);
+        fin_[k] = pp_blds(r_f, own_g[k], s2);
+      }
+      if (brd_w >= 0) {
+        bm_n = pp_blds(r_mw, brd_g, s1);
+        bf_n = pp_blds(r_f, brd_g, s1);
+      }
+    } else {
+      const pp_rsrc rm2 = pp_make_rsrc(Mw + p2), rf2 = pp_make_rsrc(F + p2);
+#pragma unroll
+      for (int k = 0; k < G::KU; ++k) {
+        min_[k] = pp_bld(rm2, own_g[k]);
+        fin_[k] = pp_bld(rf2, own_g[k]);
+      }
+      if (brd_w >= 0) {
+        bm_n = pp_bld(pp_make_rsrc(Mw + p1), brd_g);
+        bf_n = pp_bld(pp_make_rsrc(F + p1), brd_g);
+      }
     }
   };
-  auto esm = [&](int zc) {   // update at every smoothing-input voxel of plane zc (the window centre) -> s_u, then rotate
+  auto esm = [&](int zc) __attribute__((always_inline)) {   // update at every smoothing-input voxel of plane zc (the window centre) -> s_u, then rotate
     const bool count_plane = (zc >= z0 && zc <= zo_last);
     const bool zlo_b = (zc == 0), zhi_b = (zc == d.nz - 1);
 #pragma unroll
@@ -822,8 +876,10 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
       if ((k + 1) * NTH <= G::NU || (fl & F_VALID)) {
         const int l = (int)(slots[k] & 0xffffu);
         const float2 xm = s_mf[l - 1], xp = s_mf[l + 1], ym = s_mf[l - G::MWP], yp = s_mf[l + G::MWP];
-        const float gx = pp_esm_axis_data(xm.y, xp.y, mcur[k], xm.x, xp.x, hfx[k], K.ix);
-        const float gy = pp_esm_axis_data(ym.y, yp.y, mcur[k], ym.x, yp.x, hfy[k], K.iy);
+        const unsigned flb = pp_opaque(fl);   // (predicates formed here: hoisted, they would hold six scalar registers per voxel)
+        const float hfx = (flb & (F_XLO | F_XHI)) ? 0.0f : 0.5f * K.ix, hfy = (flb & (F_YLO | F_YHI)) ? 0.0f : 0.5f * K.iy;
+        const float gx = pp_esm_axis_data(xm.y, xp.y, mcur[k], xm.x, xp.x, hfx, K.ix);
+        const float gy = pp_esm_axis_data(ym.y, yp.y, mcur[k], ym.x, yp.x, hfy, K.iy);
         const float gz = pp_esm_axis(fprev[k], fnext[k], mcur[k], mprev[k], mnext[k], zlo_b, zhi_b, K.iz);
         const pp_esm_out o = pp_esm_voxel(K, fcur[k], mcur[k], gx, gy, gz);
         const int u = (int)(uflag[k] & 0xffffu);
@@ -862,9 +918,15 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
       const size_t po = (size_t)zo * sz;
 #pragma unroll
       for (int c = 0; c < (SUM ? 3 : 1); ++c) {   // two 4-byte buffer loads: no alignment case, no branch (x + 1 == nx re-reads x)
-        const pp_rsrc rd = pp_make_rsrc(D + c * N + po);
-        dsum[c].x = pp_bld(rd, o_xy);
-        dsum[c].y = pp_bld(rd, o_xy1);
+        if constexpr (PP_SOFF != 0) {
+          const unsigned so = ((unsigned)c * (unsigned)N + (unsigned)po) * 4u;
+          dsum[c].x = pp_blds(r_d, o_xy, so);
+          dsum[c].y = pp_blds(r_d, o_xy1, so);
+        } else {
+          const pp_rsrc rd = pp_make_rsrc(D + c * N + po);
+          dsum[c].x = pp_bld(rd, o_xy);
+          dsum[c].y = pp_bld(rd, o_xy1);
+        }
       }
     }
   };
@@ -897,6 +959,8 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     __syncthreads();
   }
 
+  const bool trace_on = (rank == (unsigned)(a.gx * (a.gy / 2) + a.gx / 2));   // (PP_TRACE builds: an interior tile, first z-chunk)
+  (void)trace_on;
   auto step = [&](int n, auto phase_tag) {
     constexpr int P = decltype(phase_tag)::value;
     const int zi = zs + n;
@@ -906,10 +970,13 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     const bool fresh_next = (n + 1 < nsteps) && (nxt != cur);
     const int zo = zi - R;
     const bool emit = (zo >= z0) && (zo <= zo_last) && out_ok;
+    PP_TRACE_MARK(trace_on, 0, n, 0);
     // ---- interval 1: x pass of plane `cur` (s_u -> s_x) | publish the image tile of plane `nxt` ----
     if (fresh_next) publish();
     if (fresh_cur) fused2_xpass<R, NXI, 3 * G::XI>(s_u, s_x, a.wx, xsrc, xdst);
+    PP_TRACE_MARK(trace_on, 0, n, 1);
     if (fresh_cur || fresh_next) __syncthreads();
+    PP_TRACE_MARK(trace_on, 0, n, 2);
     // ---- interval 2: y pass of plane `cur` (s_x -> registers) | ESM update of plane `nxt` (s_mf -> s_u) ----
     if (fresh_cur) {
 #pragma unroll
@@ -926,13 +993,24 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
           us[c][0] = dsum[c].x + us[c][0];
           us[c][1] = dsum[c].y + us[c][1];
         }
-        const pp_rsrc ro = pp_make_rsrc(Us + c * N + po);
-        if (pair_ok) {
-          pp_bst2s<NT>(ro, o_xy, us[c][0], us[c][1]);
-        } else if (x + 1 < d.nx) {
-          pp_gst2(reinterpret_cast<char*>(Us + c * N + po), o_xy, us[c][0], us[c][1]);
+        if constexpr (PP_SOFF != 0) {
+          const unsigned so = ((unsigned)c * (unsigned)N + (unsigned)po) * 4u;
+          if (pair_ok) {
+            pp_bst2ss<NT>(r_us, o_xy, so, us[c][0], us[c][1]);
+          } else if (x + 1 < d.nx) {
+            pp_gst2(reinterpret_cast<char*>(Us + c * N + po), o_xy, us[c][0], us[c][1]);
+          } else {
+            pp_bsts(r_us, o_xy, so, us[c][0]);
+          }
         } else {
-          pp_bst(ro, o_xy, us[c][0]);
+          const pp_rsrc ro = pp_make_rsrc(Us + c * N + po);
+          if (pair_ok) {
+            pp_bst2s<NT>(ro, o_xy, us[c][0], us[c][1]);
+          } else if (x + 1 < d.nx) {
+            pp_gst2(reinterpret_cast<char*>(Us + c * N + po), o_xy, us[c][0], us[c][1]);
+          } else {
+            pp_bst(ro, o_xy, us[c][0]);
+          }
         }
       }
     }
@@ -943,7 +1021,9 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
       if ((n + 2 < nsteps) && (nxt2 != nxt)) prefetch(nxt2);
     }
     if constexpr (SUM) load_dsum(zo + 1);
+    PP_TRACE_MARK(trace_on, 0, n, 3);
     if (fresh_cur || fresh_next) __syncthreads();
+    PP_TRACE_MARK(trace_on, 0, n, 4);
   };
   fused2_plane_loop<R, UNROLL>(step, nsteps);
   double r_ssd = (double)a_ssd, r_ssc = (double)a_ssc, r_n = (double)a_n;

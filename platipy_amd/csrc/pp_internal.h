@@ -27,6 +27,8 @@ struct pp_ctx {
   unsigned* ticket;   // device counter for last-block-finishes reductions (lazy, kept at 0 between launches)
   char* mailbox;      // 4 KB of page-locked, device-visible host memory a kernel writes small results into (lazy)
   unsigned long long mail_seq;  // sequence number of the last posted result
+  double* hist;       // device ring of the last Execute's per-iteration {metric, RMS change} (lazy; pp_demons_history)
+  int hist_cap;       // entries (iterations) the ring holds
   char err[512];
 };
 
@@ -63,6 +65,9 @@ int pp_reserve(pp_ctx* ctx, size_t bytes);
 int pp_read_back(pp_ctx* ctx, const void* dev, void* host, size_t bytes);
 // Device counter (zero between launches) for kernels whose last block folds the partial sums.
 int pp_ticket(pp_ctx* ctx, unsigned** out);
+// Device buffer for the per-iteration {metric, RMS change} pairs of one demons Execute (PP_HIST_CAP iterations).
+constexpr int PP_HIST_CAP = 4096;
+int pp_history_buffer(pp_ctx* ctx, double** out);
 // Mailbox for kernels that hand a few numbers straight to the host: 4 KB of page-locked memory the device writes
 // through its host pointer.  Layout: bytes [0, 3072) payload, [3072, 4096) up to 128 completion flags (uint64).
 // A kernel stores its payload, __threadfence_system(), then stores the launch's sequence number into its flag;
@@ -145,6 +150,17 @@ struct pp_taps_small {
 // device helpers
 
 __device__ __forceinline__ int pp_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// The value, opaque to the optimiser at this point (an empty asm with the value as a read-write VGPR operand): what is
+// derived from it afterwards is computed where it is used instead of being hoisted out of the enclosing loop.  For
+// rarely-taken paths whose hoisted per-lane predicates (two scalar registers each) would otherwise be held -- and
+// spilled -- across the hot loop.
+__device__ __forceinline__ unsigned pp_opaque(unsigned v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
 
 // Continuous index = base + frac with integer base and frac in [0,1): the inside-buffer test
 // of itk::ImageFunction::IsInsideBuffer, [-0.5, n-0.5), done exactly on (base, frac).

@@ -2,8 +2,8 @@
 // (see include/hip/hip_runtime.h).
 //
 // A thread block runs as blockDim cooperative fibers (ucontext) on ONE OS thread: a fiber runs until
-// it reaches __syncthreads() (or returns), then the next fiber runs; when every live fiber has
-// arrived the round restarts.  Blocks are independent, so a pool of OS threads executes different
+// it waits (at __syncthreads() or at a wavefront rendezvous inside a shuffle / vote) or returns, then the
+// next fiber runs; a waiting fiber yields again each round until the barrier it waits at is complete.  Blocks are independent, so a pool of OS threads executes different
 // blocks in parallel; `__shared__` is `static thread_local`, i.e. private to the OS thread and thus
 // to the block it is currently running.
 //
@@ -55,6 +55,9 @@ constexpr size_t STACK_BYTES = 256 * 1024;
 struct Worker {
   std::vector<Fiber> fibers;
   std::vector<char*> stacks;
+  // barrier state of the block being run: block-wide (__syncthreads) and per wavefront (shuffles, votes)
+  unsigned live = 0, bar_arrived = 0, bar_gen = 0;
+  unsigned wave_live[32] = {}, wave_arrived[32] = {}, wave_gen[32] = {};
 #if defined(__x86_64__)
   void* sched_sp = nullptr;
 #else
@@ -65,10 +68,26 @@ struct Worker {
 
 thread_local Worker* t_worker = nullptr;
 
+unsigned linear_tid(const Fiber* f) { return f->tid.x + g_blockDim.x * (f->tid.y + g_blockDim.y * f->tid.z); }
+
 void fiber_entry() {
   Fiber* f = t_current;
   (*t_worker->body)();
   f->done = true;
+  {   // a thread that has returned no longer takes part in barriers: release those its exit completes
+    Worker& w = *t_worker;
+    const unsigned wv = linear_tid(f) >> 6;
+    --w.live;
+    --w.wave_live[wv];
+    if (w.bar_arrived && w.bar_arrived == w.live) {
+      w.bar_arrived = 0;
+      ++w.bar_gen;
+    }
+    if (w.wave_arrived[wv] && w.wave_arrived[wv] == w.wave_live[wv]) {
+      w.wave_arrived[wv] = 0;
+      ++w.wave_gen[wv];
+    }
+  }
 #if defined(__x86_64__)
   hipemu_switch(&f->sp, t_worker->sched_sp);   // never resumed
   __builtin_trap();
@@ -106,9 +125,14 @@ void run_block(Worker& w, dim3 grid, dim3 block, unsigned long b, const std::fun
     makecontext(&f.ctx, fiber_entry, 0);
 #endif
   }
-  unsigned live = n;
-  while (live) {
-    // one round: every live fiber runs to its next barrier (or to the end)
+  w.live = n;
+  w.bar_arrived = 0;
+  for (unsigned k = 0; k < 32; ++k) {
+    w.wave_arrived[k] = 0;
+    w.wave_live[k] = (64 * k < n) ? ((n - 64 * k < 64) ? n - 64 * k : 64) : 0;
+  }
+  while (w.live) {
+    // one round: every live fiber runs until it next yields (waiting at a barrier, it yields again until released)
     for (unsigned t = 0; t < n; ++t) {
       Fiber& f = w.fibers[t];
       if (f.done) continue;
@@ -118,7 +142,6 @@ void run_block(Worker& w, dim3 grid, dim3 block, unsigned long b, const std::fun
 #else
       swapcontext(&w.sched, &f.ctx);
 #endif
-      if (f.done) --live;
     }
   }
   t_current = nullptr;
@@ -133,6 +156,32 @@ void fiber_yield() {
 #else
   swapcontext(&f->ctx, &t_worker->sched);
 #endif
+}
+
+// __syncthreads(): wait until every live thread of the block has arrived.
+void block_barrier() {
+  Worker& w = *t_worker;
+  const unsigned g = w.bar_gen;
+  if (++w.bar_arrived == w.live) {
+    w.bar_arrived = 0;
+    ++w.bar_gen;
+    return;
+  }
+  while (w.bar_gen == g) fiber_yield();
+}
+
+// Rendezvous of the live lanes of the calling thread's wavefront (shuffles / votes: every lane of the WAVEFRONT must reach
+// the call; other wavefronts of the block may be elsewhere, as on the hardware).
+void wave_barrier() {
+  Worker& w = *t_worker;
+  const unsigned wv = linear_tid(t_current) >> 6;
+  const unsigned g = w.wave_gen[wv];
+  if (++w.wave_arrived[wv] == w.wave_live[wv]) {
+    w.wave_arrived[wv] = 0;
+    ++w.wave_gen[wv];
+    return;
+  }
+  while (w.wave_gen[wv] == g) fiber_yield();
 }
 
 void launch(dim3 grid, dim3 block, const std::function<void()>& body) {

@@ -59,6 +59,8 @@ struct Fiber {
 extern thread_local Fiber* t_current;
 extern dim3 g_blockDim, g_gridDim;
 void fiber_yield();
+void block_barrier();
+void wave_barrier();
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 }  // namespace hipemu
 
@@ -67,7 +69,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 #define blockDim (::hipemu::g_blockDim)
 #define gridDim (::hipemu::g_gridDim)
 
-static inline void __syncthreads() { ::hipemu::fiber_yield(); }
+static inline void __syncthreads() { ::hipemu::block_barrier(); }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   ::hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
@@ -141,6 +143,8 @@ static inline int __float2int_rd(float x) { return (int)floorf(x); }
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
 static inline float __fdividef(float a, float b) { return a / b; }
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))   // v_rcp_f32 (1 ulp) on the GPU
+static inline void __builtin_amdgcn_sched_barrier(int) {}                  // (a scheduling hint: nothing to emulate)
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // (only ever applied to wave-uniform values)
 static inline unsigned __umul24(unsigned a, unsigned b) { return (unsigned)((unsigned long long)(a & 0xffffffu) * (b & 0xffffffu)); }
 
 // buffer resources: base pointer + 32-bit byte offsets (the stand-in ignores the range / format words)
@@ -164,17 +168,17 @@ static inline void __builtin_amdgcn_raw_buffer_store_b64(hipemu_u2 v, __amdgpu_b
   memcpy(r.base + (size_t)voff + soff, &v, 8);
 }
 
-// Wavefront shuffle (64 lanes).  Every thread of the block must reach the call (uniform control flow): the value is
-// exchanged through a per-block table between two block-wide yields.
+// Wavefront shuffle (64 lanes).  Every live lane of the WAVEFRONT must reach the call: the value is exchanged through a
+// per-block table between two wavefront rendezvous.
 namespace hipemu { extern thread_local double t_shfl[1024]; }
 static inline float hipemu_shfl_from(float v, int delta) {   // value of lane (lane + delta), own value when that lane does not exist
   const unsigned t = threadIdx.x;
   ::hipemu::t_shfl[t] = (double)v;
-  ::hipemu::fiber_yield();
+  ::hipemu::wave_barrier();
   const int src = (int)(t & 63u) + delta;
   const unsigned idx = (t & ~63u) + (unsigned)src;
   const float r = (src >= 0 && src < 64 && idx < blockDim.x) ? (float)::hipemu::t_shfl[idx] : v;
-  ::hipemu::fiber_yield();
+  ::hipemu::wave_barrier();
   return r;
 }
 static inline float __shfl_up(float v, unsigned delta, int /*width*/ = 64) { return hipemu_shfl_from(v, -(int)delta); }
@@ -193,9 +197,19 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, i
 static inline double __shfl_xor(double v, int lane_mask, int /*width*/ = 64) {
   const unsigned t = threadIdx.x;
   ::hipemu::t_shfl[t] = v;
-  ::hipemu::fiber_yield();
+  ::hipemu::wave_barrier();
   const unsigned src = (t & ~63u) | ((t ^ (unsigned)lane_mask) & 63u);
   const double r = src < blockDim.x ? ::hipemu::t_shfl[src] : v;
-  ::hipemu::fiber_yield();
+  ::hipemu::wave_barrier();
+  return r;
+}
+// Wavefront vote: non-zero if the predicate holds in any live lane of the caller's wavefront.
+static inline int __any(int pred) {
+  const unsigned t = threadIdx.x;
+  ::hipemu::t_shfl[t] = pred ? 1.0 : 0.0;
+  ::hipemu::wave_barrier();
+  int r = 0;
+  for (unsigned l = (t & ~63u); l < (t & ~63u) + 64u && l < blockDim.x; ++l) r |= (::hipemu::t_shfl[l] != 0.0);
+  ::hipemu::wave_barrier();
   return r;
 }

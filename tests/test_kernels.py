@@ -630,3 +630,39 @@ def test_argument_errors(backend):
     p = ctx.default_demons_params()
     with pytest.raises(_lib.PlatipyAmdError):          # direction cosines are handled above the ABI
         ctx.demons_execute(a, a, rot, p, backend.empty((3,) + shape))
+
+
+WIDE = ((8, 40, 136), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0))   # 64 x 16 tiles: tile (1, 1) lies strictly inside the volume
+
+
+@pytest.mark.parametrize("sentinels", [False, True])
+def test_fused_kernels_on_interior_tiles(backend, sentinels, monkeypatch):
+    """A grid with tiles strictly inside the volume (the other grids of this file only have border tiles, whose clamps and
+    out-of-volume sentinel slots take different paths): generation 2 == generation 1 bit for bit, both == the oracle.
+    `sentinels`: FLT_MAX voxels planted in the moving image inside the interior tile -- iteration 0 reads the moving image
+    as the warped one, so ITK's sentinel case analysis is exercised away from the volume border too."""
+    shape, spacing, origin = WIDE
+    fix = phantom(shape, seed=50)
+    dv = random_dvf(shape, spacing, seed=51, max_mm=2.0)
+    mov = O.warp_image(O.Vol(fix, spacing, origin), dv.astype(np.float64), edge_value=-1000.0).arr.astype(np.float32)
+    iters = 3
+    if sentinels:
+        mov[3, 20:23, 80:90] = np.finfo(np.float32).max
+        mov[6, 25, 100] = np.finfo(np.float32).max
+        iters = 1          # (later iterations would interpolate FLT_MAX into infinities: nothing to compare)
+    monkeypatch.setenv("PP_FUSED_TILE", "0")
+    p = _demons_params(backend.ctx, iters, spacing, _lib.DEMONS_FUSED, max_rms=0.0)
+    out = {}
+    for gen in ("2", "1"):
+        monkeypatch.setenv("PP_FUSED_GEN", gen)
+        f = backend.empty((3,) + shape)
+        st = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, f)
+        out[gen] = (backend.host(f).copy(), st.metric, st.rms_change, st.n_pixels)
+    np.testing.assert_array_equal(out["2"][0].view(np.uint32), out["1"][0].view(np.uint32))
+    np.testing.assert_allclose(out["2"][1:3], out["1"][1:3], rtol=1e-6)
+    assert out["2"][3] == out["1"][3]
+    want, wst = _oracle_execute(fix, mov, spacing, origin, iters, 0.0)
+    err = np.abs(out["2"][0] - want)
+    assert err.max() <= 2e-3 and np.sqrt((err ** 2).mean()) <= 5e-5
+    assert out["2"][3] == wst.n_pixels
+    np.testing.assert_allclose(out["2"][1], wst.metric, rtol=1e-4)

@@ -10,7 +10,7 @@ def kernel_lines(path, key):
     out, on = [], False
     for ln in open(path):
         if not on:
-            if ln.startswith("_Z") and key in ln and re.match(r"^_Z\w+:", ln):
+            if ln.startswith("_ZN") and key in ln and re.match(r"^_ZN\w+:", ln):
                 on = True
             continue
         if ln.startswith(".Lfunc_end"):

@@ -162,5 +162,27 @@ int main(int argc, char** argv) {
     fflush(stdout);
     for (auto& k : keys) unsetenv(k.c_str());
   }
+  // -DPP_TRACE builds: per-wave shader-clock stamps at the plane loop's barriers (one interior block per kernel)
+  if (auto trace_read = reinterpret_cast<int (*)(unsigned*, int)>(dlsym(h, "pp_debug_trace_read"))) {
+    const int STEPS = 140, SLOTS = 6;
+    std::vector<unsigned> buf(2 * 8 * STEPS * SLOTS);
+    if (trace_read(buf.data(), (int)buf.size()) > 0) {
+      for (int k = 0; k < 2; ++k) {
+        printf("trace kernel %c: step | per wave: t(slot1)-t(slot0) ... (shader clocks since slot 0 of wave 0)\n", k ? 'B' : 'A');
+        for (int s = 20; s < 32; ++s) {
+          const unsigned base = buf[((k * 8 + 0) * STEPS + s) * SLOTS + 0];
+          printf("  step %3d:", s);
+          for (int w = 0; w < 8; ++w) {
+            printf(" w%d[", w);
+            for (int q = 0; q < (k ? 4 : 5); ++q) printf("%s%d", q ? " " : "", (int)(buf[((k * 8 + w) * STEPS + s) * SLOTS + q] - base));
+            printf("]");
+          }
+          printf("\n");
+        }
+        const unsigned t0 = buf[((k * 8 + 0) * STEPS + 20) * SLOTS + 0], t1 = buf[((k * 8 + 0) * STEPS + 120) * SLOTS + 0];
+        printf("  100 steps of wave 0: %u clocks = %.1f per step\n", t1 - t0, (t1 - t0) / 100.0);
+      }
+    }
+  }
   return 0;
 }
