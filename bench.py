@@ -38,20 +38,51 @@ from platipy_amd import _lib  # noqa: E402
 # Generation-2 fused kernels: A reads F, M o D and D (4 + 4 + 12) and writes S = D + G_u * update (12); B reads S (12) and
 # the moving image once (4) and writes D' (12) and M o D' (4).  With PP_FUSED_SUM=0 (and generation 1) A writes the
 # smoothed update alone (20) and B reads D and U (44).  Either way an iteration moves 64 compulsory bytes per voxel.
-_SEPARATE = os.environ.get("PP_FUSED_SUM") == "0"
+# The library names what it ran: "k_fused2_*" = SUM mode, "k_fused2_*/sep" = the update stored alone (PP_FUSED_SUM=0, or one of the
+# two kernels in generation 1 because of its radius), so the byte model follows the schedule, not an environment variable.
 COMPULSORY_BYTES = {
-    "k_fused2_force_smooth": 20 if _SEPARATE else 32, "k_fused2_add_smooth_warp": 44 if _SEPARATE else 32,
+    "k_fused2_force_smooth": 32, "k_fused2_add_smooth_warp": 32, "k_fused2_force_smooth/sep": 20, "k_fused2_add_smooth_warp/sep": 44,
     "k_fused_force_smooth": 20, "k_fused_add_smooth_warp": 44,
     "k_warp_same_grid": 20, "k_demons_force": 20, "k_conv_axis x3 (update)": 72, "k_conv_axis x3 (add+field)": 84,
 }
 CONTRACT_BYTES = {
     "k_fused2_force_smooth": 20 + 72, "k_fused2_add_smooth_warp": 36 + 48 + 20,
+    "k_fused2_force_smooth/sep": 20 + 72, "k_fused2_add_smooth_warp/sep": 36 + 48 + 20,
     "k_fused_force_smooth": 20 + 72, "k_fused_add_smooth_warp": 36 + 48 + 20,
     "k_warp_same_grid": 20, "k_demons_force": 20, "k_conv_axis x3 (update)": 72, "k_conv_axis x3 (add+field)": 84,
 }
 CONTRACT_BYTES_ITER = 196
 COMPULSORY_BYTES_ITER_FUSED = 64
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def kernel_source_sha16():
+    """sha256 (first 16 hex digits) over the demons kernel sources: a committed PMC capture is attached to the bench line only
+    when it was taken of exactly these sources (`roofline.traffic` must be of HEAD's kernels)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "platipy_amd", "csrc")
+    for f in ("pp_demons.hip", "pp_demons_fused2.h", "pp_warp_sample.h", "pp_internal.h"):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(nx, ny, nz):
+    """The newest profiles/round*_pmc.json of this grid whose `kernel_source_sha16` matches the sources in the tree."""
+    import glob
+
+    sha = kernel_source_sha16()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if list(pmc.get("size", [])) == [nx, ny, nz] and pmc.get("kernel_source_sha16") == sha:
+            pmc["_file"] = os.path.relpath(path, ROOT)
+            return pmc
+    return None
 
 
 def synth_pair(ctx, shape, spacing, seed, device, warp_seed=None, label=None):
@@ -188,6 +219,15 @@ def multi_atlas_streams_leg(ctx, shape, spacing, device, rank=0, world=1, per_gp
     return dt, dice, list(getattr(run_segmentation, "last_iar_removed", []))
 
 
+EXCHANGE_LABELS = ["crop_allreduce", "iar_exchange", "fusion_layout", "fusion_allreduce", "fusion_reduce", "contour_allreduce", "other"]
+
+
+def exchange_ms_over_ranks(ranks, mine):
+    """The pipeline's per-label exchange times (projects/multiatlas.py::_Dist), maximum over ranks; a fixed label list so that
+    every rank makes the same collective call."""
+    return ranks.max_dict(mine or {}, EXCHANGE_LABELS)
+
+
 def cpu_baseline(fixed, moving, spacing, budget_s=15.0):
     """The reference's CPU path timed beside the GPU, on the metric's own configuration (the full bench pair, not a crop).
     SimpleITK (the reference's own arithmetic) is used when importable; otherwise the oracle (C/OpenMP restatement, fp64
@@ -272,6 +312,23 @@ class Ranks:
         self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
         return float(tt.item())
 
+    def count(self):
+        """Ranks taking part in the job's collectives: an all_reduce(SUM) of ones (collective: every rank calls it)."""
+        if not self.dist:
+            return 1
+        tt = torch.ones(1, dtype=torch.float32, device=self._cdev())
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.SUM)
+        return int(round(float(tt.item())))
+
+    def max_dict(self, d, keys):
+        """Element-wise maximum over ranks of d[k] for the given keys (missing -> 0); collective."""
+        vals = [float(d.get(k, 0.0)) for k in keys]
+        if self.dist and keys:
+            tt = torch.tensor(vals, dtype=torch.float64, device=self._cdev())
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            vals = [float(v) for v in tt.tolist()]
+        return dict(zip(keys, vals))
+
     def gather(self, x):
         """-> every rank's value, in rank order (on every rank)."""
         if not self.dist:
@@ -313,6 +370,8 @@ def main():
     ap.add_argument("--no-registration", action="store_true")
     ap.add_argument("--no-atlas", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="time the region without the per-launch HIP events (no roofline block)")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed block of --steps iterations is run this many times; `value` and "
+                    "`ms_per_step` are the MEDIAN block's, min / max are reported beside it (boxes differ by several per cent run to run)")
     ap.add_argument("--pmc-calibration", action="store_true",
                     help="first run two kernels with known byte counts (16 B/lane and 4 B/lane), so that a rocprofv3 --pmc pass of this "
                          "command can calibrate FETCH_SIZE / WRITE_SIZE as MI355X_MICROARCH.md prescribes (tools/gpu_pmc2.sh)")
@@ -363,7 +422,16 @@ def main():
     torch.cuda.synchronize()
     ctx.profile_enable(not args.no_kernel_events)
     p.iterations = args.steps
-    dt, per_rank, balance = ranks.timed(lambda: ctx.demons_execute(fixed, moving, geom, p, field, want_stats=False), torch.cuda.synchronize)
+    # The timed region -- exactly --steps iterations between barrier + synchronize on both sides, maximum over ranks -- is
+    # run --repeats times; the MEDIAN block is the one reported (per-kernel HIP events accumulate over all of them).
+    blocks = []
+    for _ in range(max(1, args.repeats)):
+        blocks.append(ranks.timed(lambda: ctx.demons_execute(fixed, moving, geom, p, field, want_stats=False), torch.cuda.synchronize))
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
+    dt, per_rank, balance = blocks[order[len(order) // 2]]
+    repeats = {"n": len(blocks), "ms_per_step_min": blocks[order[0]][0] * 1e3 / args.steps,
+               "ms_per_step_median": dt * 1e3 / args.steps, "ms_per_step_max": blocks[order[-1]][0] * 1e3 / args.steps,
+               "reported": "median"}
     prof = ctx.profile_read()
     ctx.profile_enable(False)
 
@@ -386,13 +454,7 @@ def main():
         # profiles/round2_pmc.json, which names the commit and the raw counter file it was reduced from; FETCH_SIZE
         # calibrated as MI355X_MICROARCH.md prescribes).  Counters cannot be read inside an untraced run, so the figure
         # is attached only when the committed capture is of this size and these kernels.
-        pmc = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round2_pmc.json")))
-            if list(pmc["size"]) != [nx, ny, nz]:
-                pmc = None
-        except (OSError, ValueError, KeyError):
-            pmc = None
+        pmc = load_pmc(nx, ny, nz)
         if pmc:
             for name, k in kernels.items():
                 tb = pmc.get("hbm_bytes_per_launch", {}).get(name)
@@ -405,8 +467,9 @@ def main():
             traffic = pmc.get("hbm_bytes_per_launch", {}).get(dom) if pmc else None
             roofline = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": a / HBM_PEAK_GBS, "traffic": traffic,
-                        "traffic_source": ({"file": "profiles/round2_pmc.json", "commit": pmc.get("commit"),
-                                            "raw": pmc.get("raw")} if traffic else None),
+                        "traffic_source": ({"file": pmc.get("_file"), "commit": pmc.get("commit"), "raw": pmc.get("raw"),
+                                            "kernel_source_sha16": pmc.get("kernel_source_sha16")} if traffic else
+                                           {"note": "no committed PMC capture of these kernel sources (sha %s)" % kernel_source_sha16()}),
                         "bytes_model": "compulsory (inputs once + outputs once of the schedule that runs)",
                         "algorithmic_bytes_per_launch": kernels[dom]["compulsory_bytes_per_voxel"] * nvox,
                         "avg_launch_ms": kernels[dom]["avg_ms"],
@@ -435,6 +498,7 @@ def main():
                                    f"{nx}x{ny}x{nz} fp32 CT-like pair per GPU, sigma_u 1.0 vox, sigma_d 1.5 mm, "
                                    f"schedule {args.variant}", "parallelism": f"1 atlas-to-target registration per GPU x{world}"},
             "ranks": balance,
+            "repeats": repeats,
             "roofline": roofline,
             "roofline_iteration": {"achieved": iter_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": iter_gbps / HBM_PEAK_GBS,
                                    "compulsory_bytes_per_voxel": iter_bytes,
@@ -478,14 +542,19 @@ def main():
             watchdog.start()
         try:
             dt_a, nvox_label, dice_a = multi_atlas_leg(ctx, fixed, moving, spacing, rank, world, device)
+            rs = __import__("platipy_amd").projects.multiatlas.run_segmentation
+            xms = exchange_ms_over_ranks(ranks, getattr(rs, "last_exchange_ms", {}))
             if world > 1:
                 dt_a = max_over_ranks(dt_a)
             if rank == 0:
                 out["multi_atlas"] = {"atlases": world, "atlases_per_gpu": 1, "structures": 1, "seconds": dt_a,
                                       "atlases_per_min": 60.0 * world / dt_a, "fused_label_voxels": nvox_label,
                                       "dice_vs_template_label": dice_a,
-                                      "fusion_allreduce_bytes": getattr(__import__("platipy_amd").projects.multiatlas.run_segmentation,
-                                                                        "last_fusion_payload_bytes", None),
+                                      "fusion_allreduce_bytes": getattr(rs, "last_fusion_payload_bytes", None),
+                                      # where an N > 1 run's time goes besides the chains: every exchange of the pipeline,
+                                      # milliseconds, maximum over ranks (0 at N = 1: nothing is exchanged)
+                                      "fusion_allreduce_ms": xms.get("fusion_allreduce", 0.0), "crop_allreduce_ms": xms.get("crop_allreduce", 0.0),
+                                      "iar_exchange_ms": xms.get("iar_exchange", 0.0), "exchange_ms": xms,
                                       "settings": "multiatlas/run.py defaults (affine GD-line-search 16/8/4 x50; demons isotropic "
                                                   "6/3/1.5 mm x150/125/100; local vote), atlases resident in HBM"}
         except Exception as e:
@@ -493,10 +562,13 @@ def main():
                 out["multi_atlas"] = f"failed: {e!r}"
         try:
             dt_s, dice_s, removed = multi_atlas_streams_leg(ctx, (nz, ny, nx), spacing, device, rank, world)
+            xms = exchange_ms_over_ranks(ranks, getattr(__import__("platipy_amd").projects.multiatlas.run_segmentation, "last_exchange_ms", {}))
             if world > 1:
                 dt_s = max_over_ranks(dt_s)
             if rank == 0:
                 out["multi_atlas_streams"] = {"atlases": 4 * world, "atlases_per_gpu": 4, "hip_streams": 4, "seconds": dt_s,
+                                              "fusion_allreduce_ms": xms.get("fusion_allreduce", 0.0), "iar_exchange_ms": xms.get("iar_exchange", 0.0),
+                                              "exchange_ms": xms,
                                               "atlases_per_min": 60.0 * 4 * world / dt_s, "dice_vs_template_label": dice_s,
                                               "iterative_atlas_removal": ("on, removed %s" % removed) if 4 * world >= 8 else "off (< 8 atlases)",
                                               "settings": "as multi_atlas; 4 independent atlas warps per GPU, chains overlapped on 4 HIP "
@@ -507,6 +579,10 @@ def main():
         if watchdog is not None:
             watchdog.cancel()
 
+    if rank == 0:
+        out["rccl_ranks"] = ranks.count()     # ranks that answered an all_reduce of ones (1 without a process group)
+    else:
+        ranks.count()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fixed, moving, spacing)

@@ -848,17 +848,21 @@ int fused_shape(const pp_dims& d, int slots0, int slots1) {
 // with sigma_u (radius RA) and the field with sigma_d (radius RB), so each runs the narrowest template that fits.
 template <int R, int OPT, int SH>
 int occ_force() {
+  static int cache = 0;
+  if (cache) return cache;
   int a = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fused_force_smooth<R, OPT, SH>, TILE_OUT / OPT, 0) != hipSuccess) a = 2;
   (void)hipGetLastError();
-  return a < 1 ? 1 : a;
+  return cache = (a < 1 ? 1 : a);
 }
 template <int R, int OPT, int SH>
 int occ_warp() {
+  static int cache = 0;
+  if (cache) return cache;
   int a = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_fused_add_smooth_warp<R, OPT, SH>, TILE_OUT / OPT, 0) != hipSuccess) a = 2;
   (void)hipGetLastError();
-  return a < 1 ? 1 : a;
+  return cache = (a < 1 ? 1 : a);
 }
 
 #define PP_BY_RADIUS(R, OPT, CALL)                                                                   \
@@ -920,27 +924,31 @@ int launch_warp(pp_ctx* ctx, int sh, const float* D, const float* Us, const floa
 #define PP_B2_KERNEL(SHV, SUMV, NTV) k_fused2_add_smooth_warp<R, SHV, (R <= PP_RING_UNROLL_MAX_R), SUMV, NTV>
 
 template <int R>
-int occ_force2(int sh) {   // (the SUM variant holds six more registers; both stay in the same occupancy tier)
+int occ_force2(int sh) {   // (cached: the answer depends on the kernel binary only, and the query costs ~10 us per call)
+  static int cache[2] = {0, 0};
+  if (cache[sh ? 1 : 0]) return cache[sh ? 1 : 0];
   int a = 0;
   const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(1, true, false), 512, 0)
                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(0, true, false), 512, 0);
   if (e != hipSuccess) a = 2;
   (void)hipGetLastError();
-  return a < 1 ? 1 : a;
+  return cache[sh ? 1 : 0] = (a < 1 ? 1 : a);
 }
 template <int R>
-int occ_warp2(int sh) {
+int occ_warp2(int sh) {   // (cached: the answer depends on the kernel binary only, and the query costs ~10 us per call)
+  static int cache[2] = {0, 0};
+  if (cache[sh ? 1 : 0]) return cache[sh ? 1 : 0];
   int a = 0;
   const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(1, true, false), 512, 0)
                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(0, true, false), 512, 0);
   if (e != hipSuccess) a = 2;
   (void)hipGetLastError();
-  return a < 1 ? 1 : a;
+  return cache[sh ? 1 : 0] = (a < 1 ? 1 : a);
 }
 template <int R>
 int launch_force2(pp_ctx* ctx, int sh, bool sum, const float* F, const float* Mw_in, const float* D, float* Us, const fused_args& fu,
                   const pp_esm_consts& K, double* partials, pp_dev_stats* st, const double* prev, int nprev, double max_rms) {
-  pp_prof_scope ps(ctx, "k_fused2_force_smooth");
+  pp_prof_scope ps(ctx, sum ? "k_fused2_force_smooth" : "k_fused2_force_smooth/sep");   // (bench.py keys its byte model on the name)
   const dim3 grid(8u * (unsigned)fu.per_xcd), block(512);
 #define PP_GO(SHV, SUMV, NTV) \
   hipLaunchKernelGGL((PP_A2_KERNEL(SHV, SUMV, NTV)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, st, prev, nprev, max_rms)
@@ -957,7 +965,7 @@ int launch_force2(pp_ctx* ctx, int sh, bool sum, const float* F, const float* Mw
 template <int R>
 int launch_warp2(pp_ctx* ctx, int sh, bool sum, const float* D, const float* Us, const float* M, float* Dn, float* Mw_out,
                  const fused_args& fd, const pp_warp_scale& sc, const int* halt) {
-  pp_prof_scope ps(ctx, "k_fused2_add_smooth_warp");
+  pp_prof_scope ps(ctx, sum ? "k_fused2_add_smooth_warp" : "k_fused2_add_smooth_warp/sep");
   const dim3 grid(8u * (unsigned)fd.per_xcd), block(512);
 #define PP_GO(SHV, SUMV, NTV) hipLaunchKernelGGL((PP_B2_KERNEL(SHV, SUMV, NTV)), grid, block, 0, ctx->stream, D, Us, M, Dn, Mw_out, fd, sc, halt)
   if (!sum) {

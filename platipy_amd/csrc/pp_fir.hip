@@ -178,13 +178,13 @@ __global__ void __launch_bounds__(NT) k_fir_march(const float* __restrict__ in, 
   auto load = [&](int q, float (&v)[VEC]) {
     q = q < 0 ? 0 : (q > len - 1 ? len - 1 : q);
     const size_t a = base + (size_t)q * stride;
-    if (VEC == 4) {
+    if constexpr (VEC == 4) {
       float4 t = *reinterpret_cast<const float4*>(in + a);
       if (ADD) {
         const float4 u = *reinterpret_cast<const float4*>(add + a);
         t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
       }
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[VEC - 1] = t.w;
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     } else {
       v[0] = in[a];
       if (ADD) v[0] += add[a];
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(NT) k_fir_march(const float* __restrict__ in, 
 #pragma unroll
           for (int v = 0; v < VEC; ++v) acc[v] = fmaf(taps.w[k], win[(u + 1 + k) % W][v], acc[v]);
         const size_t a = base + (size_t)pos * stride;
-        if (VEC == 4) *reinterpret_cast<float4*>(out + a) = make_float4(acc[0], acc[1], acc[2], acc[VEC - 1]);
+        if constexpr (VEC == 4) *reinterpret_cast<float4*>(out + a) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         else out[a] = acc[0];
       }
     }

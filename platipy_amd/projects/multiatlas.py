@@ -103,7 +103,9 @@ QUICK_REG_SETTINGS = {  # multiatlas/run.py:205-215
 
 
 class _Dist:
-    """torch.distributed when initialised, a single-rank stand-in otherwise."""
+    """torch.distributed when initialised, a single-rank stand-in otherwise.  Every exchange is timed under a label
+    (`timings`: label -> milliseconds, summed): CUDA events on the current stream for device tensors -- no host
+    synchronisation is added, the events are read when `timings_ms()` is asked for -- perf_counter for host tensors (gloo)."""
 
     def __init__(self):
         import torch.distributed as dist
@@ -111,15 +113,48 @@ class _Dist:
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.rank = self.dist.get_rank() if self.dist else 0
         self.world = self.dist.get_world_size() if self.dist else 1
+        self._events, self._host_ms, self.label = [], {}, "other"
+
+    def _timed(self, t, fn):
+        if not self.dist:
+            return fn()
+        if t.is_cuda:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn()
+            b.record()
+            self._events.append((self.label, a, b))
+            return out
+        import time
+
+        t0 = time.perf_counter()
+        out = fn()
+        self._host_ms[self.label] = self._host_ms.get(self.label, 0.0) + 1e3 * (time.perf_counter() - t0)
+        return out
+
+    def timings_ms(self):
+        """label -> total milliseconds spent in that label's exchanges on this rank (synchronises the recorded events)."""
+        out = dict(self._host_ms)
+        for label, a, b in self._events:
+            b.synchronize()
+            out[label] = out.get(label, 0.0) + a.elapsed_time(b)
+        return out
 
     def all_reduce_sum(self, t):
         if self.dist:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            self._timed(t, lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM))
+        return t
+
+    def reduce_sum_to_root(self, t):
+        """SUM onto rank 0 (the `RCCL reduce` of north_star): half the ring traffic of an all_reduce; other ranks' buffers
+        hold partial sums afterwards and must not be used."""
+        if self.dist:
+            self._timed(t, lambda: self.dist.reduce(t, dst=0, op=self.dist.ReduceOp.SUM))
         return t
 
     def all_reduce_min(self, t):
         if self.dist:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+            self._timed(t, lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN))
         return t
 
     def all_gather(self, t):
@@ -127,7 +162,7 @@ class _Dist:
         if not self.dist:
             return [t]
         out = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(out, t)
+        self._timed(t, lambda: self.dist.all_gather(out, t))
         return out
 
 
@@ -184,28 +219,36 @@ def _mask_outside(image, mask, outside_value):
     return image.like(torch.where(mask != 0, t, torch.full((), outside_value, dtype=t.dtype, device=t.device)))
 
 
-def run_segmentation(img, settings=MUTLIATLAS_SETTINGS_DEFAULTS, atlases=None, streams_per_gpu=1, return_atlas_set=False):
+def run_segmentation(img, settings=MUTLIATLAS_SETTINGS_DEFAULTS, atlases=None, streams_per_gpu=1, return_atlas_set=False,
+                     fusion_collective="all_reduce"):
     """Runs the atlas-based segmentation (reference multiatlas/run.py:106-441).
 
     img: target Image (replicated on every rank).  atlases: {atlas_id: {"CT Image": Image, <structure>: Image}}
     holding at least this rank's share (atlas_id_list[rank::world_size]); a rank may hold them all.
-    Returns (results, results_prob): {structure: uint8 Image}, {structure: fp32 probability Image}, on every rank.
+    Returns (results, results_prob): {structure: uint8 Image}, {structure: fp32 probability Image}.
+    fusion_collective: "all_reduce" (default) -- every rank receives the sums, finalises identically and returns the
+    results; "reduce" -- the sums go to rank 0 only (an RCCL reduce: half the xGMI bytes), rank 0 alone finalises and
+    returns the results, the other ranks return empty dicts (the reference's single caller is rank 0).
     """
-    out = atlas_pipeline(img, settings, None, atlases, streams_per_gpu, cardiac=False)
+    out = atlas_pipeline(img, settings, None, atlases, streams_per_gpu, cardiac=False, fusion_collective=fusion_collective)
     run_segmentation.last_iar_removed = out["iar_removed"]
     run_segmentation.last_fusion_payload_bytes = out["fusion_payload_bytes"]
+    run_segmentation.last_exchange_ms = out["exchange_ms"]
+    run_segmentation.last_world_size = out["world_size"]
     if return_atlas_set:
         return out["results"], out["results_prob"], out["atlas_set"]
     return out["results"], out["results_prob"]
 
 
-def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_per_gpu=1, cardiac=False):
+def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_per_gpu=1, cardiac=False, fusion_collective="all_reduce"):
     """The skeleton shared by run_segmentation (multiatlas/run.py:106-441) and run_cardiac_segmentation
     (cardiac/run.py:507-1147): read atlases -> crop the target -> per atlas [linear -> (structure-guided demons)
     -> demons -> propagate] -> (iterative atlas removal) -> weight maps -> fuse -> threshold -> paste back ->
     post-process.  `cardiac` selects the cardiac pipeline's result conventions (only structures with an
     optimal_threshold are voted, the guide structure is handed back, return_as_cropped).
     Returns a dict: results, results_prob, atlas_set, iar_removed, img_crop."""
+    if fusion_collective not in ("all_reduce", "reduce"):
+        raise ValueError("fusion_collective must be 'all_reduce' or 'reduce'")
     img = as_image(img)
     settings = copy.deepcopy(settings)
     dd = _Dist()
@@ -263,6 +306,7 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
         acc = torch.zeros(img.shape, dtype=torch.float32, device=device)
         for t in _map_atlases(quick, mine, streams_per_gpu, device).values():
             acc += t
+        dd.label = "crop_allreduce"
         dd.all_reduce_sum(acc)
         combined = img.like(((acc / float(len(crop_ids))) > -1000).to(torch.uint8))
         crop_box_size, crop_box_index = label_to_roi(combined, expansion_mm=expansion_mm)
@@ -328,6 +372,7 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
     if ref_struct:
         from ..label.iar import run_iar, run_iar_distributed
 
+        dd.label = "iar_exchange"
         if dd.world > 1:
             # every rank scores its own atlases; consensus, distance samples and Q values are exchanged (label/iar.py)
             weights = {i: float(compute_weight_map(img_crop, atlas_set[i]["DIR"]["CT Image"], vote_type="global").tensor.flatten()[0])
@@ -355,6 +400,7 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
     # Payload of the one data-path collective.  When every atlas (on every rank) carries every structure the weight sum is
     # the same for all structures, so the buffer is [sum w, sum w L_1 .. sum w L_S] = (1 + S) volumes; an atlas
     # that lacks a structure does not vote on it (fusion.py:263-276), which needs a weight sum per structure: 2 S volumes.
+    dd.label = "fusion_layout"
     complete = torch.tensor([1 if all(s in atlas_set[a]["DIR"] for a in my_ids for s in atlas_structure_list) else 0],
                             dtype=torch.int32, device=device if dd.dist is None or dd.dist.get_backend() == "nccl" else "cpu")
     shared_wsum = bool(int(dd.all_reduce_min(complete).item()))
@@ -368,8 +414,18 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
                 ctx.fuse_accumulate(w, label_tensor(d[s]), buf[0] if k == 0 else None, buf[1 + k], n)
             elif s in d:
                 ctx.fuse_accumulate(w, label_tensor(d[s]), buf[2 * k], buf[2 * k + 1], n)
-    dd.all_reduce_sum(buf)
+    dd.label = "fusion_allreduce" if fusion_collective == "all_reduce" else "fusion_reduce"
+    if fusion_collective == "all_reduce":
+        dd.all_reduce_sum(buf)
+    else:
+        dd.reduce_sum_to_root(buf)
     fusion_payload_bytes = buf.numel() * 4
+    dd.label = "other"
+    root_only = fusion_collective == "reduce" and dd.world > 1
+    if root_only and dd.rank != 0:      # the sums live on rank 0: nothing to finalise here
+        del buf
+        return {"results": {}, "results_prob": {}, "atlas_set": atlas_set, "iar_removed": removed, "img_crop": img_crop,
+                "fusion_payload_bytes": fusion_payload_bytes, "exchange_ms": dd.timings_ms(), "world_size": dd.world}
     combined_label_dict = {s: finalize_probability(ctx, img_crop, buf[0] if shared_wsum else buf[2 * k], buf[1 + k] if shared_wsum else buf[2 * k + 1])
                            for k, s in enumerate(atlas_structure_list)}
     del buf
@@ -394,6 +450,9 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
                     enc |= (process_probability_image(atlas_set[a]["DIR"][s], 0.5).tensor != 0).to(torch.int64) << (pos + 1)
             if len(atlas_id_list) > 32:
                 raise ValueError("You can only encode a maximum of 32 structures with this method!")
+            if root_only:
+                raise NotImplementedError("return_proba_as_contours gathers every rank's contours: use fusion_collective='all_reduce'")
+            dd.label = "contour_allreduce"
             dd.all_reduce_sum(enc)
             prob = img_crop.like(enc)
             template_p = img.like(torch.zeros(img.shape, dtype=prob.tensor.dtype, device=device))
@@ -429,4 +488,4 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
     if as_cropped:
         results["CROP_IMAGE"] = img_crop
     return {"results": results, "results_prob": results_prob, "atlas_set": atlas_set, "iar_removed": removed, "img_crop": img_crop,
-            "fusion_payload_bytes": fusion_payload_bytes}
+            "fusion_payload_bytes": fusion_payload_bytes, "exchange_ms": dd.timings_ms(), "world_size": dd.world}

@@ -7,6 +7,8 @@ Deviations, all deliberate and visible:
   * the displacement field is computed in fp32 (the reference keeps sitkVectorFloat64); the tolerance against the
     fp64 restatement is stated and tested in tests/; `field_dtype=torch.float64` returns it in the reference's type;
   * `ncores` is accepted and ignored (it set ITK's CPU thread count);
+  * iteration observers (`verbose=True`, AddCommand) fire after each level's Execute, once per iteration that ran, with the
+    per-iteration metric the device recorded (the loop itself never returns to the host);
   * non-identity direction cosines (axis flips / oblique acquisitions): the registration runs in the image's
     own index-aligned frame -- every stage is linear in the field and the pyramid grids share one origin and
     one direction, so this is the same computation -- and the field is rotated back to physical (LPS)
@@ -20,6 +22,13 @@ from ..image import Image, as_image, cast_tensor, to_sitk
 from .. import runtime
 from ..transform import DisplacementFieldTransform, sitkLinear
 from .utils import resample_field, resample_image, smooth_and_resample, transform_to_displacement_field
+
+
+class _IterationView:
+    """The filter's measurements as an sitkIterationEvent observer sees them after iteration `elapsed_iterations`."""
+
+    def __init__(self, elapsed, metric, rms_change):
+        self.elapsed_iterations, self.metric, self.rms_change = elapsed, metric, rms_change
 
 
 class HipDemonsFilter:
@@ -83,7 +92,10 @@ class HipDemonsFilter:
         self._max_error = float(v)
 
     def AddCommand(self, event, fn):
-        """Iteration callbacks cannot fire inside the on-device loop; they run once after Execute."""
+        """registration_method.AddCommand(sitk.sitkIterationEvent, fn) (reference deformable.py:260-264).  The loop runs on the
+        device without host round trips, so the observers fire after Execute -- once per iteration that ran, in order, with
+        GetElapsedIterations() / GetMetric() / GetRMSChange() answering what they answered at that iteration's event (the
+        kernel that closes an iteration keeps the values in a device ring, pp_demons_history)."""
         self._commands.append(fn)
 
     # measurements
@@ -123,9 +135,13 @@ class HipDemonsFilter:
         p.max_kernel_width = self._max_kernel_width
         p.variant = self._variant
         field = torch.empty((3,) + f.shape, dtype=torch.float32, device=ft.device)
-        self._stats = ctx.demons_execute(ft, mt, f.geom(), p, field, want_stats=True)
-        for fn in self._commands:
-            fn()
+        final = ctx.demons_execute(ft, mt, f.geom(), p, field, want_stats=True)
+        if self._commands:
+            for k, (metric, rms) in enumerate(ctx.demons_history()):
+                self._stats = _IterationView(k + 1, metric, rms)
+                for fn in self._commands:
+                    fn()
+        self._stats = final
         out = Image(field, f.spacing, f.origin, f.direction, True)
         return to_sitk(out) if wants_sitk else out
 

@@ -24,8 +24,9 @@ trajectory is not a goal for this stage; it is judged by final metric / transfor
     smoothed with ITK's Gaussian operator of variance 1.5; the derivative differences the smoothed log-PDFs between
     neighbouring moving-bin centres -- this build's estimator under ITK's parameters, not a restatement of ITK's
     interpolated-PDF derivative).  Intensity ranges are taken over the whole images (ITK: inside the masks);
-  * the "exhaustive" optimiser walks the reference's grid (2 x 10 + 1 steps per parameter, step length 1 in units of
-    the physical-shift scales) in batches of 16 evaluations per launch; grids above EXHAUSTIVE_MAX_EVALUATIONS raise
+  * the "exhaustive" optimiser walks the grid of SetOptimizerAsExhaustive (2 n_i + 1 steps per parameter, step length in
+    units of the physical-shift scales) in batches of 16 evaluations per launch; numberOfSteps defaults to the reference's
+    six tens and can be passed (exhaustive_steps); grids above exhaustive_max_evaluations (EXHAUSTIVE_MAX_EVALUATIONS) raise
     instead of running for days (the reference itself says "use is not currently recommended").
 """
 import numpy as np
@@ -407,7 +408,7 @@ def _golden_section(fbatch, a, b, c, eps=0.01, max_iter=20, depth=None):
     return (c + a) / 2.0
 
 
-def _exhaustive(ms, model, params, number_of_steps, step_length, verbose):
+def _exhaustive(ms, model, params, number_of_steps, step_length, verbose, max_evaluations=None):
     """itk::ExhaustiveOptimizerv4 as SetOptimizerAsExhaustive(numberOfSteps, stepLength=1.0) drives it (reference
     linear.py:215-222): every point of the grid initial + (k_i - n_i) * stepLength * scale_i, k_i = 0 .. 2 n_i, with the
     optimiser scales from physical shift; the best point wins.  Evaluated 16 grid points per launch."""
@@ -416,9 +417,10 @@ def _exhaustive(ms, model, params, number_of_steps, step_length, verbose):
         raise ValueError(f"exhaustive: numberOfSteps has {len(number_of_steps)} entries, the transform has {n} parameters "
                          "(ITK raises here too; the reference passes six)")
     total = int(np.prod([2 * k + 1 for k in number_of_steps], dtype=np.float64))
-    if total > EXHAUSTIVE_MAX_EVALUATIONS:
-        raise ValueError(f"exhaustive: the grid has {total:,} points (> EXHAUSTIVE_MAX_EVALUATIONS = {EXHAUSTIVE_MAX_EVALUATIONS:,}); "
-                         "the reference would evaluate them one by one -- reduce the steps or raise the limit")
+    limit = EXHAUSTIVE_MAX_EVALUATIONS if max_evaluations is None else int(max_evaluations)
+    if total > limit:
+        raise ValueError(f"exhaustive: the grid has {total:,} points (> EXHAUSTIVE_MAX_EVALUATIONS = {limit:,}); the reference would "
+                         "evaluate them one by one -- pass fewer exhaustive_steps or a larger exhaustive_max_evaluations")
     scales = ms.scales(model, params)
     base = np.asarray(params, dtype=np.float64)
     best_v, best_p = float("inf"), base.copy()
@@ -461,10 +463,19 @@ def linear_registration(
     number_of_iterations=50,
     default_value=None,
     verbose=False,
+    exhaustive_steps=None,
+    exhaustive_step_length=1.0,
+    exhaustive_max_evaluations=None,
 ):
     """Initial linear registration between two images (reference registration/linear.py:50-260).
 
     Returns (registered_image, CompositeTransform([initial_centering_transform, optimised_transform])).
+
+    The last three arguments are extensions for optimiser="exhaustive" (the reference hard-codes numberOfSteps = [10] * 6 at
+    linear.py:221, 21^6 = 85.8 M evaluations on a six-parameter model, and says itself that "use is not currently
+    recommended"): `exhaustive_steps` = SetOptimizerAsExhaustive's numberOfSteps, one entry per transform parameter
+    (default: the reference's six tens), `exhaustive_step_length` its stepLength, `exhaustive_max_evaluations` the largest
+    grid this call may walk (default EXHAUSTIVE_MAX_EVALUATIONS; the reference's own grid needs 85_766_121).
     """
     fixed_image, moving_image = as_image(fixed_image), as_image(moving_image)
     moving_image_type = moving_image.tensor.dtype
@@ -528,7 +539,8 @@ def linear_registration(
             continue
 
         if opt == "exhaustive":
-            params = _exhaustive(ms, model, params, [10, 10, 10, 10, 10, 10], 1.0, verbose)     # linear.py:215-222
+            steps = [10, 10, 10, 10, 10, 10] if exhaustive_steps is None else [int(k) for k in exhaustive_steps]     # linear.py:215-222
+            params = _exhaustive(ms, model, params, steps, float(exhaustive_step_length), verbose, exhaustive_max_evaluations)
             continue
 
         if NATIVE_OPTIMISER and type(model) in _NATIVE_MODEL and ms.bins is None:

@@ -38,7 +38,9 @@ def _split_transform(transform, reference):
         A, off = CompositeTransform(parts).matrix_offset()
         return A, off, None
     if len(fields) > 1 or fields[0] != len(parts) - 1:
-        raise NotImplementedError("a displacement field is supported alone or as the first-applied (last-listed) member of a composite")
+        # any sitk.Transform may reach apply_transform (reference registration/utils.py:176-190): fields anywhere in the
+        # composite, several of them, each on its own grid -> one total displacement field on the reference grid
+        return None, None, _total_field(parts, reference)
     dvf = parts[-1].field
     if not dvf.same_grid(reference):
         dvf = resample_field(dvf, reference)
@@ -50,6 +52,39 @@ def _split_transform(transform, reference):
     At = torch.tensor(A, dtype=torch.float32, device=f.device)
     f = torch.einsum("rc,czyx->rzyx", At, f).contiguous()
     return A, off, f
+
+
+def _total_field(parts, reference):
+    """D(p) = T(p) - p on `reference`'s grid for T = parts[0] o parts[1] o ... (the LAST member is applied first), members
+    linear or displacement-field transforms in any order.  A field member F maps q -> q + F(q), with F interpolated
+    linearly on ITS grid and zero outside it (itk::DisplacementFieldTransform); the running map is kept as p + D(p)."""
+    ctx = runtime.context(reference.device)
+    geom = reference.geom()
+    A, off, D = np.eye(3), np.zeros(3), None        # pending linear map q = A p + off while no field has been applied yet
+    for part in reversed(parts):
+        if not isinstance(part, DisplacementFieldTransform):
+            a, o = part.matrix_offset()
+            if D is None:
+                A, off = a @ A, a @ off + o
+            else:   # q' = a (p + D) + o  ->  D' = (a - I) p + o + a D
+                aD = torch.einsum("rc,czyx->rzyx", torch.tensor(a, dtype=torch.float32, device=D.device), D).contiguous()
+                out = torch.empty_like(D)
+                ctx.transform_to_field(geom, a, o, aD, out)
+                D = out
+            continue
+        if D is None:
+            D = torch.empty((3,) + reference.shape, dtype=torch.float32, device=reference.device)
+            ctx.transform_to_field(geom, A, off, None, D)        # (A - I) p + off; zeros for the identity
+        F = part.field
+        Ft = (F.tensor if F.tensor.dtype == torch.float32 else F.tensor.float()).contiguous()
+        if F.same_grid(reference):
+            ctx.compose_field(D, Ft, geom)                       # D(p) += F(p + D(p))
+        else:   # the member's own grid: each component sampled at p + D(p), linear, 0 outside
+            add = torch.empty_like(D)
+            for c in range(3):
+                ctx.resample(Ft[c].contiguous(), F.geom(), geom, add[c], field=D, interp=_lib.INTERP_LINEAR, default_value=0.0, u8=False)
+            D = D + add
+    return D
 
 
 def transform_to_displacement_field(transform, reference):

@@ -20,8 +20,12 @@ def _worker(rank, world, port, out_dir):
         assert ranks.rank == rank
         dt, per_rank, balance = ranks.timed(lambda: time.sleep(0.05 + 0.10 * rank), lambda: None)
         mx = ranks.max(float(rank + 1))
+        # the N > 1 line's diagnostic keys: ranks that answer a collective, per-label exchange times (maximum over ranks)
+        n = ranks.count()
+        xms = bench.exchange_ms_over_ranks(ranks, {"fusion_allreduce": 1.0 + rank, "iar_exchange": 5.0 - 4.0 * rank})
         if rank == 0:
-            json.dump({"dt": dt, "per_rank": per_rank, "balance": balance, "max": mx}, open(os.path.join(out_dir, "r.json"), "w"))
+            json.dump({"dt": dt, "per_rank": per_rank, "balance": balance, "max": mx, "rccl_ranks": n, "xms": xms},
+                      open(os.path.join(out_dir, "r.json"), "w"))
     finally:
         ranks.close()
 
@@ -37,6 +41,9 @@ def test_ranks_skeleton_two_processes_gloo(tmp_path):
     assert r["dt"] >= max(r["per_rank"]) - 1e-3                     # the job's time is the slowest rank's (plus the barrier)
     assert r["balance"]["slowest_rank"] == 1 and r["balance"]["imbalance"] > 0.2
     assert r["balance"]["per_rank_s"] == r["per_rank"]
+    assert r["rccl_ranks"] == 2
+    assert r["xms"]["fusion_allreduce"] == 2.0 and r["xms"]["iar_exchange"] == 5.0 and r["xms"]["crop_allreduce"] == 0.0
+    assert set(r["xms"]) == set(__import__("bench").EXCHANGE_LABELS)
 
 
 def test_ranks_skeleton_single_process():
@@ -45,6 +52,8 @@ def test_ranks_skeleton_single_process():
     ranks = bench.Ranks(1, torch.device("cpu"))
     dt, per_rank, balance = ranks.timed(lambda: time.sleep(0.01), lambda: None)
     assert len(per_rank) == 1 and dt >= 0.01 and balance["imbalance"] == 0.0 and ranks.max(3.0) == 3.0
+    assert ranks.count() == 1 and bench.exchange_ms_over_ranks(ranks, {"fusion_allreduce": 2.5})["fusion_allreduce"] == 2.5
+    assert len(bench.kernel_source_sha16()) == 16 and bench.load_pmc(1, 2, 3) is None
     ranks.close()
 
 

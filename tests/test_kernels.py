@@ -666,3 +666,32 @@ def test_fused_kernels_on_interior_tiles(backend, sentinels, monkeypatch):
     assert err.max() <= 2e-3 and np.sqrt((err ** 2).mean()) <= 5e-5
     assert out["2"][3] == wst.n_pixels
     np.testing.assert_allclose(out["2"][1], wst.metric, rtol=1e-4)
+
+
+@pytest.mark.parametrize("variant", [_lib.DEMONS_STAGED, _lib.DEMONS_FUSED])
+def test_demons_history_is_what_an_iteration_observer_reads(backend, variant):
+    """pp_demons_history: entry k = GetMetric() / GetRMSChange() after iteration k + 1 (deformable.py:260-264,
+    registration/utils.py:36-41), kept on the device by the kernel that closes each iteration.  Checked against runs that
+    stop after k + 1 iterations, and with the early halt."""
+    shape, spacing, origin = GRIDS[1]
+    fix = phantom(shape, seed=40)
+    dv = random_dvf(shape, spacing, seed=41, max_mm=2.5)
+    mov = O.warp_image(O.Vol(fix, spacing, origin), dv.astype(np.float64), edge_value=-1000.0).arr.astype(np.float32)
+    g = geom_of(shape, spacing, origin)
+    p = _demons_params(backend.ctx, 5, spacing, variant, max_rms=0.0)
+    f = backend.empty((3,) + shape)
+    st = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), g, p, f)
+    hist = backend.ctx.demons_history()
+    assert len(hist) == st.elapsed_iterations == 5
+    assert hist[-1] == (st.metric, st.rms_change)
+    for k in (1, 3):
+        pk = _demons_params(backend.ctx, k, spacing, variant, max_rms=0.0)
+        sk = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), g, pk, f)
+        assert hist[k - 1] == (sk.metric, sk.rms_change)
+        assert len(backend.ctx.demons_history()) == k
+    assert hist[0][0] > hist[-1][0]                 # the metric falls
+    # early halt: the history ends where the loop did
+    ph = _demons_params(backend.ctx, 5, spacing, variant, max_rms=0.5 * (hist[1][1] + hist[2][1]))
+    sh = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), g, ph, f)
+    hh = backend.ctx.demons_history()
+    assert sh.halted and len(hh) == sh.elapsed_iterations == 3 and hh == hist[:3]

@@ -407,3 +407,12 @@ def test_exhaustive_optimiser_walks_the_grid(host_api):
         L._exhaustive(ms, model, np.zeros(3), [10] * 6, 1.0, False)         # the reference's six steps on a 3-parameter model
     with pytest.raises(ValueError, match="EXHAUSTIVE_MAX_EVALUATIONS"):
         pa.registration.linear_registration(f, m, reg_method="rigid", optimiser="exhaustive", shrink_factors=[1], smooth_sigmas=[0])
+    # ... and through the L2 function: numberOfSteps per parameter passed in, the known shift found on the grid
+    _, tfm = pa.registration.linear_registration(f, m, reg_method="translation", optimiser="exhaustive", shrink_factors=[1], smooth_sigmas=[0],
+                                                 sampling_rate=1.0, exhaustive_steps=[3, 3, 3])
+    A, off = tfm.matrix_offset()
+    np.testing.assert_allclose(A, np.eye(3), atol=1e-12)
+    np.testing.assert_allclose(off, [1.0, -2.0, 0.0], atol=1e-9)
+    _, tfm6 = pa.registration.linear_registration(f, m, reg_method="rigid", optimiser="exhaustive", shrink_factors=[2], smooth_sigmas=[0],
+                                                  sampling_rate=1.0, exhaustive_steps=[1, 1, 1, 2, 2, 2])     # 27 * 125 grid points
+    assert np.linalg.norm(np.asarray(tfm6.matrix_offset()[1]) - [1.0, -2.0, 0.0]) < 1.5

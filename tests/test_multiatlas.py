@@ -97,6 +97,20 @@ def _worker(rank, world, port, out_dir):
         assert pa.projects.multiatlas.run_segmentation.last_fusion_payload_bytes == 3 * 4 * crop_voxels and crop_voxels > 1000
         np.save(os.path.join(out_dir, f"wh_{rank}.npy"), results["WHOLEHEART"].numpy())
         np.save(os.path.join(out_dir, f"prob_{rank}.npy"), prob["WHOLEHEART"].numpy())
+        # every exchange is timed under its label (bench.py's N > 1 line reports them)
+        ms = pa.projects.multiatlas.run_segmentation.last_exchange_ms
+        assert {"crop_allreduce", "fusion_allreduce", "fusion_layout"} <= set(ms) and all(v >= 0.0 for v in ms.values()), ms
+        assert pa.projects.multiatlas.run_segmentation.last_world_size == world
+        # the same job with the sums reduced onto rank 0 only (north_star's "RCCL reduce"): rank 0 gets the identical
+        # result, the other rank an empty one
+        r2, p2 = pa.projects.multiatlas.run_segmentation(target, _settings(ids), atlases=mine, fusion_collective="reduce")
+        ms2 = pa.projects.multiatlas.run_segmentation.last_exchange_ms
+        assert "fusion_reduce" in ms2 and "fusion_allreduce" not in ms2
+        if rank == 0:
+            assert np.array_equal(r2["WHOLEHEART"].numpy(), results["WHOLEHEART"].numpy())
+            assert np.array_equal(p2["WHOLEHEART"].numpy(), prob["WHOLEHEART"].numpy())
+        else:
+            assert r2 == {} and p2 == {}
     finally:
         dist.destroy_process_group()
 

@@ -300,3 +300,74 @@ def test_bspline_interpolation_matches_scipy(host_api):
                                                                             resolution_staging=[2, 1], iteration_staging=[3, 3],
                                                                             interp_order=pa.sitkBSpline)
     assert np.isfinite(d3.numpy()).all() and ((fix - img3.numpy()) ** 2).mean() < ((fix - mov) ** 2).mean()
+
+
+def test_apply_transform_general_composites(host_api):
+    """Any composite reaches apply_transform (reference registration/utils.py:176-190): displacement fields in any position,
+    more than one, on grids other than the reference's.  Checked against the total map built with scipy
+    (map_coordinates, order 1, zero outside a field's domain) and the oracle's resample through that field."""
+    from scipy.ndimage import map_coordinates
+
+    pa = host_api
+    shape, spacing, origin = (14, 22, 30), (1.0, 1.2, 2.0), (5.0, -3.0, 1.0)
+    img = phantom(shape, seed=6)
+    f1 = random_dvf(shape, spacing, seed=70, max_mm=2.5)                     # on the image grid
+    g2_shape, g2_sp, g2_or = (9, 12, 16), (2.1, 2.3, 3.4), (3.0, -4.0, 0.5)  # a coarser grid of its own
+    f2 = random_dvf(g2_shape, g2_sp, seed=71, max_mm=3.0)
+    ang = 0.06
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+    lin = pa.AffineTransform(R * 1.02, (0.8, -0.4, 0.3), (18.0, 9.0, 12.0))
+    F1 = pa.DisplacementFieldTransform(pa.image_from_array(f1, spacing, origin, is_vector=True))
+    F2 = pa.DisplacementFieldTransform(pa.image_from_array(f2, g2_sp, g2_or, is_vector=True))
+    comp = pa.CompositeTransform([F1, lin, F2])            # F2 first, then the linear map, then F1
+    ref = pa.image_from_array(np.zeros(shape, np.float32), spacing, origin)
+
+    def field_at(f, sp, org, q):      # linear interpolation of a planar field at physical points q [3, ...], zero outside
+        idx = [(q[a] - org[a]) / sp[a] for a in range(3)]
+        return np.stack([map_coordinates(f[c].astype(np.float64), [idx[2], idx[1], idx[0]], order=1, mode="constant", cval=0.0) for c in range(3)])
+
+    zz, yy, xx = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing="ij")
+    p = np.stack([origin[0] + spacing[0] * xx, origin[1] + spacing[1] * yy, origin[2] + spacing[2] * zz])
+    q = p + field_at(f2, g2_sp, g2_or, p)
+    A, off = lin.matrix_offset()
+    q = np.einsum("rc,czyx->rzyx", A, q) + off.reshape(3, 1, 1, 1)
+    q = q + field_at(f1, spacing, origin, q)
+    want_field = q - p
+    got_field = pa.registration.utils.transform_to_displacement_field(comp, ref).numpy()
+    # (ITK's buffer test lets a sample within half a voxel OUTSIDE a field's grid read its clamped edge value, scipy's
+    # constant mode blends towards zero there: compare where every sample lies inside the grids)
+    inside = np.ones(shape, bool)
+    for f_sp, f_or, f_shape, pts in ((g2_sp, g2_or, g2_shape, p), (spacing, origin, shape, q - field_at(f1, spacing, origin, q))):
+        for a in range(3):
+            c = (pts[a] - f_or[a]) / f_sp[a]
+            inside &= (c >= 0) & (c <= f_shape[2 - a] - 1)
+    assert inside.mean() > 0.3
+    np.testing.assert_allclose(got_field[:, inside], want_field[:, inside], rtol=0, atol=2e-4)
+    got = pa.registration.apply_transform(pa.image_from_array(img, spacing, origin), ref, comp, -1000, pa.sitkLinear)
+    want = O.apply_transform(O.Vol(img, spacing, origin), O.Vol(np.zeros(shape, np.float32), spacing, origin),
+                             field_vol=O.Vol(got_field.astype(np.float64), spacing, origin), default_value=-1000, interpolator=O.INTERP_LINEAR)
+    np.testing.assert_allclose(got.numpy(), want.arr, rtol=0, atol=5e-3)
+    # two fields on the reference grid, nothing between them: D = F_b + F_a(p + F_b)
+    comp2 = pa.CompositeTransform([F1, F1])
+    d2 = pa.registration.utils.transform_to_displacement_field(comp2, ref).numpy()
+    q2 = p + field_at(f1, spacing, origin, p)
+    want2 = q2 + field_at(f1, spacing, origin, q2) - p
+    in2 = np.ones(shape, bool)
+    for a in range(3):
+        c = (q2[a] - origin[a]) / spacing[a]
+        in2 &= (c >= 0) & (c <= shape[2 - a] - 1)
+    np.testing.assert_allclose(d2[:, in2], want2[:, in2], rtol=0, atol=2e-4)
+
+
+def test_verbose_registration_prints_one_line_per_iteration(host_api, capsys):
+    """verbose=True (reference deformable.py:260-264, registration/utils.py:36-41): the observer prints
+    "{elapsed:3} = {metric:10.5f}" after every iteration of every level, metrics falling within a level."""
+    pa = host_api
+    shape, spacing, origin = (12, 20, 36), (1.0, 1.1, 2.0), (10.0, -20.0, 5.0)
+    fix, mov = _pair(shape, spacing, origin, seed=100)
+    pa.registration.fast_symmetric_forces_demons_registration(pa.image_from_array(fix, spacing, origin), pa.image_from_array(mov, spacing, origin),
+                                                              resolution_staging=[2, 1], iteration_staging=[3, 4], verbose=True)
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if " = " in ln]
+    assert [int(ln.split("=")[0]) for ln in lines] == [1, 2, 3, 1, 2, 3, 4]
+    metrics = [float(ln.split("=")[1]) for ln in lines]
+    assert metrics[0] > metrics[2] and metrics[3] > metrics[6]
