@@ -19,21 +19,22 @@ constexpr int NT = 256;
 template <int AXIS, int VEC, bool ADD>
 __global__ void __launch_bounds__(NT) k_conv_axis(const float* __restrict__ in, const float* __restrict__ add,
                                                   float* __restrict__ out, pp_dims d, size_t cstride, pp_taps taps,
-                                                  const int* __restrict__ halt, const uint8_t* __restrict__ need_y,
-                                                  const uint8_t* __restrict__ need_z) {
+                                                  const int* __restrict__ halt, const int* __restrict__ rows, int use_y, int use_z) {
   if (halt && *halt) return;
   const size_t comp = (size_t)blockIdx.y * cstride;
   in += comp;
   out += comp;
   if (ADD) add += comp;
   const int nxv = d.nx / VEC;
-  const size_t total = (size_t)nxv * d.ny * d.nz;
+  // sparse mode (`rows`, see k_compact_rows): only the listed y / z are produced -- the work items are enumerated over the
+  // LISTS, so no thread is launched for a row that is never read
+  const int nys = (rows && use_y) ? rows[0] : d.ny, nzs = (rows && use_z) ? rows[1] : d.nz;
+  const size_t total = (size_t)nxv * nys * nzs;
   const int r = taps.r;
   for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
     const int xv = (int)(e % nxv);
-    const int y = (int)((e / nxv) % d.ny);
-    const int z = (int)(e / ((size_t)nxv * d.ny));
-    if ((need_y && !need_y[y]) || (need_z && !need_z[z])) continue;   // sparse mode: this output row is never read
+    const int yi = (int)((e / nxv) % nys), zi = (int)(e / ((size_t)nxv * nys));
+    const int y = (rows && use_y) ? rows[2 + yi] : yi, z = (rows && use_z) ? rows[2 + d.ny + zi] : zi;
     const size_t row = ((size_t)z * d.ny + y) * d.nx;
     if (AXIS == 0) {
       float s = 0.0f;
@@ -86,22 +87,22 @@ __global__ void __launch_bounds__(NT) k_conv_axis(const float* __restrict__ in, 
 template <bool ADD>
 __global__ void __launch_bounds__(NT) k_conv_x4(const float* __restrict__ in, const float* __restrict__ add,
                                                 float* __restrict__ out, pp_dims d, size_t cstride, pp_taps taps,
-                                                const int* __restrict__ halt, const uint8_t* __restrict__ need_y,
-                                                const uint8_t* __restrict__ need_z) {
+                                                const int* __restrict__ halt, const int* __restrict__ rows, int use_y, int use_z) {
   if (halt && *halt) return;
   const size_t comp = (size_t)blockIdx.y * cstride;
   in += comp;
   out += comp;
   if (ADD) add += comp;
   const int nxv = d.nx / 4;
-  const size_t total = (size_t)nxv * d.ny * d.nz;
+  const int nys = (rows && use_y) ? rows[0] : d.ny, nzs = (rows && use_z) ? rows[1] : d.nz;   // (sparse mode: see k_conv_axis)
+  const size_t total = (size_t)nxv * nys * nzs;
   const int r = taps.r;
   const int r4 = (r + 3) / 4 * 4;
   for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
     const int x0 = (int)(e % nxv) * 4;
-    const size_t rowi = e / nxv;
-    if ((need_y && !need_y[rowi % d.ny]) || (need_z && !need_z[rowi / d.ny])) continue;
-    const size_t row = rowi * (size_t)d.nx;
+    const int yi = (int)((e / nxv) % nys), zi = (int)(e / ((size_t)nxv * nys));
+    const int y = (rows && use_y) ? rows[2 + yi] : yi, z = (rows && use_z) ? rows[2 + d.ny + zi] : zi;
+    const size_t row = ((size_t)z * d.ny + y) * (size_t)d.nx;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     for (int o = -r4; o < 4 + r4; o += 4) {           // chunk covers inputs x0 + o .. x0 + o + 3
       float v[4];
@@ -139,6 +140,22 @@ __global__ void __launch_bounds__(NT) k_conv_x4(const float* __restrict__ in, co
   }
 }
 
+
+// rows[0] = number of needed y, rows[1] = number of needed z, rows[2 ..] = the needed y in order, rows[2 + ny ..] = the
+// needed z (one block; a few hundred entries).
+__global__ void k_compact_rows(const uint8_t* __restrict__ need_y, int ny, const uint8_t* __restrict__ need_z, int nz, int* __restrict__ rows) {
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (int y = 0; y < ny; ++y)
+      if (need_y[y]) rows[2 + n++] = y;
+    rows[0] = n;
+  } else if (threadIdx.x == 64) {
+    int n = 0;
+    for (int z = 0; z < nz; ++z)
+      if (need_z[z]) rows[2 + ny + n++] = z;
+    rows[1] = n;
+  }
+}
 
 // ---------------------------------------------------------------------------------------
 // Register-window passes along y / z (radius <= 16) and a wavefront-shuffle pass along x (radius <= 16).
@@ -330,9 +347,9 @@ void launch_x_shfl(pp_ctx* ctx, const float* in, const float* add, float* out, c
 
 template <int AXIS, bool ADD>
 int launch_axis(pp_ctx* ctx, const float* in, const float* add, float* out, const pp_dims& d, int ncomp,
-                const pp_taps& taps, const int* halt, const uint8_t* need_y = nullptr, const uint8_t* need_z = nullptr) {
+                const pp_taps& taps, const int* halt, const int* rows = nullptr, int use_y = 0, int use_z = 0) {
   const bool al16 = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | (ADD ? reinterpret_cast<uintptr_t>(add) : 0)) % 16 == 0);
-  if (!need_y && !need_z && !getenv("PP_FIR_LEGACY")) {
+  if (!rows && !getenv("PP_FIR_LEGACY")) {
     const int r = taps.r;
     if (AXIS != 0) {
       const bool v4 = al16 && (d.nx % 4 == 0);
@@ -361,8 +378,9 @@ int launch_axis(pp_ctx* ctx, const float* in, const float* add, float* out, cons
       ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | (ADD ? reinterpret_cast<uintptr_t>(add) : 0)) % 16 == 0)) {
     size_t blocks = (cstride / 4 + NT - 1) / NT;
     if (blocks > 65535u * 4u) blocks = 65535u * 4u;
+    if (rows && blocks > 4096) blocks = 4096;   // the number of listed rows is known on the device only: grid-stride over them
     hipLaunchKernelGGL((k_conv_x4<ADD>), dim3((unsigned)blocks, (unsigned)ncomp, 1), dim3(NT, 1, 1), 0, ctx->stream, in, add, out, d,
-                       cstride, taps, halt, need_y, need_z);
+                       cstride, taps, halt, rows, use_y, use_z);
     PP_LAUNCH_CHECK(ctx, "k_conv_x4");
     return PP_OK;
   }
@@ -371,12 +389,13 @@ int launch_axis(pp_ctx* ctx, const float* in, const float* add, float* out, cons
   const size_t work = cstride / (vec4 ? 4 : 1);
   size_t blocks = (work + NT - 1) / NT;
   if (blocks > 65535u * 4u) blocks = 65535u * 4u;
+  if (rows && blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
   const dim3 grid((unsigned)blocks, (unsigned)ncomp, 1), block(NT, 1, 1);
   if (vec4)
-    hipLaunchKernelGGL((k_conv_axis<AXIS, 4, ADD>), grid, block, 0, ctx->stream, in, add, out, d, cstride, taps, halt, need_y, need_z);
+    hipLaunchKernelGGL((k_conv_axis<AXIS, 4, ADD>), grid, block, 0, ctx->stream, in, add, out, d, cstride, taps, halt, rows, use_y, use_z);
   else
-    hipLaunchKernelGGL((k_conv_axis<AXIS, 1, ADD>), grid, block, 0, ctx->stream, in, add, out, d, cstride, taps, halt, need_y, need_z);
+    hipLaunchKernelGGL((k_conv_axis<AXIS, 1, ADD>), grid, block, 0, ctx->stream, in, add, out, d, cstride, taps, halt, rows, use_y, use_z);
   PP_LAUNCH_CHECK(ctx, "k_conv_axis");
   return PP_OK;
 }
@@ -464,16 +483,19 @@ int pp_discrete_gaussian_rows_f32(pp_ctx* ctx, const float* in, float* out, cons
     if (rc) return rc;
   }
   const size_t N = pp_nvox(size);
-  int rc = pp_reserve(ctx, 2 * pp_align_up(N * sizeof(float), 256));
+  int rc = pp_reserve(ctx, 2 * pp_align_up(N * sizeof(float), 256) + pp_align_up((2 + (size_t)d.ny + d.nz) * sizeof(int), 256));
   if (rc) return rc;
   pp_carver cv{ctx->ws, 0};
   float* t1 = cv.take<float>(N);
   float* t2 = cv.take<float>(N);
-  rc = launch_axis<2, false>(ctx, in, nullptr, t1, d, 1, taps[2], nullptr, nullptr, need_z);
+  int* rows = cv.take<int>(2 + (size_t)d.ny + d.nz);
+  hipLaunchKernelGGL(k_compact_rows, dim3(1), dim3(128), 0, ctx->stream, need_y, d.ny, need_z, d.nz, rows);
+  PP_LAUNCH_CHECK(ctx, "k_compact_rows");
+  rc = launch_axis<2, false>(ctx, in, nullptr, t1, d, 1, taps[2], nullptr, rows, 0, 1);
   if (rc) return rc;
-  rc = launch_axis<1, false>(ctx, t1, nullptr, t2, d, 1, taps[1], nullptr, need_y, need_z);
+  rc = launch_axis<1, false>(ctx, t1, nullptr, t2, d, 1, taps[1], nullptr, rows, 1, 1);
   if (rc) return rc;
-  return launch_axis<0, false>(ctx, t2, nullptr, out, d, 1, taps[0], nullptr, need_y, need_z);
+  return launch_axis<0, false>(ctx, t2, nullptr, out, d, 1, taps[0], nullptr, rows, 1, 1);
 }
 
 int pp_smooth_field_f32(pp_ctx* ctx, float* field, const int size[3], const double sigma_vox[3], double max_error,

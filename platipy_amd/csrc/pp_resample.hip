@@ -574,6 +574,9 @@ int pp_compose_field_f32(pp_ctx* ctx, float* total, const float* iter, const pp_
   if (!pp_geom_identity_dir(g)) return pp_fail(ctx, PP_ERR_UNSUPPORTED, "pp_compose_field_f32: identity direction only");
   const pp_dims d{g->size[0], g->size[1], g->size[2]};
   const pp_warp_scale sc{(float)(1.0 / g->spacing[0]), (float)(1.0 / g->spacing[1]), (float)(1.0 / g->spacing[2])};
+  // (measured, round 3: four voxels per thread with 16-byte accesses of `total` and the twelve corner loads of a voxel pair in
+  // flight together ran 1.43 ms against this kernel's 1.14 ms at 512 x 512 x 256 -- one voxel per thread keeps more gathers
+  // of more wavefronts in flight.)
   const pp_grid3 g3 = grid3_for(d.nx, d.ny, d.nz);
   hipLaunchKernelGGL(k_compose_same_grid, g3.grid, g3.block, 0, ctx->stream, total, iter, d, sc);
   PP_LAUNCH_CHECK(ctx, "k_compose_same_grid");

@@ -29,12 +29,15 @@ struct pp_warp_pending {
   float wx, wy, wz;
   unsigned flags;   // bit 0: inside the buffer, bit 1: x0 is the last index
 };
-__device__ __forceinline__ void fused2_warp_issue(const char* rm, const pp_warp_dims& wd, int xi, float dvx, int yi, float dvy, int zi,
-                                                  float dvz, bool lane_ok, pp_warp_pending& g) {
-  // pp_split and pp_inside1 in straight-line form.  The displacement is clamped to +-2^23 voxels first (one v_med3; also
-  // catches NaN): beyond that the sample is outside any volume this kernel takes (nx, ny, nz < 2^22) either way, and the
-  // integer conversions below stay defined.  ITK's buffer test [-0.5, n - 0.5) on the continuous index is
-  // 0 <= round-half-up index <= n - 1, and the round-half-up index is base + (frac >= 0.5).
+// The address half of a sample on its own -- byte offsets of the four x-pairs, the three weights, the flags -- so that
+// several volumes on the same grid (the three components of a displacement field) are gathered through one computation.
+struct pp_warp_addr {
+  unsigned o00, o10, o01, o11;
+  float wx, wy, wz;
+  unsigned flags;
+};
+__device__ __forceinline__ void fused2_warp_setup(const pp_warp_dims& wd, int xi, float dvx, int yi, float dvy, int zi, float dvz,
+                                                  bool lane_ok, pp_warp_addr& a) {
   const float LIM = 8388608.0f;
   const float cvx = fminf(fmaxf(dvx, -LIM), LIM), cvy = fminf(fmaxf(dvy, -LIM), LIM), cvz = fminf(fmaxf(dvz, -LIM), LIM);
   const float flx = floorf(cvx), fly = floorf(cvy), flz = floorf(cvz);
@@ -42,25 +45,45 @@ __device__ __forceinline__ void fused2_warp_issue(const char* rm, const pp_warp_
   const float fx = cvx - flx, fy = cvy - fly, fz = cvz - flz;
   const int nx_ = bx + (fx >= 0.5f ? 1 : 0), ny_ = by + (fy >= 0.5f ? 1 : 0), nz_ = bz + (fz >= 0.5f ? 1 : 0);
   const bool inside = lane_ok & ((unsigned)nx_ < (unsigned)wd.nx) & ((unsigned)ny_ < (unsigned)wd.ny) & ((unsigned)nz_ < (unsigned)wd.nz);
-  // pp_axis_setup, with the base index also clamped from above so that outside lanes still form valid addresses
   const int x0 = pp_clampi(bx, 0, wd.nx - 1), y0 = pp_clampi(by, 0, wd.ny - 1), z0 = pp_clampi(bz, 0, wd.nz - 1);
-  g.wx = bx < 0 ? 0.0f : fx;
-  g.wy = by < 0 ? 0.0f : fy;
-  g.wz = bz < 0 ? 0.0f : fz;
-  // byte offsets of the 8 corners; the upper corner of an axis repeats the lower one on the last index (ITK's clamp).
-  // 24-bit multiplies (full rate): z0 * ny + y0 < 2^24 and nx * 4 < 2^24 are checked on the host.
+  a.wx = bx < 0 ? 0.0f : fx;
+  a.wy = by < 0 ? 0.0f : fy;
+  a.wz = bz < 0 ? 0.0f : fz;
   const unsigned r00 = __umul24(__umul24((unsigned)z0, (unsigned)wd.ny) + (unsigned)y0, wd.nx4);
   const unsigned dy = y0 < wd.ny - 1 ? wd.nx4 : 0u, dz = z0 < wd.nz - 1 ? wd.sz4 : 0u;
-  const unsigned r10 = r00 + dy, r01 = r00 + dz, r11 = r01 + dy;
-  // The two x corners of a row come from ONE 8-byte load: it starts at min(x0, nx - 2), so on the last index (where
-  // ITK's upper corner repeats the lower one) both corners are its second element and nothing is read past the row.
   const bool xlast = x0 > wd.nx - 2;
   const unsigned c0 = (unsigned)(xlast ? wd.nx - 2 : x0) * 4u;
-  g.p00 = pp_gld2(rm, r00 + c0);
-  g.p10 = pp_gld2(rm, r10 + c0);
-  g.p01 = pp_gld2(rm, r01 + c0);
-  g.p11 = pp_gld2(rm, r11 + c0);
-  g.flags = (inside ? 1u : 0u) | (xlast ? 2u : 0u);
+  a.o00 = r00 + c0;
+  a.o10 = r00 + dy + c0;
+  a.o01 = r00 + dz + c0;
+  a.o11 = r00 + dz + dy + c0;
+  a.flags = (inside ? 1u : 0u) | (xlast ? 2u : 0u);
+}
+__device__ __forceinline__ void fused2_warp_load(const char* rm, const pp_warp_addr& a, pp_warp_pending& g) {
+  g.p00 = pp_gld2(rm, a.o00);
+  g.p10 = pp_gld2(rm, a.o10);
+  g.p01 = pp_gld2(rm, a.o01);
+  g.p11 = pp_gld2(rm, a.o11);
+  g.wx = a.wx;
+  g.wy = a.wy;
+  g.wz = a.wz;
+  g.flags = a.flags;
+}
+
+// One trilinear sample of the warp in two halves: `issue` forms the addresses and starts the four 8-byte loads, `finish`
+// lerps.  (pp_split and pp_inside1 in straight-line form, in fused2_warp_setup: the displacement is clamped to +-2^23
+// voxels first -- one v_med3; also catches NaN -- beyond that the sample is outside any volume this kernel takes (nx, ny,
+// nz < 2^22) either way and the integer conversions stay defined.  ITK's buffer test [-0.5, n - 0.5) on the continuous
+// index is 0 <= round-half-up index <= n - 1, and the round-half-up index is base + (frac >= 0.5).  pp_axis_setup with the
+// base index also clamped from above, so that outside lanes still form valid addresses; the upper corner of an axis
+// repeats the lower one on the last index (ITK's clamp); 24-bit multiplies: z0 * ny + y0 < 2^24 and nx * 4 < 2^24 are
+// checked on the host.  The two x corners of a row come from ONE 8-byte load that starts at min(x0, nx - 2), so on the
+// last index both corners are its second element and nothing is read past the row.)
+__device__ __forceinline__ void fused2_warp_issue(const char* rm, const pp_warp_dims& wd, int xi, float dvx, int yi, float dvy, int zi,
+                                                  float dvz, bool lane_ok, pp_warp_pending& g) {
+  pp_warp_addr a;
+  fused2_warp_setup(wd, xi, dvx, yi, dvy, zi, dvz, lane_ok, a);
+  fused2_warp_load(rm, a, g);
 }
 __device__ __forceinline__ float fused2_warp_finish(const pp_warp_pending& g) {
   const bool xlast = (g.flags & 2u) != 0;

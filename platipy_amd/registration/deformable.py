@@ -176,7 +176,7 @@ def multiscale_demons(registration_algorithm, fixed_image, moving_image, initial
 
     for i in range(len(fixed_images)):
         f_image, m_image = fixed_images[i], moving_images[i]
-        dvf_total = resample_field(dvf_total, f_image)                                           # :137
+        dvf_total = resample_field(dvf_total, f_image, copy=False)                               # :137 (dvf_total is this loop's own)
         # :139-140 -- sitk.Resample(m_image, tfm_total, interp_order): default pixel value 0 (quirk N4)
         m_image = resample_image(m_image, m_image, DisplacementFieldTransform(dvf_total), interp_order, 0.0)
         registration_algorithm.SetNumberOfIterations(iteration_staging[i])
@@ -184,7 +184,7 @@ def multiscale_demons(registration_algorithm, fixed_image, moving_image, initial
         ctx.compose_field(dvf_total.tensor, dvf_iter.tensor.contiguous(), f_image.geom())        # :154
         sigma = registration_algorithm.GetStandardDeviations()                                   # :157
         ctx.recursive_gaussian_field(dvf_total.tensor, f_image.geom(), sigma)                    # :158 (quirk N2)
-    return resample_field(dvf_total, fixed_image)                                                # :185
+    return resample_field(dvf_total, fixed_image, copy=False)                                    # :185
 
 
 def fast_symmetric_forces_demons_registration(

@@ -104,8 +104,14 @@ def transform_to_displacement_field(transform, reference):
     return Image(out, reference.spacing, reference.origin, reference.direction, True)
 
 
-def resample_field(field_image, reference):
-    """sitk.Resample(vector_image, reference): linear, identity transform, default 0."""
+def resample_field(field_image, reference, copy=True):
+    """sitk.Resample(vector_image, reference): linear, identity transform, default 0.  `copy=False`: the caller owns
+    `field_image` and lets the result alias it when no resampling is needed."""
+    if (field_image.same_grid(reference) and field_image.tensor.dtype == torch.float32 and field_image.tensor.is_contiguous()):
+        # the same grid (the finest level's up-sampling and deformable.py:185's final resample): linear interpolation at the
+        # grid points returns the samples; a copy keeps the reference's "new image" semantics (callers update fields in place)
+        t = field_image.tensor.clone() if copy else field_image.tensor
+        return Image(t, reference.spacing, reference.origin, reference.direction, True)
     ctx = runtime.context(field_image.device)
     src = field_image.tensor if field_image.tensor.dtype == torch.float32 else field_image.tensor.float()
     out = torch.empty((3,) + reference.shape, dtype=torch.float32, device=src.device)
@@ -253,6 +259,11 @@ def smooth_and_resample(image, isotropic_voxel_size_mm=None, shrink_factor=None,
 
     if new_size is None:
         return image
+    if (list(new_size) == list(original_size) and interpolator in (sitkLinear, sitkNearestNeighbor)
+            and np.allclose(new_spacing, original_spacing, rtol=1e-12, atol=0.0)):
+        # shrink factor 1 (the finest pyramid level): the output grid IS the input grid -- ((n - 1) s) / (n - 1) can differ from
+        # s in the last bit, a shift of < 1e-9 voxel -- and resampling onto it returns the samples themselves
+        return Image(image.tensor, new_spacing, image.GetOrigin(), image.GetDirection())
     ref = Image(torch.empty((new_size[2], new_size[1], new_size[0]), dtype=torch.float32, device="meta"), new_spacing,
                 image.GetOrigin(), image.GetDirection())
     out = resample_image(image, ref, None, interpolator, 0.0)
