@@ -29,7 +29,13 @@ if "k_ssd_partial" in tab and "FETCH_SIZE" in tab["k_ssd_partial"]:
     cal["fetch_4B"] = 24.0 * n / (tab["k_ssd_partial"]["FETCH_SIZE"] * 1024)
 ff = max(cal.get("fetch_16B", 2.0), cal.get("fetch_4B", 2.0), cal.get("fetch_16B_lib", 2.0))
 fw = max(cal.get("write_16B", 1.0), cal.get("write_16B_lib", 1.0))
-out = {"commit": commit, "size": [nx, ny, nz], "raw": md.replace("gpurun_out/r2/", "profiles/round2_"), "calibration": cal,
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_sha16  # noqa: E402  (the capture is tied to the kernel sources it was taken of)
+
+raw = md.replace("gpurun_out/r2/", "profiles/round2_").replace("gpurun_out/r3final/", "profiles/round3_")
+out = {"commit": commit, "kernel_source_sha16": kernel_source_sha16(), "size": [nx, ny, nz], "raw": raw, "calibration": cal,
        "fetch_factor": ff, "write_factor": fw, "hbm_bytes_per_launch": {}, "fetch_bytes_per_launch": {}, "write_bytes_per_launch": {},
        "tcc_hit_rate": {}}
 for k, c in tab.items():
