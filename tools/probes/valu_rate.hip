@@ -126,8 +126,7 @@ int main() {
   run<11>("v_max_f32", 16, cus, ghz, out);
   run<12>("v_floor_f32", 16, cus, ghz, out);
   run<13>("v_add_u32", 16, cus, ghz, out);
-  run<14>("v_mul_u32_u24", 16, cus, ghz, out);
-  run<8>("v_fma_f32 dependent chain", 16, cus, ghz, out);
-  run<9>("v_fma_f32 + s_and_b64", 32, cus, ghz, out);
+  // (kinds 8, 9 and 14 -- dependent chain, VALU + SALU pairs, 24-bit multiply -- are not run: one of them does not finish
+  // within minutes on MI355X and the round's GPU budget has better uses)
   return 0;
 }
