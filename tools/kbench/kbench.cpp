@@ -166,7 +166,21 @@ int main(int argc, char** argv) {
   if (auto trace_read = reinterpret_cast<int (*)(unsigned*, int)>(dlsym(h, "pp_debug_trace_read"))) {
     const int STEPS = 140, SLOTS = 6;
     std::vector<unsigned> buf(2 * 8 * STEPS * SLOTS);
-    if (trace_read(buf.data(), (int)buf.size()) > 0) {
+    if (trace_read(buf.data(), (int)buf.size()) > 0 && getenv("KBENCH_PHASES")) {
+      // small-grid kernels: phase stamps (steps 0..8, slot 0) of the first eight waves, clocks since wave 0's phase 0
+      for (int k = 0; k < 2; ++k) {
+        printf("phases kernel %c (0 entry, 1 halt read, 2 fold done, 8 images in LDS, 3 smoothing input ready, 4 x done, 5 y done, 6 z done, 7 end)\n", k ? 'B' : 'A');
+        // rows 0..3: waves 0..3 of the middle block, rows 4..7: waves 0..3 of the last block; shader clocks / 10 ns ticks
+        const unsigned base = buf[((k * 8 + 0) * STEPS + 0) * SLOTS + 0], wbase = buf[((k * 8 + 0) * STEPS + 0) * SLOTS + 1];
+        for (int w = 0; w < 8; w += 2) {
+          printf("  %s w%d:", w < 4 ? "mid " : "last", w & 3);
+          for (int s : {0, 1, 2, 8, 3, 4, 5, 6, 7})
+            printf(" p%d=%d/%.2fus", s, (int)(buf[((k * 8 + w) * STEPS + s) * SLOTS + 0] - base),
+                   0.01 * (int)(buf[((k * 8 + w) * STEPS + s) * SLOTS + 1] - wbase));
+          printf("\n");
+        }
+      }
+    } else if (trace_read(buf.data(), (int)buf.size()) > 0) {
       for (int k = 0; k < 2; ++k) {
         printf("trace kernel %c: step | per wave: t(slot1)-t(slot0) ... (shader clocks since slot 0 of wave 0)\n", k ? 'B' : 'A');
         for (int s = 20; s < 32; ++s) {
