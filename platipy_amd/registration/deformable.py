@@ -146,6 +146,11 @@ class HipDemonsFilter:
         return to_sitk(out) if wants_sitk else out
 
 
+def _zero_field(reference):
+    return Image(torch.zeros((3,) + reference.shape, dtype=torch.float32, device=reference.device), reference.spacing,
+                 reference.origin, reference.direction, True)
+
+
 def multiscale_demons(registration_algorithm, fixed_image, moving_image, initial_transform=None,
                       initial_displacement_field=None, isotropic_resample=None, resolution_staging=None,
                       smoothing_sigmas=None, iteration_staging=None, interp_order=sitkLinear):
@@ -169,14 +174,16 @@ def multiscale_demons(registration_algorithm, fixed_image, moving_image, initial
             # :101-108 -- sitk.TransformToDisplacementField(initial_transform, VectorFloat64, fixed grid)
             dvf_total = transform_to_displacement_field(initial_transform, fixed_image)
         else:
-            dvf_total = Image(torch.zeros((3,) + fixed_image.shape, dtype=torch.float32, device=fixed_image.device),
-                              fixed_image.spacing, fixed_image.origin, fixed_image.direction, True)
+            dvf_total = None        # the zero field of :110-123; resampled onto any grid it is that grid's zero field
     else:
         dvf_total = resample_field(as_image(initial_displacement_field), fixed_image)
 
     for i in range(len(fixed_images)):
         f_image, m_image = fixed_images[i], moving_images[i]
-        dvf_total = resample_field(dvf_total, f_image, copy=False)                               # :137 (dvf_total is this loop's own)
+        if dvf_total is None:
+            dvf_total = _zero_field(f_image)       # (not 800 MB of zeros at full resolution resampled onto the coarsest grid)
+        else:
+            dvf_total = resample_field(dvf_total, f_image, copy=False)                           # :137 (dvf_total is this loop's own)
         # :139-140 -- sitk.Resample(m_image, tfm_total, interp_order): default pixel value 0 (quirk N4)
         m_image = resample_image(m_image, m_image, DisplacementFieldTransform(dvf_total), interp_order, 0.0)
         registration_algorithm.SetNumberOfIterations(iteration_staging[i])
@@ -184,6 +191,8 @@ def multiscale_demons(registration_algorithm, fixed_image, moving_image, initial
         ctx.compose_field(dvf_total.tensor, dvf_iter.tensor.contiguous(), f_image.geom())        # :154
         sigma = registration_algorithm.GetStandardDeviations()                                   # :157
         ctx.recursive_gaussian_field(dvf_total.tensor, f_image.geom(), sigma)                    # :158 (quirk N2)
+    if dvf_total is None:
+        return _zero_field(fixed_image)
     return resample_field(dvf_total, fixed_image, copy=False)                                    # :185
 
 

@@ -183,7 +183,14 @@ class ScaleVersor3DTransform(_Parametrised):
 class ScaleSkewVersor3DTransform(_Parametrised):
     """itk::ScaleSkewVersor3DTransform -- parameters: versor (3), translation (3), scale (3), skew (6).  As in
     ScaleVersor3D the scale and the six skew terms are ADDED to the rotation matrix: diagonal += scale_i - 1, off-diagonal
-    entries (0,1) (0,2) (1,0) (1,2) (2,0) (2,1) += skew_0..5 (ScaleSkewVersor3DTransform::ComputeMatrix, additive form)."""
+    entries (0,1) (0,2) (1,0) (1,2) (2,0) (2,1) += skew_0..5 (ScaleSkewVersor3DTransform::ComputeMatrix, additive form).
+
+    Which ITK this reproduces: the 15-parameter class that sitk.ScaleSkewVersor3DTransform wraps in SimpleITK 2.x / ITK 5.x.
+    ITK 5 added a SEPARATE class, ComposeScaleSkewVersor3DTransform (12 parameters: three skews, matrix = rotation * scale
+    * upper-triangular skew), for the composed form and left this one additive for backward compatibility; the reference's
+    reg_method="ScaleSkewVersor" (linear.py:179-180) constructs the 15-parameter class.  No ITK source is available here:
+    this is a recollection (DESIGN.md section 3 lists it with the others) and tools/compare_with_sitk.py is where it gets
+    checked the day a SimpleITK box exists.  pp_linear.hip's PP_MODEL_SCALE_SKEW_VERSOR decodes identically."""
     n_params = 15
 
     def identity_parameters(self):

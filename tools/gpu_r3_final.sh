@@ -5,6 +5,8 @@
 #   gpurun_out/r3final/bench_under_rocprof.json   the bench line of the traced run (HIP-event kernel times to compare)
 #   gpurun_out/r3final/kernel_stats.md            rocprofv3 per-kernel statistics of that run
 #   gpurun_out/r3final/pmc.json / pmc_counters.md calibrated HBM-side bytes per launch + every raw counter
+#   gpurun_out/r3final/standalone_kernels.txt     tools/kbench/sbench: every once-per-level kernel alone, algorithmic GB/s
+#   gpurun_out/r3final/registration_kernels.md    per-kernel breakdown of ONE whole config-2 registration (the second of two)
 set +e
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
@@ -35,3 +37,39 @@ done
 python tools/pmc_summary.py $OUT/pmc $OUT/pmc_counters.md
 python tools/pmc_reduce.py $OUT/pmc_counters.md $COMMIT 512 512 256 > $OUT/pmc.json
 cat $OUT/pmc.json
+
+echo "== stand-alone kernels"
+timeout 300 tools/kbench/sbench platipy_amd/csrc/libplatipy_hip.so 512 512 256 5 > $OUT/standalone_kernels.txt 2>&1
+cat $OUT/standalone_kernels.txt
+echo "== one whole registration, per kernel"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OLDPWD/$OUT/regtrace -o reg -- bash -c "cd $OLDPWD && python tools/profile_registration.py" > $OLDPWD/$OUT/registration_run.log 2>&1 )
+grep registration_s $OUT/registration_run.log
+python - <<PY > $OUT/registration_kernels.md
+import csv, glob, collections, re
+rows = []
+for f in glob.glob("$OUT/regtrace/**/*kernel_trace.csv", recursive=True):
+    rows += list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# tools/profile_registration.py runs the registration twice (warm-up, then timed): the trace's last registration starts at
+# the last launch of the first pyramid kernel sequence -- take the second half of the launches of the demons kernels' span
+fused = [i for i, r in enumerate(rows) if "k_fused2_force_smooth" in r["Kernel_Name"]]
+half = fused[len(fused) // 2]
+# walk back from the first fused launch of the second registration to the start of that registration: the first kernel
+# after the previous registration's last kernel (a gap of more than 1 ms on the device = the host-side synchronize + print)
+start = half
+while start > 0 and int(rows[start]["Start_Timestamp"]) - int(rows[start - 1]["End_Timestamp"]) < 1000000:
+    start -= 1
+sel = rows[start:]
+agg = collections.defaultdict(list)
+for r in sel:
+    m = re.search(r"(k_\w+|__amd\w+|at::native::\w+)", r["Kernel_Name"])
+    agg[m.group(1) if m else r["Kernel_Name"][:60]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+span = (int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])) / 1e3
+tot = sum(sum(v) for v in agg.values())
+print(f"One fast_symmetric_forces_demons_registration at 512x512x256, [8,4,1] x [10,10,10] (second of two runs): {len(sel)} launches, "
+      f"{tot / 1e3:.3f} ms of kernel time inside a device span of {span / 1e3:.3f} ms.\n")
+print("| kernel | calls | total us | avg us | % of kernel time |\n|---|---|---|---|---|")
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+    print(f"| {k} | {len(v)} | {sum(v):.1f} | {sum(v) / len(v):.2f} | {100 * sum(v) / tot:.1f} |")
+PY
+head -30 $OUT/registration_kernels.md
