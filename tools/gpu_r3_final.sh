@@ -73,3 +73,7 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     print(f"| {k} | {len(v)} | {sum(v):.1f} | {sum(v) / len(v):.2f} | {100 * sum(v) / tot:.1f} |")
 PY
 head -30 $OUT/registration_kernels.md
+echo "== randomised parity sweep (HIP vs oracle)"
+timeout 600 python tools/fuzz_parity.py 31 16 > $OUT/fuzz_parity.txt 2>&1; tail -3 $OUT/fuzz_parity.txt
+echo "== configs end to end"
+timeout 900 python tools/run_configs.py > $OUT/configs.txt 2> $OUT/configs.err; cut -c1-300 $OUT/configs.txt
