@@ -142,18 +142,92 @@ __global__ void __launch_bounds__(NT) k_conv_x4(const float* __restrict__ in, co
 
 
 // rows[0] = number of needed y, rows[1] = number of needed z, rows[2 ..] = the needed y in order, rows[2 + ny ..] = the
-// needed z (one block; a few hundred entries).
-__global__ void k_compact_rows(const uint8_t* __restrict__ need_y, int ny, const uint8_t* __restrict__ need_z, int nz, int* __restrict__ rows) {
+// needed z.  One block: the flags of a list go to LDS and every listed entry counts the flags before it (a few hundred
+// entries; the serial form spent 50 us chasing one dependent load per entry).
+constexpr int COMPACT_MAX = 4096;
+__device__ void compact_list(const uint8_t* __restrict__ need, int n, int* __restrict__ dst, int* __restrict__ count, uint8_t* flags) {
+  if (n > COMPACT_MAX) {   // (not a size this path sees: one thread walks the list)
+    if (threadIdx.x == 0) {
+      int c = 0;
+      for (int i = 0; i < n; ++i)
+        if (need[i]) dst[c++] = i;
+      *count = c;
+    }
+    return;
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) flags[i] = need[i] ? 1 : 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    if (!flags[i]) continue;
+    int before = 0;
+    for (int j = 0; j < i; ++j) before += flags[j];
+    dst[before] = i;
+  }
   if (threadIdx.x == 0) {
-    int n = 0;
-    for (int y = 0; y < ny; ++y)
-      if (need_y[y]) rows[2 + n++] = y;
-    rows[0] = n;
-  } else if (threadIdx.x == 64) {
-    int n = 0;
-    for (int z = 0; z < nz; ++z)
-      if (need_z[z]) rows[2 + ny + n++] = z;
-    rows[1] = n;
+    int c = 0;
+    for (int j = 0; j < n; ++j) c += flags[j];
+    *count = c;
+  }
+  __syncthreads();
+}
+__global__ void __launch_bounds__(NT) k_compact_rows(const uint8_t* __restrict__ need_y, int ny, const uint8_t* __restrict__ need_z, int nz,
+                                                     int* __restrict__ rows) {
+  __shared__ uint8_t flags[COMPACT_MAX];
+  compact_list(need_y, ny, rows + 2, rows + 0, flags);
+  compact_list(need_z, nz, rows + 2 + ny, rows + 1, flags);
+}
+
+// ---------------------------------------------------------------------------------------
+// Passes for the pyramid's blur -- sparse outputs (a quarter of the planes and rows are ever read by the resample that
+// follows; radius ~11 / ~21 at sigma 4 / 8 voxels) -- and for dense passes of radius 17 .. 32.
+//
+// y / z (k_fir_march_sp, defined after k_fir_march below): that register-window march with three changes.  The window is longer than
+// the filter by K slots and the load issued at a step lands K steps later, so K loads per thread are in flight (the march
+// is a chain of dependent loads otherwise; an LDS ring per thread was tried first and capped the occupancy at 6 waves per
+// CU: 1.4 TB/s).  The march runs over the EXTENDED line (in[clamp(p)]), so ITK's ZeroFluxNeumann edge needs no case
+// analysis.  And a step forms its output only if the list names it (wavefront-uniform branch): every input is loaded
+// once and only the outputs that are read cost arithmetic.  k_conv_axis, which this replaces here, re-reads 2r + 1 planes
+// per output: with sparse outputs (no reuse between neighbouring outputs in L1) ~6 reads of every plane from the
+// infinity cache.  Taps are padded with zeros to the bucket RB on both sides: fma(0, v, s) = s for finite v and the
+// leading zero taps give +0, the value the sum starts from -- bit-identical to k_conv_axis.
+// x (k_fir_x_row): one extended row per block round in LDS, two adjacent outputs per thread.
+template <int WB>
+__global__ void __launch_bounds__(NT) k_fir_x_row(const float* __restrict__ in, float* __restrict__ out, pp_dims d, size_t cstride, pp_taps taps,
+                                                  const int* __restrict__ halt, const int* __restrict__ rows, int use_y, int use_z) {
+  // The row is staged EXTENDED (r clamped voxels either side, then WB finite pad values), so an output reads 2r + 1
+  // consecutive LDS words at immediate offsets; a thread forms two adjacent outputs from one set of reads.
+  constexpr int ROW_MAX = 4096;
+  __shared__ __attribute__((aligned(16))) float srow[ROW_MAX + 3 * WB + 3];
+  if (halt && *halt) return;
+  in += (size_t)blockIdx.y * cstride;
+  out += (size_t)blockIdx.y * cstride;
+  const int nys = (rows && use_y) ? rows[0] : d.ny, nzs = (rows && use_z) ? rows[1] : d.nz;
+  const int r = taps.r, W = 2 * r + 1;
+  float tw[WB];
+#pragma unroll
+  for (int k = 0; k < WB; ++k) tw[k] = k < W ? taps.w[k] : 0.0f;
+  const int next = d.nx + 2 * r;   // extended row: word e holds in[clamp(e - r)]
+  for (size_t e = blockIdx.x; e < (size_t)nys * nzs; e += gridDim.x) {
+    const int yi = (int)(e % nys), zi = (int)(e / nys);
+    const int y = (rows && use_y) ? rows[2 + yi] : yi, z = (rows && use_z) ? rows[2 + d.ny + zi] : zi;
+    const size_t row = ((size_t)z * d.ny + y) * (size_t)d.nx;
+    for (int q = threadIdx.x; q < next + WB + 2; q += NT) srow[q] = q < next ? in[row + pp_clampi(q - r, 0, d.nx - 1)] : 0.0f;
+    __syncthreads();
+    for (int x = 2 * threadIdx.x; x < d.nx; x += 2 * NT) {
+      const float* const win = srow + x;   // words x .. x + 2r feed output x, x + 1 .. x + 2r + 1 feed output x + 1
+      float a[WB + 1];
+#pragma unroll
+      for (int k = 0; k <= WB; ++k) a[k] = win[k];
+      float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+      for (int k = 0; k < WB; ++k) {
+        s0 = fmaf(tw[k], a[k], s0);
+        s1 = fmaf(tw[k], a[k + 1], s1);
+      }
+      out[row + x] = s0;
+      if (x + 1 < d.nx) out[row + x + 1] = s1;
+    }
+    __syncthreads();
   }
 }
 
@@ -308,6 +382,85 @@ __global__ void __launch_bounds__(NT) k_fir_x_shfl(const float* __restrict__ in,
   }
 }
 
+template <int P>
+struct march_phase { static constexpr int value = P; };
+template <int P, int L>
+struct march_phases {   // step(pb + P, phase P) for P = 0 .. L - 1 while the position stays <= last
+  template <class F>
+  static __device__ __forceinline__ bool run(F& step, int pb, int last) {
+    if (pb + P > last) return false;
+    step(pb + P, march_phase<P>{});
+    return march_phases<P + 1, L>::run(step, pb, last);
+  }
+};
+template <int L>
+struct march_phases<L, L> {
+  template <class F>
+  static __device__ __forceinline__ bool run(F&, int, int) { return true; }
+};
+
+template <int AXIS, int RB, int K>
+__global__ void __launch_bounds__(NT) k_fir_march_sp(const float* __restrict__ in, float* __restrict__ out, pp_dims d, size_t cstride,
+                                                     taps_bucket<RB> taps, const int* __restrict__ halt, const int* __restrict__ rows, int use_y,
+                                                     int use_z, int nseg) {
+  constexpr int W = 2 * RB + 1, L = W + K;
+  if (halt && *halt) return;
+  in += (size_t)blockIdx.z * cstride;
+  out += (size_t)blockIdx.z * cstride;
+  const int len = AXIS == 1 ? d.ny : d.nz;
+  const int other = AXIS == 1 ? d.nz : d.ny;
+  // outputs along the axis and lines across the other one: everything, or the lists of k_compact_rows
+  const int* out_list = nullptr;
+  const int* line_list = nullptr;
+  int nout = len, nlines = other;
+  if (rows) {
+    if (AXIS == 1 ? use_y : use_z) {
+      out_list = AXIS == 1 ? rows + 2 : rows + 2 + d.ny;
+      nout = AXIS == 1 ? rows[0] : rows[1];
+    }
+    if (AXIS == 1 ? use_z : use_y) {
+      line_list = AXIS == 1 ? rows + 2 + d.ny : rows + 2;
+      nlines = AXIS == 1 ? rows[1] : rows[0];
+    }
+  }
+  const size_t total = (size_t)d.nx * nlines;
+  if ((size_t)blockIdx.x * NT >= total) return;
+  const size_t col = (size_t)blockIdx.x * NT + threadIdx.x;
+  const bool valid = col < total;
+  const size_t colc = valid ? col : total - 1;
+  const int x = (int)(colc % d.nx), li = (int)(colc / d.nx);
+  const int line = line_list ? line_list[li] : li;
+  const size_t stride = AXIS == 1 ? (size_t)d.nx : (size_t)d.nx * d.ny;
+  const size_t base = (AXIS == 1 ? (size_t)line * d.nx * d.ny : (size_t)line * d.nx) + x;
+  // this block's share of the outputs (consecutive list entries), marched from its first to its last
+  const int per = (nout + nseg - 1) / nseg;
+  int oi = (int)blockIdx.y * per;
+  const int o_end = oi + per < nout ? oi + per : nout;
+  if (oi >= o_end) return;
+  const int p_first = out_list ? out_list[oi] : oi, p_last = out_list ? out_list[o_end - 1] : o_end - 1;
+  auto ld = [&](int q) { return in[base + (size_t)pp_clampi(q, 0, len - 1) * stride]; };
+  // slot (q - (p_first - RB)) % L holds extended position q; L - 1 of them loaded ahead
+  float win[L];
+#pragma unroll
+  for (int j = 0; j < L - 1; ++j) win[j] = ld(p_first - RB + j);
+  int o_next = p_first;
+  // one step per position; instantiated once per ring phase u (L copies: the slots are renamed, never moved or indexed)
+  auto step = [&](int pos, auto phase) {
+    constexpr int u = decltype(phase)::value;
+    win[(u + L - 1) % L] = ld(pos + RB + K);   // replaces position pos - RB - 1; read K steps from now
+    if (pos == o_next) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < W; ++k) acc = fmaf(taps.w[k], win[(u + k) % L], acc);
+      if (valid) out[base + (size_t)pos * stride] = acc;
+      ++oi;
+      o_next = oi < o_end ? (out_list ? out_list[oi] : oi) : -1;
+    }
+  };
+  for (int pb = p_first; pb <= p_last; pb += L)
+    if (!march_phases<0, L>::run(step, pb, p_last)) break;
+}
+
 template <int RB>
 taps_bucket<RB> bucket_taps(const pp_taps& t) {
   taps_bucket<RB> b;
@@ -362,8 +515,12 @@ int launch_axis(pp_ctx* ctx, const float* in, const float* add, float* out, cons
       if (v4 && r <= 2) PP_MARCH(2, 4);
       if (v4 && r <= 4) PP_MARCH(4, 4);
       if (v4 && r <= 8) PP_MARCH(8, 4);
-      if (r <= 8) PP_MARCH(8, 1);
-      if (r <= 16) PP_MARCH(16, 1);
+      // scalar columns: from radius 9 k_fir_march_sp (loads K steps ahead of their use) is the faster march -- measured
+      // 0.64 -> 0.50 ms for the three passes of a variance-16 blur at 512 x 512 x 256 (r = 13); it has no ADD form
+      if (ADD || r <= 8) {
+        if (r <= 8) PP_MARCH(8, 1);
+        if (r <= 16) PP_MARCH(16, 1);
+      }
 #undef PP_MARCH
     } else if (al16 && (d.nx % 4 == 0) && r <= 16) {
       if (r <= 4) launch_x_shfl<4, ADD>(ctx, in, add, out, d, ncomp, taps, halt);
@@ -374,6 +531,39 @@ int launch_axis(pp_ctx* ctx, const float* in, const float* add, float* out, cons
     }
   }
   const size_t cstride = (size_t)d.nx * d.ny * d.nz;
+  // sparse outputs, or a radius beyond the dense register-window buckets (PP_FIR_MARCH_SP=0 keeps the one-output-per-thread kernels)
+  const char* sp_env = getenv("PP_FIR_MARCH_SP");   // (once per pass of a once-per-level filter)
+  if (!ADD && !(sp_env && atoi(sp_env) == 0) && !getenv("PP_FIR_LEGACY") && taps.r <= 32) {
+    if (AXIS != 0) {
+      const int len = AXIS == 1 ? d.ny : d.nz, other = AXIS == 1 ? d.nz : d.ny;
+      const int W = 2 * taps.r + 1;
+      const unsigned bx = (unsigned)(((size_t)d.nx * other + NT - 1) / NT);
+      // segments of the outputs: enough blocks to fill the chip a few times over, each with >= 4 windows of outputs' inputs
+      int nseg = (int)((1536 + bx - 1) / bx);
+      const int max_seg = len / (4 * W) > 1 ? len / (4 * W) : 1;
+      if (nseg > max_seg) nseg = max_seg;
+      if (nseg < 1) nseg = 1;
+      const dim3 grid(bx, (unsigned)nseg, (unsigned)ncomp);
+#define PP_MSP(RB, KK) hipLaunchKernelGGL((k_fir_march_sp<(AXIS == 0 ? 1 : AXIS), RB, KK>), grid, dim3(NT), 0, ctx->stream, in, out, d, cstride, bucket_taps<RB>(taps), halt, rows, use_y, use_z, nseg)
+      if (taps.r <= 12) PP_MSP(12, 24);
+      else if (taps.r <= 24) PP_MSP(24, 24);
+      else PP_MSP(32, 16);
+#undef PP_MSP
+      PP_LAUNCH_CHECK(ctx, "k_fir_march_sp");
+      return PP_OK;
+    } else if (d.nx <= 4096) {   // (dense x passes of radius <= 16 went to k_fir_x_shfl above)
+      const int W = 2 * taps.r + 1;
+#define PP_XROW(WB) hipLaunchKernelGGL((k_fir_x_row<WB>), dim3(8192, (unsigned)ncomp, 1), dim3(NT), 0, ctx->stream, in, out, d, cstride, taps, halt, rows, use_y, use_z)
+      if (W <= 15) PP_XROW(15);
+      else if (W <= 23) PP_XROW(23);
+      else if (W <= 31) PP_XROW(31);
+      else if (W <= 47) PP_XROW(47);
+      else PP_XROW(65);
+#undef PP_XROW
+      PP_LAUNCH_CHECK(ctx, "k_fir_x_row");
+      return PP_OK;
+    }
+  }
   if (AXIS == 0 && (d.nx % 4 == 0) && taps.r >= 3 &&
       ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | (ADD ? reinterpret_cast<uintptr_t>(add) : 0)) % 16 == 0)) {
     size_t blocks = (cstride / 4 + NT - 1) / NT;
@@ -489,7 +679,7 @@ int pp_discrete_gaussian_rows_f32(pp_ctx* ctx, const float* in, float* out, cons
   float* t1 = cv.take<float>(N);
   float* t2 = cv.take<float>(N);
   int* rows = cv.take<int>(2 + (size_t)d.ny + d.nz);
-  hipLaunchKernelGGL(k_compact_rows, dim3(1), dim3(128), 0, ctx->stream, need_y, d.ny, need_z, d.nz, rows);
+  hipLaunchKernelGGL(k_compact_rows, dim3(1), dim3(NT), 0, ctx->stream, need_y, d.ny, need_z, d.nz, rows);
   PP_LAUNCH_CHECK(ctx, "k_compact_rows");
   rc = launch_axis<2, false>(ctx, in, nullptr, t1, d, 1, taps[2], nullptr, rows, 0, 1);
   if (rc) return rc;

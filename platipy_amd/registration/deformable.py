@@ -49,6 +49,7 @@ class HipDemonsFilter:
         self._intensity_threshold = 0.001
         self._variant = {"auto": _lib.DEMONS_AUTO, "staged": _lib.DEMONS_STAGED, "fused": _lib.DEMONS_FUSED}[variant]
         self._stats = None
+        self._pending = None      # the context whose history ring holds the last Execute's measurements, until they are asked for
         self._commands = []
 
     # configuration, SimpleITK names
@@ -98,14 +99,26 @@ class HipDemonsFilter:
         kernel that closes an iteration keeps the values in a device ring, pp_demons_history)."""
         self._commands.append(fn)
 
-    # measurements
+    # measurements.  Execute does not read them back: that is a host-device round trip per pyramid level with the GPU
+    # idle behind it.  They stay in the context's history ring (pp_demons_history) until one of the getters asks, or until
+    # ANOTHER filter is about to run on the same context (its Execute resolves this one's first).
+    def _resolve(self):
+        ctx, self._pending = self._pending, None
+        if ctx is not None and getattr(ctx, "_demons_owner", None) is self:
+            ctx._demons_owner = None
+            history = ctx.demons_history()
+            self._stats = _IterationView(len(history), *history[-1]) if history else None
+
     def GetElapsedIterations(self):
+        self._resolve()
         return self._stats.elapsed_iterations if self._stats else 0
 
     def GetMetric(self):
+        self._resolve()
         return self._stats.metric if self._stats else float("nan")
 
     def GetRMSChange(self):
+        self._resolve()
         return self._stats.rms_change if self._stats else float("nan")
 
     def Execute(self, fixed_image, moving_image):
@@ -135,13 +148,21 @@ class HipDemonsFilter:
         p.max_kernel_width = self._max_kernel_width
         p.variant = self._variant
         field = torch.empty((3,) + f.shape, dtype=torch.float32, device=ft.device)
-        final = ctx.demons_execute(ft, mt, f.geom(), p, field, want_stats=True)
+        owner = getattr(ctx, "_demons_owner", None)
+        if owner is not None and owner is not self:
+            owner._resolve()
+        self._pending = None
+        # (the ring holds PP_HIST_CAP = 4096 iterations; beyond that, and with observers, the measurements are read back here)
+        lazy = not self._commands and 0 < self._iterations <= 4096
+        final = ctx.demons_execute(ft, mt, f.geom(), p, field, want_stats=not lazy)
         if self._commands:
             for k, (metric, rms) in enumerate(ctx.demons_history()):
                 self._stats = _IterationView(k + 1, metric, rms)
                 for fn in self._commands:
                     fn()
         self._stats = final
+        ctx._demons_owner = self if lazy else None
+        self._pending = ctx if lazy else None
         out = Image(field, f.spacing, f.origin, f.direction, True)
         return to_sitk(out) if wants_sitk else out
 

@@ -97,6 +97,34 @@ def test_fir_register_window_and_shuffle_passes_equal_the_legacy_pass(backend, s
     np.testing.assert_array_equal(res["1"], res[None])
 
 
+@pytest.mark.parametrize("shape", [(19, 26, 40), (33, 41, 48), (12, 70, 300)])
+@pytest.mark.parametrize("variance", [1.0, 16.0, 64.0, 110.0])
+def test_fir_sparse_passes_equal_the_one_output_per_thread_passes(backend, shape, variance, monkeypatch):
+    """The pyramid's blur is produced only on the rows its resample reads (pp_discrete_gaussian_rows_f32).  The passes
+    behind it (k_fir_march_sp: a register window with loads in flight K steps ahead, outputs formed only where the list
+    names them; k_fir_x_row: an extended row in LDS; radius up to 32) form every output with the dense filter's own
+    sequence of fmas: bit-identical, on the listed rows, to the one-output-per-thread kernels (PP_FIR_MARCH_SP=0) and to
+    the dense filter, for lists with gaps, first / last rows, and radii beyond the axis length."""
+    img = phantom(shape, seed=14)
+    size = (shape[2], shape[1], shape[0])
+    rng = np.random.default_rng(int(variance) + shape[0])
+    need_y = (rng.random(shape[1]) < 0.3).astype(np.uint8)
+    need_z = (rng.random(shape[0]) < 0.4).astype(np.uint8)
+    need_y[[0, -1]] = 1
+    need_z[[0, -1]] = 1
+    out = {}
+    for sp in ("0", "1"):
+        monkeypatch.setenv("PP_FIR_MARCH_SP", sp)
+        dst = backend.empty(shape)
+        backend.ctx.discrete_gaussian_rows(backend.dev(img), dst, size, (1.0, 1.0, 1.0), (variance,) * 3, backend.dev(need_y), backend.dev(need_z),
+                                           0.01, 64, True)
+        out[sp] = backend.host(dst)[need_z.astype(bool)][:, need_y.astype(bool)].copy()
+    np.testing.assert_array_equal(out["0"], out["1"])
+    dense = backend.empty(shape)
+    backend.ctx.discrete_gaussian(backend.dev(img), dense, size, (1.0, 1.0, 1.0), (variance,) * 3, 0.01, 64, True)
+    np.testing.assert_array_equal(backend.host(dense)[need_z.astype(bool)][:, need_y.astype(bool)], out["1"])
+
+
 @pytest.mark.parametrize("grid", GRIDS)
 def test_smooth_field(backend, grid):
     shape, spacing, _ = grid

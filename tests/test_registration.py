@@ -371,3 +371,36 @@ def test_verbose_registration_prints_one_line_per_iteration(host_api, capsys):
     assert [int(ln.split("=")[0]) for ln in lines] == [1, 2, 3, 1, 2, 3, 4]
     metrics = [float(ln.split("=")[1]) for ln in lines]
     assert metrics[0] > metrics[2] and metrics[3] > metrics[6]
+
+
+def test_filter_measurements_are_read_on_demand_and_survive_another_filter(host_api):
+    """Execute leaves GetElapsedIterations / GetMetric / GetRMSChange in the context's history ring and reads them when
+    asked (no host-device round trip per pyramid level).  They equal what an observer saw at the last iteration event,
+    and a second filter running on the same context does not overwrite the first one's answers."""
+    pa = host_api
+    from platipy_amd.registration.deformable import HipDemonsFilter
+
+    shape, spacing, origin = (12, 20, 36), (1.0, 1.1, 2.0), (10.0, -20.0, 5.0)
+    fix, mov = _pair(shape, spacing, origin, seed=101)
+    f, m = pa.image_from_array(fix, spacing, origin), pa.image_from_array(mov, spacing, origin)
+    seen = []
+    watched = HipDemonsFilter()
+    watched.SetNumberOfIterations(5)
+    watched.SetMaximumRMSError(0.0)
+    watched.AddCommand(None, lambda: seen.append((watched.GetElapsedIterations(), watched.GetMetric(), watched.GetRMSChange())))
+    watched.Execute(f, m)
+    assert [s[0] for s in seen] == [1, 2, 3, 4, 5]
+    a = HipDemonsFilter()
+    a.SetNumberOfIterations(5)
+    a.SetMaximumRMSError(0.0)
+    a.Execute(f, m)
+    assert a._pending is not None                      # nothing read back yet
+    b = HipDemonsFilter()
+    b.SetNumberOfIterations(2)
+    b.SetMaximumRMSError(0.0)
+    b.Execute(f, m)                                    # same context: resolves a's measurements before its own run
+    assert a._pending is None
+    assert (a.GetElapsedIterations(), a.GetMetric(), a.GetRMSChange()) == seen[4]
+    assert (b.GetElapsedIterations(), b.GetMetric(), b.GetRMSChange()) == seen[1]
+    fresh = HipDemonsFilter()
+    assert fresh.GetElapsedIterations() == 0 and np.isnan(fresh.GetMetric())
