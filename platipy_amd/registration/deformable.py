@@ -280,16 +280,22 @@ def fast_symmetric_forces_demons_registration(
     if not smoothing_sigmas:
         smoothing_sigmas = [i * smoothing_sigma_factor for i in resolution_staging]
 
+    if default_value is None:
+        # CT-like moving image (:286-291).  Asked BEFORE the registration is enqueued: the answer is a host read-back, and
+        # behind the whole registration it would idle the GPU until the host has come back and launched the final resample.
+        mt = moving_image.tensor
+        if mt.dtype == torch.float32 and mt.is_contiguous():
+            lowest = runtime.context(mt.device).minmax(mt, mt.numel())[0]
+        else:
+            lowest = float(mt.min())
+        default_value = -1000 if lowest <= -1000 else 0
+
     deformation_field = multiscale_demons(
         registration_algorithm=registration_method, fixed_image=fixed_image, moving_image=moving_image,
         resolution_staging=resolution_staging, smoothing_sigmas=smoothing_sigmas, iteration_staging=iteration_staging,
         isotropic_resample=isotropic_resample, initial_displacement_field=initial_displacement_field,
         interp_order=interp_order)
 
-    if default_value is None:
-        default_value = 0
-        if float(moving_image.tensor.min()) <= -1000:   # CT-like (:286-291)
-            default_value = -1000
     output_transform = DisplacementFieldTransform(deformation_field)
     registered_image = resample_image(moving_image, fixed_image, output_transform, interp_order, default_value)
     registered_image = registered_image.like(cast_tensor(registered_image.tensor, moving_image_type))

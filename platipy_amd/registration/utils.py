@@ -1,5 +1,6 @@
 """Drop-in for platipy/imaging/registration/utils.py:54-267 (apply_transform, its two wrappers and
 smooth_and_resample), on torch tensors in HBM through the HIP C ABI."""
+import functools
 import logging
 
 import numpy as np
@@ -204,6 +205,17 @@ def _rows_read_by_resample(n_in, n_out, ratio):
     return need
 
 
+@functools.lru_cache(maxsize=64)
+def _need_masks(sizes_in, sizes_out, ratios, device):
+    """(need_y, need_z) as uint8 device tensors for a pyramid level's geometry, or None when hardly anything can be skipped.
+    Cached: a pipeline registers many pairs on the same grids, and each upload is a host-device round trip in front of
+    the level's first kernel."""
+    need = [_rows_read_by_resample(n_in, n_out, ratio) for n_in, n_out, ratio in zip(sizes_in, sizes_out, ratios)]
+    if need[0].mean() * need[1].mean() > 0.5:
+        return None
+    return tuple(torch.from_numpy(n).to(torch.device(device)) for n in need)
+
+
 def smooth_and_resample(image, isotropic_voxel_size_mm=None, shrink_factor=None, smoothing_sigma=None,
                         interpolator=sitkLinear):
     """One pyramid level (reference: registration/utils.py:195-267): optional Gaussian blur with sigma in mm,
@@ -241,9 +253,8 @@ def smooth_and_resample(image, isotropic_voxel_size_mm=None, shrink_factor=None,
         maximum_kernel_width = int(max([8 * j * i for i, j in zip(image.GetSpacing(), smoothing_variance)]))
         need = None
         if new_size is not None and interpolator in (sitkLinear, sitkNearestNeighbor):
-            need = [_rows_read_by_resample(original_size[a], new_size[a], new_spacing[a] / original_spacing[a]) for a in (1, 2)]
-            if need[0].mean() * need[1].mean() > 0.5:      # hardly anything to skip
-                need = None
+            need = _need_masks(tuple(original_size[1:]), tuple(new_size[1:]),
+                               tuple(new_spacing[a] / original_spacing[a] for a in (1, 2)), str(image.device))
         if need is None:
             image = discrete_gaussian(image, smoothing_variance, maximum_kernel_width)
         else:
@@ -251,9 +262,7 @@ def smooth_and_resample(image, isotropic_voxel_size_mm=None, shrink_factor=None,
             src = image.tensor if image.tensor.dtype == torch.float32 else image.tensor.float()
             out = torch.empty_like(src)
             var = [float(v) for v in smoothing_variance]
-            need_y = torch.from_numpy(need[0]).to(image.device)
-            need_z = torch.from_numpy(need[1]).to(image.device)
-            ctx.discrete_gaussian_rows(src.contiguous(), out, image.GetSize(), image.spacing, var, need_y, need_z, 0.01,
+            ctx.discrete_gaussian_rows(src.contiguous(), out, image.GetSize(), image.spacing, var, need[0], need[1], 0.01,
                                        int(maximum_kernel_width), True)
             image = image.like(out)      # valid exactly where the resample below reads it
 
