@@ -50,19 +50,16 @@ rows = []
 for f in glob.glob("$OUT/regtrace/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# tools/profile_registration.py runs the registration twice (warm-up, then timed): the trace's last registration starts at
-# the last launch of the first pyramid kernel sequence -- take the second half of the launches of the demons kernels' span
 fused = [i for i, r in enumerate(rows) if "k_fused2_force_smooth" in r["Kernel_Name"]]
-half = fused[len(fused) // 2]
-# walk back from the first fused launch of the second registration to the start of that registration: the first kernel
-# after the previous registration's last kernel (a gap of more than 1 ms on the device = the host-side synchronize + print)
-start = half
-while start > 0 and int(rows[start]["Start_Timestamp"]) - int(rows[start - 1]["End_Timestamp"]) < 1000000:
-    start -= 1
+# tools/profile_registration.py runs the registration twice (warm-up, then timed).  The second one starts behind the
+# largest device-idle gap between the first run's last fused launch and the second run's first (the host-side
+# synchronize + print between the two calls).
+lo, hi = fused[len(fused) // 2 - 1], fused[len(fused) // 2]
+start = max(range(lo + 1, hi + 1), key=lambda i: int(rows[i]["Start_Timestamp"]) - int(rows[i - 1]["End_Timestamp"]))
 sel = rows[start:]
 agg = collections.defaultdict(list)
 for r in sel:
-    m = re.search(r"(k_\w+|__amd\w+|at::native::\w+)", r["Kernel_Name"])
+    m = re.search(r"(k_\w+(?:<[^>]*>)?|__amd\w+|at::native::\w+)", r["Kernel_Name"])
     agg[m.group(1) if m else r["Kernel_Name"][:60]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 span = (int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])) / 1e3
 tot = sum(sum(v) for v in agg.values())
