@@ -135,8 +135,10 @@ class _MeanSquares:
             from .._lib import MI_JOINT, MI_MATTES, MiBins
 
             nb, pad = MI_BINS[metric], 2
-            f_lo, f_hi = ctx.minmax(self.ft, self.ft.numel())
-            m_lo, m_hi = ctx.minmax(self.mt, self.mt.numel())
+            # intensity range of each image INSIDE its mask when one is given (both ITK v4 MI metrics' Initialize() walk
+            # the image and skip points outside the mask); an empty mask leaves the whole image
+            f_lo, f_hi = self._intensity_range(ctx, self.ft, self.fmask)
+            m_lo, m_hi = self._intensity_range(ctx, self.mt, self.mmask)
             b = MiBins()
             b.nbins, b.kernel = nb, (MI_MATTES if metric == "mattes_mi" else MI_JOINT)
             # itk::MattesMutualInformation...::Initialize: bin = (max - min) / (bins - 2 padding), normalised min = min / bin - padding
@@ -145,6 +147,15 @@ class _MeanSquares:
             b.f_norm_min = f_lo / b.f_bin - pad
             b.m_norm_min = m_lo / b.m_bin - pad
             self.bins = b
+
+    @staticmethod
+    def _intensity_range(ctx, image, mask):
+        if mask is not None:
+            inside = mask != 0
+            if bool(inside.any()):
+                inf = torch.tensor(float("inf"), dtype=image.dtype, device=image.device)
+                return float(torch.where(inside, image, inf).min()), float(torch.where(inside, image, -inf).max())
+        return ctx.minmax(image, image.numel())
 
     def total(self, model, params):
         """(A, off) of initial o model(params): q = A p + off."""

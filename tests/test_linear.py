@@ -419,3 +419,34 @@ def test_exhaustive_optimiser_walks_the_grid(host_api):
     _, tfm6 = pa.registration.linear_registration(f, m, reg_method="rigid", optimiser="exhaustive", shrink_factors=[2], smooth_sigmas=[0],
                                                   sampling_rate=1.0, exhaustive_steps=[1, 1, 1, 2, 2, 2])     # 27 * 125 grid points
     assert np.linalg.norm(np.asarray(tfm6.matrix_offset()[1]) - [1.0, -2.0, 0.0]) < 1.5
+
+
+def test_mi_intensity_range_is_taken_inside_the_masks(host_api):
+    """Both ITK v4 mutual-information metrics size their histogram from the intensities INSIDE the fixed / moving mask
+    (reference linear.py:133-148 passes fixed_structure / moving_structure as metric masks): an outlier outside the mask
+    must not stretch the bins."""
+    pa = host_api
+    from platipy_amd import runtime
+    from platipy_amd.registration import linear as L
+
+    shape, sp = (12, 16, 20), (1.0, 1.0, 1.0)
+    fix = phantom(shape, seed=330, noise=0)
+    mov = phantom(shape, seed=331, noise=0)
+    mask = np.zeros(shape, np.uint8)
+    mask[2:10, 3:13, 4:16] = 1
+    fix[0, 0, 0] = 30000.0                     # outside the mask
+    mov[11, 15, 19] = -30000.0
+    f, m, k = pa.image_from_array(fix, sp), pa.image_from_array(mov, sp), pa.image_from_array(mask, sp)
+    init = L.centered_transform_initializer(f, m)
+    vsize, vspacing, vorigin, vdir = L._shrink_geometry(f, 1)
+    ctx = runtime.context(f.device)
+    for metric, nb in L.MI_BINS.items():
+        masked = L._MeanSquares(ctx, f, m, vsize, vspacing, vorigin, vdir, init, 1.0, k, k, metric=metric).bins
+        whole = L._MeanSquares(ctx, f, m, vsize, vspacing, vorigin, vdir, init, 1.0, None, None, metric=metric).bins
+        inside = mask.astype(bool)
+        np.testing.assert_allclose(masked.f_bin, (fix[inside].max() - fix[inside].min()) / (nb - 4), rtol=1e-6)
+        np.testing.assert_allclose(masked.m_bin, (mov[inside].max() - mov[inside].min()) / (nb - 4), rtol=1e-6)
+        assert whole.f_bin > 5 * masked.f_bin and whole.m_bin > 5 * masked.m_bin
+        empty = pa.image_from_array(np.zeros(shape, np.uint8), sp)
+        np.testing.assert_allclose(L._MeanSquares(ctx, f, m, vsize, vspacing, vorigin, vdir, init, 1.0, empty, None, metric=metric).bins.f_bin,
+                                   whole.f_bin, rtol=1e-6)
