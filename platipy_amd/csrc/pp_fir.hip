@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(NT) k_compact_rows(const uint8_t* __restrict__
 
 // ---------------------------------------------------------------------------------------
 // Passes for the pyramid's blur -- sparse outputs (a quarter of the planes and rows are ever read by the resample that
-// follows; radius ~11 / ~21 at sigma 4 / 8 voxels) -- and for dense passes of radius 17 .. 32.
+// follows; radius ~11 / ~21 at sigma 4 / 8 voxels) -- and for dense passes of radius 9 .. 24 (y, z) and 17 .. 32 (x).
 //
 // y / z (k_fir_march_sp, defined after k_fir_march below): that register-window march with three changes.  The window is longer than
 // the filter by K slots and the load issued at a step lands K steps later, so K loads per thread are in flight (the march
@@ -534,7 +534,7 @@ int launch_axis(pp_ctx* ctx, const float* in, const float* add, float* out, cons
   // sparse outputs, or a radius beyond the dense register-window buckets (PP_FIR_MARCH_SP=0 keeps the one-output-per-thread kernels)
   const char* sp_env = getenv("PP_FIR_MARCH_SP");   // (once per pass of a once-per-level filter)
   if (!ADD && !(sp_env && atoi(sp_env) == 0) && !getenv("PP_FIR_LEGACY") && taps.r <= 32) {
-    if (AXIS != 0) {
+    if (AXIS != 0 && taps.r <= 24) {
       const int len = AXIS == 1 ? d.ny : d.nz, other = AXIS == 1 ? d.nz : d.ny;
       const int W = 2 * taps.r + 1;
       const unsigned bx = (unsigned)(((size_t)d.nx * other + NT - 1) / NT);
@@ -546,12 +546,11 @@ int launch_axis(pp_ctx* ctx, const float* in, const float* add, float* out, cons
       const dim3 grid(bx, (unsigned)nseg, (unsigned)ncomp);
 #define PP_MSP(RB, KK) hipLaunchKernelGGL((k_fir_march_sp<(AXIS == 0 ? 1 : AXIS), RB, KK>), grid, dim3(NT), 0, ctx->stream, in, out, d, cstride, bucket_taps<RB>(taps), halt, rows, use_y, use_z, nseg)
       if (taps.r <= 12) PP_MSP(12, 24);
-      else if (taps.r <= 24) PP_MSP(24, 24);
-      else PP_MSP(32, 16);
+      else PP_MSP(24, 24);   // (a bucket of 32 doubles this file's compile time for sigmas between 9 and 12 voxels: left to k_conv_axis)
 #undef PP_MSP
       PP_LAUNCH_CHECK(ctx, "k_fir_march_sp");
       return PP_OK;
-    } else if (d.nx <= 4096) {   // (dense x passes of radius <= 16 went to k_fir_x_shfl above)
+    } else if (AXIS == 0 && d.nx <= 4096) {   // (dense x passes of radius <= 16 went to k_fir_x_shfl above)
       const int W = 2 * taps.r + 1;
 #define PP_XROW(WB) hipLaunchKernelGGL((k_fir_x_row<WB>), dim3(8192, (unsigned)ncomp, 1), dim3(NT), 0, ctx->stream, in, out, d, cstride, taps, halt, rows, use_y, use_z)
       if (W <= 15) PP_XROW(15);

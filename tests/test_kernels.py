@@ -102,7 +102,7 @@ def test_fir_register_window_and_shuffle_passes_equal_the_legacy_pass(backend, s
 def test_fir_sparse_passes_equal_the_one_output_per_thread_passes(backend, shape, variance, monkeypatch):
     """The pyramid's blur is produced only on the rows its resample reads (pp_discrete_gaussian_rows_f32).  The passes
     behind it (k_fir_march_sp: a register window with loads in flight K steps ahead, outputs formed only where the list
-    names them; k_fir_x_row: an extended row in LDS; radius up to 32) form every output with the dense filter's own
+    names them; k_fir_x_row: an extended row in LDS; radius up to 24 / 32) form every output with the dense filter's own
     sequence of fmas: bit-identical, on the listed rows, to the one-output-per-thread kernels (PP_FIR_MARCH_SP=0) and to
     the dense filter, for lists with gaps, first / last rows, and radii beyond the axis length."""
     img = phantom(shape, seed=14)
