@@ -29,6 +29,8 @@ trajectory is not a goal for this stage; it is judged by final metric / transfor
     six tens and can be passed (exhaustive_steps); grids above exhaustive_max_evaluations (EXHAUSTIVE_MAX_EVALUATIONS) raise
     instead of running for days (the reference itself says "use is not currently recommended").
 """
+import os
+
 import numpy as np
 import torch
 
@@ -333,7 +335,7 @@ def _optimise_level_native(ctx, ms, model, params, opt, number_of_iterations, ve
     lv.iterations = int(number_of_iterations)
     lv.vsize[:] = [int(v) for v in ms.vsize]
     lv.stride = int(ms.stride)
-    lv.speculation = int(LINE_SEARCH_SPECULATION)
+    lv.speculation = int(os.environ.get("PP_LINE_SEARCH_SPECULATION", LINE_SEARCH_SPECULATION))
     lv.v_i2p[:] = ms.i2p_v.ravel().tolist()
     lv.v_origin[:] = np.asarray(ms.o_v, dtype=np.float64).tolist()
     lv.f_p2i[:] = _p2i(ms.fixed).ravel().tolist()
@@ -360,7 +362,8 @@ def _optimise_level_native(ctx, ms, model, params, opt, number_of_iterations, ve
 
 # How many levels of the golden-section decision tree are evaluated per launch (2^depth - 1 learning rates, + the
 # bracket's middle point on the first round: 16 at depth 4 = one pp_metric_values_affine_f32 call).
-LINE_SEARCH_SPECULATION = 4
+LINE_SEARCH_SPECULATION = 4   # measured best (profiles/round3_linear_speculation.txt: affine stage 32.4 / 34.0 / 38.0 / 65.3 ms at
+#                               depth 4 / 3 / 2 / 1); PP_LINE_SEARCH_SPECULATION overrides it for such sweeps
 
 
 def _golden_section(fbatch, a, b, c, eps=0.01, max_iter=20, depth=None):
