@@ -198,6 +198,7 @@ void pp_destroy(pp_ctx* ctx) {
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->ticket) (void)hipFree(ctx->ticket);
   if (ctx->hist) (void)hipFree(ctx->hist);
+  if (ctx->fsamp) (void)hipFree(ctx->fsamp);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   if (ctx->prof) {

@@ -258,7 +258,8 @@ template <int MODE>
 __global__ void __launch_bounds__(NT) k_metric_affine(const float* __restrict__ F, pp_dims df, const float* __restrict__ M,
                                                       pp_dims dm, const uint8_t* __restrict__ fmask,
                                                       const uint8_t* __restrict__ mmask, msq_args a,
-                                                      double* __restrict__ partials /* [grid][NACC] */) {
+                                                      double* __restrict__ partials /* [grid][NACC] */,
+                                                      const float* __restrict__ fsamp /* pp_fixed_samples, or NULL */) {
   constexpr int NACC = MODE == 0 ? 14 : 42;
   __shared__ double red[3 * NT];
   double acc[NACC];
@@ -276,16 +277,23 @@ __global__ void __launch_bounds__(NT) k_metric_affine(const float* __restrict__ 
     }
     int bf_[3], bm_[3];
     float ff[3], fm[3];
-    if (!msq_locate(cf, df, bf_, ff) || !msq_locate(cm, dm, bm_, fm)) continue;
-    if (fmask) {
-      const int qx = (int)floor(cf[0] + 0.5), qy = (int)floor(cf[1] + 0.5), qz = (int)floor(cf[2] + 0.5);
-      if (!fmask[((size_t)qz * df.ny + qy) * df.nx + qx]) continue;
+    float fval = 0.0f;
+    if (fsamp) {   // the fixed side of this sample was evaluated once for the level (same arithmetic)
+      fval = fsamp[e];
+      if (__builtin_bit_cast(unsigned, fval) == PP_FSAMP_INVALID) continue;
+      if (!msq_locate(cm, dm, bm_, fm)) continue;
+    } else {
+      if (!msq_locate(cf, df, bf_, ff) || !msq_locate(cm, dm, bm_, fm)) continue;
+      if (fmask) {
+        const int qx = (int)floor(cf[0] + 0.5), qy = (int)floor(cf[1] + 0.5), qz = (int)floor(cf[2] + 0.5);
+        if (!fmask[((size_t)qz * df.ny + qy) * df.nx + qx]) continue;
+      }
     }
     if (mmask) {
       const int qx = (int)floor(cm[0] + 0.5), qy = (int)floor(cm[1] + 0.5), qz = (int)floor(cm[2] + 0.5);
       if (!mmask[((size_t)qz * dm.ny + qy) * dm.nx + qx]) continue;
     }
-    const float fval = pp_trilinear(F, df.nx, df.ny, df.nz, bf_[0], ff[0], bf_[1], ff[1], bf_[2], ff[2]);
+    if (!fsamp) fval = pp_trilinear(F, df.nx, df.ny, df.nz, bf_[0], ff[0], bf_[1], ff[1], bf_[2], ff[2]);
     int x0, x1, y0, y1, z0, z1;
     float wx, wy, wz;
     pp_axis_setup(bm_[0], fm[0], dm.nx, x0, x1, wx);
@@ -437,7 +445,7 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
                                                       int ncand, double* partials /* [chunk][grid.x][CH*NV] */,
                                                       unsigned* __restrict__ ticket, double* result /* host mailbox: [cand][6] */,
                                                       unsigned long long* flags /* host mailbox: one per chunk */,
-                                                      unsigned long long seq) {
+                                                      unsigned long long seq, const float* __restrict__ fsamp /* or NULL */) {
   constexpr int NV = MODE == 0 ? 2 : 6;
   constexpr int ROW = CH * NV;
   __shared__ double red[CH * (MODE == 0 ? 2 : 6) * NT];   // 64 KB / 48 KB: every accumulator of every thread
@@ -452,16 +460,24 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
     const size_t lin = e * (size_t)a.stride;
     const double v[3] = {(double)(lin % a.vsize[0]), (double)((lin / a.vsize[0]) % a.vsize[1]),
                          (double)(lin / ((size_t)a.vsize[0] * a.vsize[1]))};
-    double cf[3];
-    for (int r = 0; r < 3; ++r) cf[r] = a.Af[r * 3 + 0] * v[0] + a.Af[r * 3 + 1] * v[1] + a.Af[r * 3 + 2] * v[2] + a.bf[r];
-    int bf_[3];
-    float ff[3];
-    if (!msq_locate(cf, df, bf_, ff)) continue;
-    if (fmask) {
-      const int qx = (int)floor(cf[0] + 0.5), qy = (int)floor(cf[1] + 0.5), qz = (int)floor(cf[2] + 0.5);
-      if (!fmask[((size_t)qz * df.ny + qy) * df.nx + qx]) continue;
+    double fd;
+    if (fsamp) {   // the fixed side of this sample was evaluated once for the level: a coalesced 4-byte read instead of four
+                   // sparse cache lines per sample (at shrink 4 a probe dragged a quarter of the fixed image through HBM)
+      const float fv = fsamp[e];
+      if (__builtin_bit_cast(unsigned, fv) == PP_FSAMP_INVALID) continue;
+      fd = fv;
+    } else {
+      double cf[3];
+      for (int r = 0; r < 3; ++r) cf[r] = a.Af[r * 3 + 0] * v[0] + a.Af[r * 3 + 1] * v[1] + a.Af[r * 3 + 2] * v[2] + a.bf[r];
+      int bf_[3];
+      float ff[3];
+      if (!msq_locate(cf, df, bf_, ff)) continue;
+      if (fmask) {
+        const int qx = (int)floor(cf[0] + 0.5), qy = (int)floor(cf[1] + 0.5), qz = (int)floor(cf[2] + 0.5);
+        if (!fmask[((size_t)qz * df.ny + qy) * df.nx + qx]) continue;
+      }
+      fd = msq_trilinear_pairs(F, df.nx, df.ny, df.nz, bf_[0], ff[0], bf_[1], ff[1], bf_[2], ff[2]);
     }
-    const double fd = msq_trilinear_pairs(F, df.nx, df.ny, df.nz, bf_[0], ff[0], bf_[1], ff[1], bf_[2], ff[2]);
     if constexpr (CH >= 16) {
     // Straight-line over the candidates: every candidate forms a valid (clamped) address and gathers unconditionally, and
     // "inside / masked" only selects what is accumulated -- so a group of four candidates has no branches and the gathers of the
@@ -918,6 +934,73 @@ int pp_binary_threshold_f32(pp_ctx* ctx, const float* prob, size_t n, double max
   return PP_OK;
 }
 
+// The fixed side of every sample of a metric lattice: value of the trilinear interpolant, or PP_FSAMP_INVALID where the
+// point leaves the fixed buffer or its mask (the tests the metric kernels make, in their order).
+__global__ void __launch_bounds__(NT) k_fixed_samples(const float* __restrict__ F, pp_dims df, const uint8_t* __restrict__ fmask, msq_args a,
+                                                      float* __restrict__ fsamp) {
+  const size_t nvirt = (size_t)a.vsize[0] * a.vsize[1] * a.vsize[2];
+  const size_t nsamp = (nvirt + a.stride - 1) / a.stride;
+  for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nsamp; e += (size_t)gridDim.x * NT) {
+    const size_t lin = e * (size_t)a.stride;
+    const double v[3] = {(double)(lin % a.vsize[0]), (double)((lin / a.vsize[0]) % a.vsize[1]),
+                         (double)(lin / ((size_t)a.vsize[0] * a.vsize[1]))};
+    double cf[3];
+    for (int r = 0; r < 3; ++r) cf[r] = a.Af[r * 3 + 0] * v[0] + a.Af[r * 3 + 1] * v[1] + a.Af[r * 3 + 2] * v[2] + a.bf[r];
+    int bf_[3];
+    float ff[3];
+    bool ok = msq_locate(cf, df, bf_, ff);
+    if (ok && fmask) {
+      const int qx = (int)floor(cf[0] + 0.5), qy = (int)floor(cf[1] + 0.5), qz = (int)floor(cf[2] + 0.5);
+      ok = fmask[((size_t)qz * df.ny + qy) * df.nx + qx] != 0;
+    }
+    fsamp[e] = ok ? msq_trilinear_pairs(F, df.nx, df.ny, df.nz, bf_[0], ff[0], bf_[1], ff[1], bf_[2], ff[2]) : __builtin_bit_cast(float, PP_FSAMP_INVALID);
+  }
+}
+
+static int pp_fixed_samples(pp_ctx* ctx, const float* fixed, const int fsize[3], const double Af[9], const double bf[3], const int vsize[3],
+                            int stride, const unsigned char* fmask, const float** out) {
+  *out = nullptr;
+  if (ctx->fsamp_scope <= 0 || getenv("PP_NO_FIXED_SAMPLES")) return PP_OK;
+  auto& k = ctx->fsamp_key;
+  const bool same = ctx->fsamp_valid && k.fixed == fixed && k.fmask == fmask && k.stride == stride &&
+                    memcmp(k.fsize, fsize, sizeof(k.fsize)) == 0 && memcmp(k.vsize, vsize, sizeof(k.vsize)) == 0 &&
+                    memcmp(k.Af, Af, sizeof(k.Af)) == 0 && memcmp(k.bf, bf, sizeof(k.bf)) == 0;
+  if (!same) {
+    const size_t nsamp = ((size_t)vsize[0] * vsize[1] * vsize[2] + stride - 1) / stride;
+    if (nsamp > ctx->fsamp_cap) {
+      if (ctx->fsamp) (void)hipFree(ctx->fsamp);
+      ctx->fsamp = nullptr;
+      ctx->fsamp_cap = 0;
+      void* p = nullptr;
+      if (hipMalloc(&p, nsamp * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();
+        return PP_OK;   // (no cache: the metric kernels sample the fixed image themselves)
+      }
+      ctx->fsamp = static_cast<float*>(p);
+      ctx->fsamp_cap = nsamp;
+    }
+    msq_args a;
+    memset(&a, 0, sizeof(a));
+    memcpy(a.Af, Af, sizeof(a.Af));
+    memcpy(a.bf, bf, sizeof(a.bf));
+    for (int i = 0; i < 3; ++i) a.vsize[i] = vsize[i];
+    a.stride = stride;
+    const pp_dims df{fsize[0], fsize[1], fsize[2]};
+    hipLaunchKernelGGL(k_fixed_samples, dim3(grid_for(nsamp, 2048u)), dim3(NT), 0, ctx->stream, fixed, df, fmask, a, ctx->fsamp);
+    PP_LAUNCH_CHECK(ctx, "k_fixed_samples");
+    k.fixed = fixed;
+    k.fmask = fmask;
+    k.stride = stride;
+    memcpy(k.fsize, fsize, sizeof(k.fsize));
+    memcpy(k.vsize, vsize, sizeof(k.vsize));
+    memcpy(k.Af, Af, sizeof(k.Af));
+    memcpy(k.bf, bf, sizeof(k.bf));
+    ctx->fsamp_valid = 1;
+  }
+  *out = ctx->fsamp;
+  return PP_OK;
+}
+
 static int metric_affine(pp_ctx* ctx, int mode, const float* fixed, const int fsize[3], const float* moving, const int msize[3],
                          const double Af[9], const double bf[3], const double Am[9], const double bm[3], const int vsize[3],
                          int stride, const uint8_t* fixed_mask, const uint8_t* moving_mask, double* result) {
@@ -935,14 +1018,19 @@ static int metric_affine(pp_ctx* ctx, int mode, const float* fixed, const int fs
   a.stride = stride;
   const size_t nsamp = ((size_t)vsize[0] * vsize[1] * vsize[2] + stride - 1) / stride;
   const pp_dims df{fsize[0], fsize[1], fsize[2]}, dm{msize[0], msize[1], msize[2]};
-  const unsigned nb = grid_for(nsamp, 512u);
+  const unsigned nb = grid_for(nsamp, 512u);   // (256 measures the same, 128 slower: profiles/round3_metric_probe_latency.txt)
   int rc = pp_reserve(ctx, pp_align_up((size_t)nb * nacc * sizeof(double), 256));
   if (rc) return rc;
   double* partials = reinterpret_cast<double*>(ctx->ws);
+  const float* fsamp = nullptr;
+  rc = pp_fixed_samples(ctx, fixed, fsize, Af, bf, vsize, stride, fixed_mask, &fsamp);
+  if (rc) return rc;
   if (mode == 0)
-    hipLaunchKernelGGL((k_metric_affine<0>), dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, partials);
+    hipLaunchKernelGGL((k_metric_affine<0>), dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, partials,
+                       fsamp);
   else
-    hipLaunchKernelGGL((k_metric_affine<1>), dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, partials);
+    hipLaunchKernelGGL((k_metric_affine<1>), dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, partials,
+                       fsamp);
   PP_LAUNCH_CHECK(ctx, "k_metric_affine");
   char* mail = nullptr;
   unsigned long long* flags = nullptr;
@@ -1001,7 +1089,15 @@ int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, con
   const bool small = metric == 0 && nsamp < 150000;
   const int ch = metric == 0 ? (small || ncand <= 4 ? CH0S : CH0) : CH1, nv = metric == 0 ? 2 : 6;
   const int nchunk = (ncand + ch - 1) / ch;
-  const unsigned nb = grid_for(nsamp, 1024u);
+  // Blocks per chunk: one sample per thread up to ~512 blocks in the whole launch (512 on big lattices, where 16 candidates
+  // are one chunk; 128 on small ones, where they are four).  Measured on MI355X (profiles/round3_metric_probe_latency.txt):
+  // beyond that a probe gets SLOWER with more blocks -- 1024 blocks of two samples per thread cost 76 / 150 us (1 / 16
+  // candidates, 128 x 128 x 64 lattice), 512 blocks of four 54 / 125 us; the 64 x 64 x 32 lattice with 16 candidates 78 -> 57 us
+  // at 128 blocks per chunk.  (Not the ticket: a two-level ticket changed nothing.)  The cap depends on the lattice only, so
+  // a candidate's partial sums do not depend on how many companions ride in the launch.  PP_METRIC_BLOCKS overrides it.
+  unsigned nb_cap = (metric == 0 && small) || metric != 0 ? 128u : 512u;
+  if (const char* e = getenv("PP_METRIC_BLOCKS")) nb_cap = (unsigned)atoi(e);
+  const unsigned nb = grid_for(nsamp, nb_cap);
   const size_t row = (size_t)ch * nv;
   int rc = pp_reserve(ctx, pp_align_up((size_t)nb * nchunk * row * sizeof(double), 256));
   if (rc) return rc;
@@ -1015,15 +1111,18 @@ int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, con
   rc = pp_mailbox(ctx, &mail, &flags, &seq);
   if (rc) return rc;
   double* hres = reinterpret_cast<double*>(mail);      // 16 x 6 doubles = 768 B of the payload area
+  const float* fsamp = nullptr;
+  rc = pp_fixed_samples(ctx, fixed, fsize, Af, bf, vsize, stride, fixed_mask, &fsamp);
+  if (rc) return rc;
   if (metric == 0 && ch == CH0S)
     hipLaunchKernelGGL((k_metric_values<0, CH0S>), dim3(nb, nchunk), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask,
-                       moving_mask, a, ncand, partials, ticket, hres, flags, seq);
+                       moving_mask, a, ncand, partials, ticket, hres, flags, seq, fsamp);
   else if (metric == 0)
     hipLaunchKernelGGL((k_metric_values<0, CH0>), dim3(nb, nchunk), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask,
-                       moving_mask, a, ncand, partials, ticket, hres, flags, seq);
+                       moving_mask, a, ncand, partials, ticket, hres, flags, seq, fsamp);
   else
     hipLaunchKernelGGL((k_metric_values<1, CH1>), dim3(nb, nchunk), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask,
-                       moving_mask, a, ncand, partials, ticket, hres, flags, seq);
+                       moving_mask, a, ncand, partials, ticket, hres, flags, seq, fsamp);
   PP_LAUNCH_CHECK(ctx, "k_metric_values");
   rc = pp_mail_wait(ctx, nchunk, seq);
   if (rc) return rc;

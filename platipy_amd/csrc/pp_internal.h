@@ -29,6 +29,18 @@ struct pp_ctx {
   unsigned long long mail_seq;  // sequence number of the last posted result
   double* hist;       // device ring of the last Execute's per-iteration {metric, RMS change} (lazy; pp_demons_history)
   int hist_cap;       // entries (iterations) the ring holds
+  // Fixed-image samples of the metric lattice, kept while one optimiser level runs (pp_fixed_samples): the sample points
+  // of the fixed image do not move between the level's hundreds of metric evaluations.
+  float* fsamp;
+  size_t fsamp_cap;        // floats
+  int fsamp_scope;         // > 0 inside pp_linear_optimize_f32: the fixed image cannot change under the cache
+  int fsamp_valid;
+  struct {
+    const float* fixed;
+    const unsigned char* fmask;
+    int fsize[3], vsize[3], stride;
+    double Af[9], bf[3];
+  } fsamp_key;
   char err[512];
 };
 
@@ -58,6 +70,17 @@ struct pp_device_guard {
 };
 
 int pp_fail(pp_ctx* ctx, int code, const char* fmt, ...);
+// The metric entry points of pp_fusion.hip keep a device array of the fixed image's trilinear samples on the metric
+// lattice (PP_FSAMP_INVALID bits where a sample falls outside the fixed buffer or its mask): built on first use inside a
+// pp_fsamp_scope and reused while the key matches; outside such a scope they sample the fixed image themselves.
+constexpr unsigned PP_FSAMP_INVALID = 0x7fc0deadu;
+struct pp_fsamp_scope {
+  pp_ctx* c;
+  explicit pp_fsamp_scope(pp_ctx* ctx) : c(ctx) { ++c->fsamp_scope; }
+  ~pp_fsamp_scope() {
+    if (--c->fsamp_scope == 0) c->fsamp_valid = 0;
+  }
+};
 // Reserve `bytes` of device scratch (256-B aligned slices are carved by the callers).
 int pp_reserve(pp_ctx* ctx, size_t bytes);
 // Copy `bytes` (<= 4096) from device memory to `host` through the context's page-locked staging buffer and wait

@@ -459,6 +459,7 @@ extern "C" int pp_linear_optimize_f32(pp_ctx* ctx, const float* fixed, const int
   level_state S{ctx, level, fixed, moving, fsize, msize, fixed_mask, moving_mask, n, {}, {}, {}, 0};
   S.setup();
   const int depth = level->speculation < 1 ? 1 : (level->speculation > 4 ? 4 : level->speculation);
+  pp_fsamp_scope fixed_samples_scope(ctx);   // the fixed image is constant for this call: its lattice samples are evaluated once
 
   std::vector<double> p(params, params + n), best(p), scales(n), grad(n), g(n), hist;
   S.scales(p.data(), scales.data());

@@ -450,3 +450,38 @@ def test_mi_intensity_range_is_taken_inside_the_masks(host_api):
         empty = pa.image_from_array(np.zeros(shape, np.uint8), sp)
         np.testing.assert_allclose(L._MeanSquares(ctx, f, m, vsize, vspacing, vorigin, vdir, init, 1.0, empty, None, metric=metric).bins.f_bin,
                                    whole.f_bin, rtol=1e-6)
+
+
+@pytest.mark.parametrize("metric,masked", [("mean_squares", False), ("mean_squares", True), ("correlation", True)])
+def test_fixed_sample_cache_does_not_change_the_optimisation(backend, monkeypatch, metric, masked):
+    """Inside pp_linear_optimize_f32 the fixed image's lattice samples are evaluated once per level and read back by
+    every metric launch of the level (the probes stop dragging a quarter of the fixed image through HBM).  Same
+    arithmetic, same validity tests: the parameters equal those of the uncached path (PP_NO_FIXED_SAMPLES) exactly."""
+    import torch
+
+    import platipy_amd as pa
+    from platipy_amd import runtime
+
+    if backend.name == "emu":
+        monkeypatch.setattr(runtime, "context", lambda device=None: backend.ctx)
+        monkeypatch.setattr(runtime, "default_device", lambda: torch.device("cpu"))
+    shape, spacing, origin = (16, 20, 24), (1.5, 1.5, 2.5), (-30.0, -20.0, 10.0)
+    fix, mov, _ = _rigid_pair(pa, shape, spacing, origin, angle=0.05, shift=(1.5, -1.0, 1.0))
+    mask = None
+    if masked:
+        m = np.zeros(shape, np.uint8)
+        m[2:14, 3:17, 4:20] = 1
+        mask = pa.image_from_array(m, spacing, origin)
+    out = {}
+    for off in ("1", None):
+        if off:
+            monkeypatch.setenv("PP_NO_FIXED_SAMPLES", off)
+        else:
+            monkeypatch.delenv("PP_NO_FIXED_SAMPLES", raising=False)
+        _, tfm = pa.registration.linear_registration(
+            pa.image_from_array(fix, spacing, origin), pa.image_from_array(mov, spacing, origin), reg_method="affine", metric=metric,
+            optimiser="gradient_descent_line_search", shrink_factors=[2, 1], smooth_sigmas=[0, 0], sampling_rate=0.5, number_of_iterations=5,
+            fixed_structure=mask)
+        out[off] = np.asarray(tfm.transforms[1].GetParameters())
+    assert np.abs(out[None] - np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0.0])).max() > 1e-3
+    np.testing.assert_array_equal(out["1"], out[None])
