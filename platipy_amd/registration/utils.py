@@ -213,7 +213,13 @@ def _need_masks(sizes_in, sizes_out, ratios, device):
     need = [_rows_read_by_resample(n_in, n_out, ratio) for n_in, n_out, ratio in zip(sizes_in, sizes_out, ratios)]
     if need[0].mean() * need[1].mean() > 0.5:
         return None
-    return tuple(torch.from_numpy(n).to(torch.device(device)) for n in need)
+    dev = torch.device(device)
+    masks = tuple(torch.from_numpy(n).to(dev) for n in need)
+    if dev.type == "cuda":
+        # the upload is ordered on THIS thread's stream only; the cached tensors are handed to every worker thread (each on
+        # its own stream) from now on, so they must be complete before the cache publishes them
+        torch.cuda.current_stream(dev).synchronize()
+    return masks
 
 
 def smooth_and_resample(image, isotropic_voxel_size_mm=None, shrink_factor=None, smoothing_sigma=None,

@@ -16,6 +16,18 @@ COMMIT=${1:-unknown}
 BENCH="python bench.py --steps 20 --warmup 3 --no-registration --no-atlas --no-cpu-baseline"
 echo "== pytest -m gpu"; PP_STATS_DIR=$OUT/parity_stats timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 | tee $OUT/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $OUT/smoke.log
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  ( cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc -o $tag -- bash -c "cd $OLDPWD && $BENCH --pmc-calibration" > $OLDPWD/$OUT/pmc_$tag.log 2>&1 )
+  tail -c 200 $OUT/pmc_$tag.log | head -c 200; echo
+done
+python tools/pmc_summary.py $OUT/pmc $OUT/pmc_counters.md
+python tools/pmc_reduce.py $OUT/pmc_counters.md $COMMIT 512 512 256 > $OUT/pmc.json
+cat $OUT/pmc.json
+# the bench line reads its measured traffic from profiles/round*_pmc.json (matched on the kernel sources' hash): put this
+# run's capture there first, so that the committed line and the committed capture come from the same build
+cp $OUT/pmc.json profiles/round3_pmc.json
+cp $OUT/pmc_counters.md profiles/round3_pmc_counters.md
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/trace -o trace -- bash -c "cd $OLDPWD && $BENCH" > $OLDPWD/$OUT/bench_under_rocprof.json 2> $OLDPWD/$OUT/trace.err )
@@ -29,14 +41,6 @@ print("| kernel | calls | total us | avg us | min us | max us |\n|---|---|---|--
 for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
     print(f"| {k[:110]} | {len(v)} | {sum(v):.1f} | {sum(v)/len(v):.2f} | {min(v):.2f} | {max(v):.2f} |")
 PY
-for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do
-  tag=$(echo $set | cut -d' ' -f1)
-  ( cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc -o $tag -- bash -c "cd $OLDPWD && $BENCH --pmc-calibration" > $OLDPWD/$OUT/pmc_$tag.log 2>&1 )
-  tail -c 200 $OUT/pmc_$tag.log | head -c 200; echo
-done
-python tools/pmc_summary.py $OUT/pmc $OUT/pmc_counters.md
-python tools/pmc_reduce.py $OUT/pmc_counters.md $COMMIT 512 512 256 > $OUT/pmc.json
-cat $OUT/pmc.json
 
 echo "== stand-alone kernels"
 timeout 300 tools/kbench/sbench platipy_amd/csrc/libplatipy_hip.so 512 512 256 5 > $OUT/standalone_kernels.txt 2>&1
