@@ -71,7 +71,13 @@ int pp_fail(pp_ctx* ctx, int code, const char* fmt, ...) {
 }
 
 int pp_reserve(pp_ctx* ctx, size_t bytes) {
-  if (bytes <= ctx->ws_bytes) return PP_OK;
+  if (bytes <= ctx->ws_bytes) {
+    // debugging aid: PP_POISON_WS=1 fills the reserved scratch with NaN bytes on every call, so a kernel that reads
+    // scratch it did not write shows up as NaN / changed results (tools/stress_streams.py)
+    static const bool poison = getenv("PP_POISON_WS") != nullptr;
+    if (poison && bytes) PP_HIP(ctx, hipMemsetAsync(ctx->ws, 0xFF, bytes, ctx->stream));
+    return PP_OK;
+  }
   // Growing is rare (first call at a size); wait for queued work that may still use ws.
   PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->ws) {
@@ -106,51 +112,51 @@ int pp_read_back(pp_ctx* ctx, const void* dev, void* host, size_t bytes) {
   return PP_OK;
 }
 
-int pp_mailbox(pp_ctx* ctx, char** payload, unsigned long long** flags, unsigned long long* seq) {
+int pp_mailbox(pp_ctx* ctx, char** mailbox, unsigned long long* seq) {
   if (!ctx->mailbox) {
     void* p = nullptr;
-    if (hipHostMalloc(&p, 4096, 0) != hipSuccess || !p) {
+    if (hipHostMalloc(&p, PP_MAIL_WRITERS * PP_MAIL_SLOT, 0) != hipSuccess || !p) {
       (void)hipGetLastError();
       return pp_fail(ctx, PP_ERR_ALLOC, "mailbox allocation failed");
     }
-    memset(p, 0, 4096);
+    memset(p, 0, PP_MAIL_WRITERS * PP_MAIL_SLOT);
     ctx->mailbox = static_cast<char*>(p);
     ctx->mail_seq = 0;
   }
-  *payload = ctx->mailbox;
-  *flags = reinterpret_cast<unsigned long long*>(ctx->mailbox + PP_MAIL_FLAGS_OFF);
+  *mailbox = ctx->mailbox;
   *seq = ++ctx->mail_seq;
   return PP_OK;
 }
 
-int pp_mail_wait(pp_ctx* ctx, int nflags, unsigned long long seq) {
-  volatile unsigned long long* flags = reinterpret_cast<volatile unsigned long long*>(ctx->mailbox + PP_MAIL_FLAGS_OFF);
+int pp_mail_take(pp_ctx* ctx, int writer, int n, unsigned long long seq, double* out) {
+  if (writer < 0 || writer >= PP_MAIL_WRITERS || n < 0 || n > PP_MAIL_ENTRIES)
+    return pp_fail(ctx, PP_ERR_ARG, "pp_mail_take: writer %d / %d entries exceed the mailbox", writer, n);
+  volatile pp_mail_entry* e = pp_mail_slot(ctx->mailbox, writer);
   const auto t0 = std::chrono::steady_clock::now();
-  for (unsigned spins = 0;; ++spins) {
-    bool all = true;
-    for (int k = 0; k < nflags; ++k) all = all && flags[k] == seq;
-    if (all) break;
-    if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+  bool synced = false;
+  for (int k = 0; k < n; ++k) {
+    for (unsigned spins = 0; e[k].tag != seq; ++spins) {
+      if ((spins & 1023u) != 1023u || std::chrono::steady_clock::now() - t0 <= std::chrono::milliseconds(200)) continue;
       // not there yet: wait for the stream the ordinary way (also surfaces a failed launch), then look once more
+      if (synced) return pp_fail(ctx, PP_ERR_HIP, "kernel finished without posting its result");
       PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      for (int k = 0; k < nflags; ++k)
-        if (flags[k] != seq) return pp_fail(ctx, PP_ERR_HIP, "kernel finished without posting its result");
-      break;
+      synced = true;
     }
+    std::atomic_thread_fence(std::memory_order_acquire);   // the value is read after the tag that validates it
+    out[k] = e[k].value;
   }
-  std::atomic_thread_fence(std::memory_order_acquire);
   return PP_OK;
 }
 
 int pp_ticket(pp_ctx* ctx, unsigned** out) {
   if (!ctx->ticket) {
     void* p = nullptr;
-    if (hipMalloc(&p, 256) != hipSuccess || !p) {
+    if (hipMalloc(&p, 1024) != hipSuccess || !p) {
       (void)hipGetLastError();
       return pp_fail(ctx, PP_ERR_ALLOC, "ticket counter allocation failed");
     }
     ctx->ticket = static_cast<unsigned*>(p);
-    PP_HIP(ctx, hipMemsetAsync(ctx->ticket, 0, 256, ctx->stream));
+    PP_HIP(ctx, hipMemsetAsync(ctx->ticket, 0, 1024, ctx->stream));
   }
   *out = ctx->ticket;
   return PP_OK;

@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(NT) k_metric_affine(const float* __restrict__ 
 // Fold [count][14] partial rows into 14 sums with one tree (8 barrier steps for all fields at once); launched
 // with one block per group of 14 fields (blockIdx.x selects the group of a wider row).
 __global__ void __launch_bounds__(NT) k_sum14_final(const double* __restrict__ partials, int count, int row, double* result,
-                                                    unsigned long long* flags, unsigned long long seq) {
+                                                    int to_mailbox, unsigned long long seq) {
   __shared__ double red[NT * 14];
   const int f0 = blockIdx.x * 14;
   const int nf = row - f0 < 14 ? row - f0 : 14;
@@ -376,11 +376,11 @@ __global__ void __launch_bounds__(NT) k_sum14_final(const double* __restrict__ p
     __syncthreads();
   }
   if ((int)threadIdx.x < nf) {
-    result[f0 + threadIdx.x] = red[threadIdx.x * NT];
-    if (flags) __threadfence_system();      // result may be the host mailbox: publish before the flag
+    if (to_mailbox)   // `result` is the host mailbox: block b is writer b, field f its entry f (pp_internal.h)
+      pp_mail_post(pp_mail_slot(result, (int)blockIdx.x) + threadIdx.x, red[threadIdx.x * NT], seq);
+    else
+      result[f0 + threadIdx.x] = red[threadIdx.x * NT];
   }
-  __syncthreads();
-  if (flags && threadIdx.x == 0) flags[blockIdx.x] = seq;
 }
 
 // ---- line-search evaluations: K candidate moving maps in ONE launch, values only --------------------------
@@ -389,8 +389,9 @@ __global__ void __launch_bounds__(NT) k_sum14_final(const double* __restrict__ p
 // latency (the sample lattice is 16 K .. 1 M points).  The host speculates the next few levels of the search
 // tree and evaluates all of their learning rates at once: blockIdx.y = candidate.  The last block of a candidate to
 // finish (device ticket per candidate) folds that candidate's per-block partial sums with a fixed tree, so a candidate's value does not depend on
-// which other candidates ride in the launch.  (ctx->ticket holds 64 counters; PP_MAX_CAND of them are used.)
+// which other candidates ride in the launch.  (ctx->ticket holds 256 counters; a chunk uses the one at chunk * TICKET_STRIDE.)
 constexpr int PP_MAX_CAND = 16;
+constexpr unsigned TICKET_STRIDE = 32;   // counters of a launch's chunks sit 128 bytes apart (ctx->ticket holds 256 of them)
 struct mval_args {
   double Af[9], bf[3];
   double Am[PP_MAX_CAND][9], bm[PP_MAX_CAND][3];
@@ -443,8 +444,7 @@ template <int MODE, int CH>
 __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ F, pp_dims df, const float* __restrict__ M, pp_dims dm,
                                                       const uint8_t* __restrict__ fmask, const uint8_t* __restrict__ mmask, mval_args a,
                                                       int ncand, double* partials /* [chunk][grid.x][CH*NV] */,
-                                                      unsigned* __restrict__ ticket, double* result /* host mailbox: [cand][6] */,
-                                                      unsigned long long* flags /* host mailbox: one per chunk */,
+                                                      unsigned* __restrict__ ticket, void* mailbox /* host mailbox: chunk = writer */,
                                                       unsigned long long seq, const float* __restrict__ fsamp /* or NULL */) {
   constexpr int NV = MODE == 0 ? 2 : 6;
   constexpr int ROW = CH * NV;
@@ -566,13 +566,14 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
     __syncthreads();
   }
   if ((int)threadIdx.x < ROW) {
-    mine[threadIdx.x] = red[threadIdx.x * NT];
+    // agent-scope atomic store / load for the rows (below): they cross XCDs, each behind its own L2, inside one launch
+    __hip_atomic_store(mine + threadIdx.x, red[threadIdx.x * NT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();   // each writer publishes its own store before the block takes its ticket
   }
   __syncthreads();
   // the last block of this chunk to arrive folds the chunk's rows (fixed tree, independent of arrival order)
   if (threadIdx.x == 0) {
-    const unsigned t = atomicAdd(ticket + blockIdx.y, 1u);
+    const unsigned t = atomicAdd(ticket + blockIdx.y * TICKET_STRIDE, 1u);   // (one 128-byte line per chunk's counter)
     is_last = t == gridDim.x - 1u;
   }
   __syncthreads();
@@ -587,22 +588,18 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
     const int col = (int)threadIdx.x % ROW, part = (int)threadIdx.x / ROW;
     double p = 0.0;
     if (part < NPARTS)
-      for (unsigned i = (unsigned)part; i < gridDim.x; i += NPARTS) p += rows[(size_t)i * ROW + col];
+      for (unsigned i = (unsigned)part; i < gridDim.x; i += NPARTS)
+        p += __hip_atomic_load(rows + (size_t)i * ROW + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();   // (red still holds the block's own tree)
     if (part < NPARTS) red[part * ROW + col] = p;
     __syncthreads();
     if ((int)threadIdx.x < nc * NV) {
       double tot = 0.0;
       for (int q = 0; q < NPARTS; ++q) tot += red[q * ROW + threadIdx.x];
-      result[(c0 + (int)threadIdx.x / NV) * 6 + (int)threadIdx.x % NV] = tot;
+      pp_mail_post(pp_mail_slot(mailbox, (int)blockIdx.y) + threadIdx.x, tot, seq);   // entry = local candidate * NV + field
     }
-    __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    ticket[blockIdx.y] = 0u;
-    __threadfence_system();   // the results above reach host memory before the flag that announces them
-    flags[blockIdx.y] = seq;
-  }
+  if (threadIdx.x == 0) atomicExch(ticket + blockIdx.y * TICKET_STRIDE, 0u);   // (where the increments go, not a cached plain store)
 }
 
 
@@ -1033,17 +1030,17 @@ static int metric_affine(pp_ctx* ctx, int mode, const float* fixed, const int fs
                        fsamp);
   PP_LAUNCH_CHECK(ctx, "k_metric_affine");
   char* mail = nullptr;
-  unsigned long long* flags = nullptr;
   unsigned long long seq = 0;
-  rc = pp_mailbox(ctx, &mail, &flags, &seq);
+  rc = pp_mailbox(ctx, &mail, &seq);
   if (rc) return rc;
-  double* hres = reinterpret_cast<double*>(mail);       // up to 42 doubles of the payload area
   const int nfold = (nacc + 13) / 14;
-  hipLaunchKernelGGL(k_sum14_final, dim3(nfold), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, nacc, hres, flags, seq);
+  hipLaunchKernelGGL(k_sum14_final, dim3(nfold), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, nacc,
+                     reinterpret_cast<double*>(mail), 1, seq);
   PP_LAUNCH_CHECK(ctx, "k_sum14_final");
-  rc = pp_mail_wait(ctx, nfold, seq);
-  if (rc) return rc;
-  memcpy(result, hres, nacc * sizeof(double));
+  for (int b = 0; b < nfold; ++b) {
+    rc = pp_mail_take(ctx, b, nacc - 14 * b < 14 ? nacc - 14 * b : 14, seq, result + 14 * b);
+    if (rc) return rc;
+  }
   return PP_OK;
 }
 
@@ -1089,6 +1086,7 @@ int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, con
   const bool small = metric == 0 && nsamp < 150000;
   const int ch = metric == 0 ? (small || ncand <= 4 ? CH0S : CH0) : CH1, nv = metric == 0 ? 2 : 6;
   const int nchunk = (ncand + ch - 1) / ch;
+  PP_REQUIRE(ctx, nchunk <= PP_MAIL_WRITERS, "metric values: more chunks than mailbox writers");
   // Blocks per chunk: one sample per thread up to ~512 blocks in the whole launch (512 on big lattices, where 16 candidates
   // are one chunk; 128 on small ones, where they are four).  Measured on MI355X (profiles/round3_metric_probe_latency.txt):
   // beyond that a probe gets SLOWER with more blocks -- 1024 blocks of two samples per thread cost 76 / 150 us (1 / 16
@@ -1106,27 +1104,31 @@ int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, con
   if (rc) return rc;
   double* partials = reinterpret_cast<double*>(ctx->ws);
   char* mail = nullptr;
-  unsigned long long* flags = nullptr;
   unsigned long long seq = 0;
-  rc = pp_mailbox(ctx, &mail, &flags, &seq);
+  rc = pp_mailbox(ctx, &mail, &seq);
   if (rc) return rc;
-  double* hres = reinterpret_cast<double*>(mail);      // 16 x 6 doubles = 768 B of the payload area
   const float* fsamp = nullptr;
   rc = pp_fixed_samples(ctx, fixed, fsize, Af, bf, vsize, stride, fixed_mask, &fsamp);
   if (rc) return rc;
   if (metric == 0 && ch == CH0S)
     hipLaunchKernelGGL((k_metric_values<0, CH0S>), dim3(nb, nchunk), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask,
-                       moving_mask, a, ncand, partials, ticket, hres, flags, seq, fsamp);
+                       moving_mask, a, ncand, partials, ticket, mail, seq, fsamp);
   else if (metric == 0)
     hipLaunchKernelGGL((k_metric_values<0, CH0>), dim3(nb, nchunk), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask,
-                       moving_mask, a, ncand, partials, ticket, hres, flags, seq, fsamp);
+                       moving_mask, a, ncand, partials, ticket, mail, seq, fsamp);
   else
     hipLaunchKernelGGL((k_metric_values<1, CH1>), dim3(nb, nchunk), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask,
-                       moving_mask, a, ncand, partials, ticket, hres, flags, seq, fsamp);
+                       moving_mask, a, ncand, partials, ticket, mail, seq, fsamp);
   PP_LAUNCH_CHECK(ctx, "k_metric_values");
-  rc = pp_mail_wait(ctx, nchunk, seq);
-  if (rc) return rc;
-  memcpy(result, hres, (size_t)ncand * 6 * sizeof(double));
+  memset(result, 0, (size_t)ncand * 6 * sizeof(double));
+  for (int c = 0; c < nchunk; ++c) {
+    const int k = ncand - c * ch < ch ? ncand - c * ch : ch;
+    double vals[PP_MAIL_ENTRIES];
+    rc = pp_mail_take(ctx, c, k * nv, seq, vals);
+    if (rc) return rc;
+    for (int j = 0; j < k; ++j)
+      for (int f = 0; f < nv; ++f) result[((size_t)c * ch + j) * 6 + f] = vals[j * nv + f];
+  }
   return PP_OK;
 }
 
@@ -1182,16 +1184,16 @@ int pp_mi_gradient_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], cons
                      partials);
   PP_LAUNCH_CHECK(ctx, "k_mi_gradient");
   char* mail = nullptr;
-  unsigned long long* flags = nullptr;
   unsigned long long seq = 0;
-  rc = pp_mailbox(ctx, &mail, &flags, &seq);
+  rc = pp_mailbox(ctx, &mail, &seq);
   if (rc) return rc;
-  double* hres = reinterpret_cast<double*>(mail);
-  hipLaunchKernelGGL(k_sum14_final, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, 14, hres, flags, seq);
+  hipLaunchKernelGGL(k_sum14_final, dim3(1), dim3(NT), 0, ctx->stream, (const double*)partials, (int)nb, 14, reinterpret_cast<double*>(mail), 1,
+                     seq);
   PP_LAUNCH_CHECK(ctx, "k_sum14_final");
-  rc = pp_mail_wait(ctx, 1, seq);
+  double sums[14];
+  rc = pp_mail_take(ctx, 0, 14, seq, sums);
   if (rc) return rc;
-  memcpy(result, hres + 2, 12 * sizeof(double));
+  memcpy(result, sums + 2, 12 * sizeof(double));
   return PP_OK;
 }
 

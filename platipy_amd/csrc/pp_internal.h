@@ -92,13 +92,39 @@ int pp_ticket(pp_ctx* ctx, unsigned** out);
 constexpr int PP_HIST_CAP = 4096;
 int pp_history_buffer(pp_ctx* ctx, double** out);
 // Mailbox for kernels that hand a few numbers straight to the host: 4 KB of page-locked memory the device writes
-// through its host pointer.  Layout: bytes [0, 3072) payload, [3072, 4096) up to 128 completion flags (uint64).
-// A kernel stores its payload, __threadfence_system(), then stores the launch's sequence number into its flag;
-// pp_mail_wait spins on `nflags` flags (falling back to a stream sync if they do not arrive) -- no copy command and
-// no interrupt-driven wake-up between a launch-latency-bound kernel and the host code that consumes it.
-constexpr size_t PP_MAIL_FLAGS_OFF = 3072;
-int pp_mailbox(pp_ctx* ctx, char** payload, unsigned long long** flags, unsigned long long* seq);
-int pp_mail_wait(pp_ctx* ctx, int nflags, unsigned long long seq);
+// through its host pointer and the host polls -- no copy command and no interrupt-driven wake-up between a
+// launch-latency-bound kernel and the host code that consumes it.
+//   * Every number travels as ONE 16-byte store {value, tag} with tag = the launch's sequence number, and the host takes an
+//     entry when its tag matches (tag first, then value).  Nothing depends on the order in which separate device stores
+//     become visible in host memory.  (Until round 3 a payload was followed by a fence and a completion flag: once in a few
+//     hundred affine registrations the host read a flag ahead of the payload it announced -- posted writes to host memory
+//     may be reordered on the way -- took the previous launch's value for a candidate, and a line search branched
+//     differently: tools/determinism_linear.py.)
+//   * Up to PP_MAIL_WRITERS blocks of a launch post; writer k owns bytes [k * PP_MAIL_SLOT, (k + 1) * PP_MAIL_SLOT): its own
+//     cache lines (the writers run on different XCDs, each behind its own L2).
+struct alignas(16) pp_mail_entry {
+  double value;
+  unsigned long long tag;
+};
+constexpr size_t PP_MAIL_SLOT = 1024;         // bytes per writer: 64 entries
+constexpr int PP_MAIL_WRITERS = 4;
+constexpr int PP_MAIL_ENTRIES = (int)(PP_MAIL_SLOT / sizeof(pp_mail_entry));
+__host__ __device__ inline pp_mail_entry* pp_mail_slot(void* mailbox, int writer) {
+  return reinterpret_cast<pp_mail_entry*>(static_cast<char*>(mailbox) + (size_t)writer * PP_MAIL_SLOT);
+}
+// one 16-byte store
+__device__ __forceinline__ void pp_mail_post(pp_mail_entry* e, double value, unsigned long long tag) {
+  typedef unsigned long long u64x2 __attribute__((vector_size(16)));
+  u64x2 w;
+  w[0] = __builtin_bit_cast(unsigned long long, value);
+  w[1] = tag;
+  *reinterpret_cast<u64x2*>(e) = w;
+}
+// -> the mailbox and the sequence number of the next launch
+int pp_mailbox(pp_ctx* ctx, char** mailbox, unsigned long long* seq);
+// Wait for entries [0, n) of `writer` to carry `seq` and copy their values out (falls back to a stream synchronisation if
+// they do not arrive within 200 ms; an entry still missing after that is an error).
+int pp_mail_take(pp_ctx* ctx, int writer, int n, unsigned long long seq, double* out);
 
 #define PP_HIP(ctx, call)                                                              \
   do {                                                                                 \

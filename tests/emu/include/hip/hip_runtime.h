@@ -124,6 +124,19 @@ static inline double atomicAdd(double* p, double v) {
   do { o = *p; n = o + v; } while (!__atomic_compare_exchange(p, &o, &n, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST));
   return o;
 }
+// scoped atomic load / store builtins of clang's HIP mode (the scope is meaningless on the CPU)
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <class T>
+static inline T __hip_atomic_load(const T* p, int /*order*/, int /*scope*/) {
+  T v;
+  __atomic_load(const_cast<T*>(p), &v, __ATOMIC_SEQ_CST);
+  return v;
+}
+template <class T>
+static inline void __hip_atomic_store(T* p, T v, int /*order*/, int /*scope*/) {
+  __atomic_store(p, &v, __ATOMIC_SEQ_CST);
+}
+static inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
