@@ -865,9 +865,15 @@ int occ_warp() {
   return cache = (a < 1 ? 1 : a);
 }
 
+// PP_MINI (measurement builds, tools/kbench/mini.sh): only the radius-2, 512-thread instances exist, so the file compiles in
+// seconds while a kernel is being worked on.  Product builds never define it.
+#ifdef PP_MINI
+#define PP_BY_RADIUS(R, OPT, CALL) CALL(2, 2)
+#else
 #define PP_BY_RADIUS(R, OPT, CALL)                                                                   \
   ((OPT) == 4 ? ((R) == 1 ? CALL(1, 4) : ((R) == 2 ? CALL(2, 4) : CALL(3, 4)))                       \
               : ((R) == 1 ? CALL(1, 2) : ((R) == 2 ? CALL(2, 2) : ((R) == 3 ? CALL(3, 2) : ((R) == 4 ? CALL(4, 2) : CALL(5, 2))))))
+#endif
 
 // The 32 x 32 shape exists for the 512-thread layout only (OPT = 2).
 template <int R, int OPT>
@@ -918,8 +924,13 @@ int launch_warp(pp_ctx* ctx, int sh, const float* D, const float* Us, const floa
 
 // ---- generation 2 (pp_demons_fused2.h): 512-thread layout only, both tile shapes; kernel A for radii 1..3, kernel B 1..4
 // (beyond that the unrolled plane loop does not fit 128 registers and the first generation is faster).  SUM: see the header.
+#ifdef PP_MINI
+#define PP_BY_RADIUS_A2(R, CALL) CALL(2)
+#define PP_BY_RADIUS_B2(R, CALL) CALL(2)
+#else
 #define PP_BY_RADIUS_A2(R, CALL) ((R) == 1 ? CALL(1) : ((R) == 2 ? CALL(2) : CALL(3)))
 #define PP_BY_RADIUS_B2(R, CALL) ((R) == 1 ? CALL(1) : ((R) == 2 ? CALL(2) : ((R) == 3 ? CALL(3) : CALL(4))))
+#endif
 #define PP_A2_KERNEL(SHV, SUMV, NTV) k_fused2_force_smooth<R, SHV, (R <= PP_RING_UNROLL_MAX_R), SUMV, NTV>
 #define PP_B2_KERNEL(SHV, SUMV, NTV) k_fused2_add_smooth_warp<R, SHV, (R <= PP_RING_UNROLL_MAX_R), SUMV, NTV>
 
@@ -928,8 +939,12 @@ int occ_force2(int sh) {   // (cached: the answer depends on the kernel binary o
   static int cache[2] = {0, 0};
   if (cache[sh ? 1 : 0]) return cache[sh ? 1 : 0];
   int a = 0;
+#ifdef PP_MINI
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(0, true, true), 512, 0);
+#else
   const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(1, true, false), 512, 0)
                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(0, true, false), 512, 0);
+#endif
   if (e != hipSuccess) a = 2;
   (void)hipGetLastError();
   return cache[sh ? 1 : 0] = (a < 1 ? 1 : a);
@@ -939,8 +954,12 @@ int occ_warp2(int sh) {   // (cached: the answer depends on the kernel binary on
   static int cache[2] = {0, 0};
   if (cache[sh ? 1 : 0]) return cache[sh ? 1 : 0];
   int a = 0;
+#ifdef PP_MINI
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(0, true, true), 512, 0);
+#else
   const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(1, true, false), 512, 0)
                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(0, true, false), 512, 0);
+#endif
   if (e != hipSuccess) a = 2;
   (void)hipGetLastError();
   return cache[sh ? 1 : 0] = (a < 1 ? 1 : a);
@@ -952,6 +971,10 @@ int launch_force2(pp_ctx* ctx, int sh, bool sum, const float* F, const float* Mw
   const dim3 grid(8u * (unsigned)fu.per_xcd), block(512);
 #define PP_GO(SHV, SUMV, NTV) \
   hipLaunchKernelGGL((PP_A2_KERNEL(SHV, SUMV, NTV)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, st, prev, nprev, max_rms)
+#ifdef PP_MINI
+  (void)sh;
+  PP_GO(0, true, true);
+#else
   if (!sum) {   // (PP_FUSED_SUM=0, a measurement path: cached stores only)
     if (sh) PP_GO(1, false, false); else PP_GO(0, false, false);
   } else if (fu.streaming) {
@@ -959,6 +982,7 @@ int launch_force2(pp_ctx* ctx, int sh, bool sum, const float* F, const float* Mw
   } else {
     if (sh) PP_GO(1, true, false); else PP_GO(0, true, false);
   }
+#endif
 #undef PP_GO
   return PP_OK;
 }
@@ -968,6 +992,10 @@ int launch_warp2(pp_ctx* ctx, int sh, bool sum, const float* D, const float* Us,
   pp_prof_scope ps(ctx, sum ? "k_fused2_add_smooth_warp" : "k_fused2_add_smooth_warp/sep");
   const dim3 grid(8u * (unsigned)fd.per_xcd), block(512);
 #define PP_GO(SHV, SUMV, NTV) hipLaunchKernelGGL((PP_B2_KERNEL(SHV, SUMV, NTV)), grid, block, 0, ctx->stream, D, Us, M, Dn, Mw_out, fd, sc, halt)
+#ifdef PP_MINI
+  (void)sh;
+  PP_GO(0, true, true);
+#else
   if (!sum) {
     if (sh) PP_GO(1, false, false); else PP_GO(0, false, false);
   } else if (fd.streaming) {
@@ -975,6 +1003,7 @@ int launch_warp2(pp_ctx* ctx, int sh, bool sum, const float* D, const float* Us,
   } else {
     if (sh) PP_GO(1, true, false); else PP_GO(0, true, false);
   }
+#endif
 #undef PP_GO
   return PP_OK;
 }

@@ -459,6 +459,48 @@ __device__ __forceinline__ void fused2_plane_loop(F& step, int nsteps) {
     for (int n = 0; n < nsteps; ++n) step(n, pp_phase<-1>{});
   }
 }
+// Round 4: the plane loop in three parts.  Steps s_lo <= n < s_hi are STEADY: every wave-uniform condition of the step (a
+// fresh plane either side, an output plane, a plane to prefetch, every lane inside the volume) holds, so `step(n, phase,
+// pp_steady<true>)` is straight-line code around its memory instructions.  That matters for more than the branches: the
+// hardware's vmcnt counts loads AND stores in issue order and the compiler's s_waitcnt pass merges the states of all paths
+// into a step, so with the conditions dynamic every wait for an old load was emitted as the wait of the worst path --
+// vmcnt(0) right behind the warp's gathers, between the field stores, at the top of a step -- and each wave sat out the
+// acknowledgement of the stores and the HBM latency of the loads it had issued a moment earlier (47-61 % of wave cycles in
+// SQ_WAIT_ANY, profiles/round3_pmc_counters.md).  The steady steps run in whole groups of 2R+1 window phases (renamed z
+// window); the steps before and after run the general step with the shifting window (P = -1), whose window order equals the
+// renamed one's at every group boundary.
+template <bool B>
+struct pp_steady { static constexpr bool value = B; };
+template <int P, int W>
+struct pp_steady_unroll {
+  template <class F>
+  static __device__ __forceinline__ void run(F& step, int n0) {
+    step(n0 + P, pp_phase<P>{}, pp_steady<true>{});
+    pp_steady_unroll<P + 1, W>::run(step, n0);
+  }
+};
+template <int W>
+struct pp_steady_unroll<W, W> {
+  template <class F>
+  static __device__ __forceinline__ void run(F&, int) {}
+};
+#ifndef PP_STEADY
+#define PP_STEADY 1
+#endif
+template <int R, bool UNROLL, class F>
+__device__ __forceinline__ void fused2_plane_loop3(F& step, int nsteps, int s_lo, int s_hi) {
+  constexpr int W = 2 * R + 1;
+  int n = 0;
+  if (PP_STEADY != 0 && s_hi - s_lo >= (UNROLL ? W : 1)) {
+    for (; n < s_lo; ++n) step(n, pp_phase<-1>{}, pp_steady<false>{});
+    if constexpr (UNROLL) {
+      for (; n + W <= s_hi; n += W) pp_steady_unroll<0, W>::run(step, n);
+    } else {
+      for (; n < s_hi; ++n) step(n, pp_phase<-1>{}, pp_steady<true>{});
+    }
+  }
+  for (; n < nsteps; ++n) step(n, pp_phase<-1>{}, pp_steady<false>{});
+}
 
 // ---- kernel B, generation 2: D' = G_d * (D + U), then the next iteration's warped moving image --------
 // SUM: `Us` already holds D + U (kernel A<SUM> added D at its own output voxels, where it needs no halo), `D` is not read:
@@ -518,14 +560,18 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
   const int nsteps = ze - zs + 1;
 
   float4 dl[SUM ? 1 : 3][G::NSL], ul[3][G::NSL];   // raw D and U strips of the plane about to be published
-  auto load_plane = [&](int zc) {
+  // (ALL: every lane loads -- a lane without a strip re-reads strip 0 of the tile, whose address pp_strip_setup gave it -- so
+  // that no divergent branch surrounds the loads of a steady step: inside one, the compiler copies the loaded registers at
+  // once and waits for the load it has just issued)
+  auto load_plane = [&](int zc, auto all_tag) {
+    constexpr bool ALL = decltype(all_tag)::value;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const char* const pd = SUM ? nullptr : reinterpret_cast<const char*>(D + c * N + (size_t)zc * sz);
       const char* const pu = reinterpret_cast<const char*>(Us + c * N + (size_t)zc * sz);
 #pragma unroll
       for (int i = 0; i < G::NSL; ++i)
-        if ((i + 1) * NTH <= G::NS || st[i].slot >= 0) {
+        if (ALL || (i + 1) * NTH <= G::NS || st[i].slot >= 0) {
 #ifdef PP_ABL_NOLOAD
           if constexpr (!SUM) dl[c][i] = make_float4((float)st[i].goff * 1e-9f + (float)zc, 0.f, 1.f, 2.f);
           ul[c][i] = make_float4((float)st[i].goff * 1e-9f, 1.f, 0.f, 3.f);
@@ -564,15 +610,15 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
   // prologue: first plane through publish + x pass, second plane in flight
   {
     const int zc0 = pp_clampi(zs, 0, d.nz - 1);
-    load_plane(zc0);
+    load_plane(zc0, pp_steady<false>{});
     if constexpr (XS) {
       const float4 s3[3] = {ul[0][0], ul[1][0], ul[2][0]};
       fused2_xpass_shfl<R, G>(s3, st[0].jm, xs_out, xs_off, s_x, a.wx);
-      if (zc0 < zhi) load_plane(zc0 + 1);
+      if (zc0 < zhi) load_plane(zc0 + 1, pp_steady<false>{});
       __syncthreads();
     } else {
       publish();
-      if (zc0 < zhi) load_plane(zc0 + 1);
+      if (zc0 < zhi) load_plane(zc0 + 1, pp_steady<false>{});
       __syncthreads();
       fused2_xpass_strips<R, G>(s_u, s_x, a.wx, xsrc, xdst);
       __syncthreads();
@@ -582,13 +628,19 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
 
   const bool trace_on = (rank == (unsigned)(a.gx * (a.gy / 2) + a.gx / 2));   // (PP_TRACE builds: an interior tile, first z-chunk)
   (void)trace_on;
-  auto step = [&](int n, auto phase_tag) {
+  // steady steps (fused2_plane_loop3): planes zi - 1, zi, zi + 1, zi + 2 exist, zi - R is an output plane of this chunk and
+  // the tile lies inside the volume with even rows, so every lane stores pairs
+  const bool tile_full = (tx0 + TX <= d.nx) && (ty0 + TY <= d.ny) && pair_ok;
+  const int s_lo = (2 * R > 1 - zs) ? 2 * R : 1 - zs;
+  const int s_hi = tile_full ? zhi - 1 - zs : 0;
+  auto step = [&](int n, auto phase_tag, auto steady_tag) {
     constexpr int P = decltype(phase_tag)::value;
+    constexpr bool ST = decltype(steady_tag)::value;
     const int zi = zs + n;
-    const int cur = pp_clampi(zi, 0, d.nz - 1);
-    const bool fresh_cur = (n == 0) || (cur != pp_clampi(zi - 1, 0, d.nz - 1));
-    const int nxt = pp_clampi(zi + 1, 0, d.nz - 1);
-    const bool fresh_next = (n + 1 < nsteps) && (nxt != cur);
+    const int cur = ST ? zi : pp_clampi(zi, 0, d.nz - 1);
+    const bool fresh_cur = ST || (n == 0) || (cur != pp_clampi(zi - 1, 0, d.nz - 1));
+    const int nxt = ST ? zi + 1 : pp_clampi(zi + 1, 0, d.nz - 1);
+    const bool fresh_next = ST || ((n + 1 < nsteps) && (nxt != cur));
     PP_TRACE_MARK(trace_on, 1, n, 0);
     // ---- interval 1: y pass of plane `cur` (reads s_x) | publish plane `nxt` (writes s_u) ----
     if (fresh_cur) {
@@ -606,7 +658,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
     float dn[3][2];
     fused2_ring<R, P>(rg, v, a.wz, dn);
     const int zo = zi - R;
-    const bool emit = (zo >= z0) && (zo <= zo_last);
+    const bool emit = ST || ((zo >= z0) && (zo <= zo_last));
     float mw0 = FLT_MAX, mw1 = FLT_MAX;
 #ifdef PP_ABL_NOGATHER
     if (emit) {
@@ -618,8 +670,8 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
     // their latency hides behind the field stores, a barrier and the x pass instead of stalling the wave at once.
     pp_warp_pending g0, g1;
     if (emit) {
-      fused2_warp_issue(rm, wd, x, dn[0][0] * sc.ix, y, dn[1][0] * sc.iy, zo, dn[2][0] * sc.iz, out_ok, g0);
-      fused2_warp_issue(rm, wd, x + 1, dn[0][1] * sc.ix, y, dn[1][1] * sc.iy, zo, dn[2][1] * sc.iz, out_ok && (x + 1 < d.nx), g1);
+      fused2_warp_issue(rm, wd, x, dn[0][0] * sc.ix, y, dn[1][0] * sc.iy, zo, dn[2][0] * sc.iz, ST || out_ok, g0);
+      fused2_warp_issue(rm, wd, x + 1, dn[0][1] * sc.ix, y, dn[1][1] * sc.iy, zo, dn[2][1] * sc.iz, ST || (out_ok && (x + 1 < d.nx)), g1);
 #if !PP_B_DEFER
       mw0 = fused2_warp_finish(g0);
       mw1 = fused2_warp_finish(g1);
@@ -627,11 +679,15 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
     }
 #endif
     // the plane after `nxt` goes in flight behind the gathers
-    if (fresh_next && nxt < zhi) load_plane(nxt + 1);
+    // (steady steps pin the issue order gathers -> strip loads -> field stores: vmcnt retires in issue order, so the wait for
+    // the gathers behind the barrier must not have the younger HBM loads ahead of it)
+    if constexpr (ST) __builtin_amdgcn_sched_barrier(0);
+    if (ST || (fresh_next && nxt < zhi)) load_plane(nxt + 1, pp_steady<(ST && G::NSL == 1)>{});
+    if constexpr (ST) __builtin_amdgcn_sched_barrier(0);
     const size_t po = (size_t)zo * sz;
     const unsigned po4 = (unsigned)zo * sz * 4u, N4 = (unsigned)N * 4u;   // (3 N * 4 < 2^32: checked on the host)
     auto store_field = [&]() {
-      if (pair_ok) {
+      if (ST || pair_ok) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           if constexpr (PP_SOFF != 0) pp_bst2ss<NT>(r_dn, o_xy, c * N4 + po4, dn[c][0], dn[c][1]);
@@ -649,7 +705,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
       }
     };
     auto store_image = [&]() {
-      if (pair_ok) {
+      if (ST || pair_ok) {
         if constexpr (PP_SOFF != 0) pp_bst2ss<NT>(r_mw, o_xy, po4, mw0, mw1);
         else pp_bst2s<NT>(pp_make_rsrc(Mw + po), o_xy, mw0, mw1);
       } else if (x + 1 < d.nx) {
@@ -662,7 +718,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
 #ifdef PP_ABL_NOSTORE
     const bool do_store = emit && out_ok && dn[0][0] == 3.21e-29f && dn[1][1] == 1e-31f && dn[2][0] == 7e-33f && dn[0][1] == 2e-30f && dn[1][0] == 3e-30f && dn[2][1] == 4e-30f;
 #else
-    const bool do_store = emit && out_ok;
+    const bool do_store = ST || (emit && out_ok);
 #endif
     if (do_store) {
       store_field();
@@ -670,6 +726,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
       store_image();
 #endif
     }
+    if constexpr (ST) __builtin_amdgcn_sched_barrier(0);
     // ---- interval 2: x pass of plane `nxt` (XS: already done above; one barrier hands the buffers over) ----
     PP_TRACE_MARK(trace_on, 1, n, 1);
     if (fresh_next) {
@@ -691,7 +748,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
 #endif
     PP_TRACE_MARK(trace_on, 1, n, 3);
   };
-  fused2_plane_loop<R, UNROLL>(step, nsteps);
+  fused2_plane_loop3<R, UNROLL>(step, nsteps, s_lo, s_hi);
 }
 
 // pp_esm_axis with the border rules carried by DATA instead of per-lane flags (the hoisted flag masks cost kernel A ~36
@@ -867,9 +924,10 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
       }
     }
   };
-  auto esm = [&](int zc) __attribute__((always_inline)) {   // update at every smoothing-input voxel of plane zc (the window centre) -> s_u, then rotate
+  auto esm = [&](int zc, auto interior_tag) __attribute__((always_inline)) {   // update at every smoothing-input voxel of plane zc (the window centre) -> s_u, then rotate
+    constexpr bool ZIN = decltype(interior_tag)::value;   // 0 < zc < nz - 1 known at compile time (steady steps)
     const bool count_plane = (zc >= z0 && zc <= zo_last);
-    const bool zlo_b = (zc == 0), zhi_b = (zc == d.nz - 1);
+    const bool zlo_b = ZIN ? false : (zc == 0), zhi_b = ZIN ? false : (zc == d.nz - 1);
 #pragma unroll
     for (int k = 0; k < G::KU; ++k) {
       const unsigned fl = uflag[k] >> 16;
@@ -913,8 +971,8 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
 
   float2 dsum[SUM ? 3 : 1];
   const unsigned o_xy1 = (x + 1 < d.nx) ? o_xy + 4u : o_xy;
-  auto load_dsum = [&](int zo) {
-    if (zo >= z0 && zo <= zo_last && out_ok) {
+  auto load_dsum = [&](int zo, auto always_tag) {
+    if (decltype(always_tag)::value || (zo >= z0 && zo <= zo_last && out_ok)) {
       const size_t po = (size_t)zo * sz;
 #pragma unroll
       for (int c = 0; c < (SUM ? 3 : 1); ++c) {   // two 4-byte buffer loads: no alignment case, no branch (x + 1 == nx re-reads x)
@@ -950,26 +1008,33 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     publish();
     prefetch(zc0);
     __syncthreads();
-    esm(zc0);
+    esm(zc0, pp_steady<false>{});
     {   // step 0's image loads (see the end of the plane step)
       const int n1 = pp_clampi(zs + 1, 0, d.nz - 1);
       if (nsteps > 1 && n1 != zc0) prefetch(n1);
     }
-    if constexpr (SUM) load_dsum(zs - R);
+    if constexpr (SUM) load_dsum(zs - R, pp_steady<false>{});
     __syncthreads();
   }
 
   const bool trace_on = (rank == (unsigned)(a.gx * (a.gy / 2) + a.gx / 2));   // (PP_TRACE builds: an interior tile, first z-chunk)
   (void)trace_on;
-  auto step = [&](int n, auto phase_tag) {
+  // steady steps (fused2_plane_loop3): planes zi - 1 .. zi + 2 exist and zi + 1 is not the last one (no z-border rule in the
+  // update of plane zi + 1), zi - R and zi - R + 1 are output planes of this chunk, and the tile lies inside the volume with
+  // even rows, so every lane loads D and stores pairs
+  const bool tile_full = (tx0 + TX <= d.nx) && (ty0 + TY <= d.ny) && pair_ok;
+  const int s_lo = (2 * R > 1 - zs) ? 2 * R : 1 - zs;
+  const int s_hi = tile_full ? ((d.nz - 3 < ze - 2) ? d.nz - 3 : ze - 2) - zs + 1 : 0;
+  auto step = [&](int n, auto phase_tag, auto steady_tag) {
     constexpr int P = decltype(phase_tag)::value;
+    constexpr bool ST = decltype(steady_tag)::value;
     const int zi = zs + n;
-    const int cur = pp_clampi(zi, 0, d.nz - 1);
-    const bool fresh_cur = (n == 0) || (cur != pp_clampi(zi - 1, 0, d.nz - 1));
-    const int nxt = pp_clampi(zi + 1, 0, d.nz - 1);
-    const bool fresh_next = (n + 1 < nsteps) && (nxt != cur);
+    const int cur = ST ? zi : pp_clampi(zi, 0, d.nz - 1);
+    const bool fresh_cur = ST || (n == 0) || (cur != pp_clampi(zi - 1, 0, d.nz - 1));
+    const int nxt = ST ? zi + 1 : pp_clampi(zi + 1, 0, d.nz - 1);
+    const bool fresh_next = ST || ((n + 1 < nsteps) && (nxt != cur));
     const int zo = zi - R;
-    const bool emit = (zo >= z0) && (zo <= zo_last) && out_ok;
+    const bool emit = ST || ((zo >= z0) && (zo <= zo_last) && out_ok);
     PP_TRACE_MARK(trace_on, 0, n, 0);
     // ---- interval 1: x pass of plane `cur` (s_u -> s_x) | publish the image tile of plane `nxt` ----
     if (fresh_next) publish();
@@ -982,20 +1047,25 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
 #pragma unroll
       for (int c = 0; c < 3; ++c) fused2_ypass<R, SH>(s_x, c, yb, a.wy, v[c]);
     }
-    if (fresh_next) esm(nxt);
+    if (fresh_next) esm(nxt, steady_tag);
     float us[3][2];
     fused2_ring<R, P>(rg, v, a.wz, us);
     if (emit) {
       const size_t po = (size_t)zo * sz;
+      // (all three adds before the first store: the adds wait for the D loads of the previous step, and a wait placed
+      // between two stores also waits for the first store's acknowledgement -- vmcnt counts in issue order)
+      if constexpr (SUM) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        if constexpr (SUM) {
+        for (int c = 0; c < 3; ++c) {
           us[c][0] = dsum[c].x + us[c][0];
           us[c][1] = dsum[c].y + us[c][1];
         }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
         if constexpr (PP_SOFF != 0) {
           const unsigned so = ((unsigned)c * (unsigned)N + (unsigned)po) * 4u;
-          if (pair_ok) {
+          if (ST || pair_ok) {
             pp_bst2ss<NT>(r_us, o_xy, so, us[c][0], us[c][1]);
           } else if (x + 1 < d.nx) {
             pp_gst2(reinterpret_cast<char*>(Us + c * N + po), o_xy, us[c][0], us[c][1]);
@@ -1017,15 +1087,15 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     // The next step's loads go in flight here, behind this step's stores, so that no wait of this step has them
     // pending: the image planes are consumed by the next ESM pass, D (SUM) by the next stores.
     {
-      const int nxt2 = pp_clampi(zi + 2, 0, d.nz - 1);
-      if ((n + 2 < nsteps) && (nxt2 != nxt)) prefetch(nxt2);
+      const int nxt2 = ST ? zi + 2 : pp_clampi(zi + 2, 0, d.nz - 1);
+      if (ST || ((n + 2 < nsteps) && (nxt2 != nxt))) prefetch(nxt2);
     }
-    if constexpr (SUM) load_dsum(zo + 1);
+    if constexpr (SUM) load_dsum(zo + 1, steady_tag);
     PP_TRACE_MARK(trace_on, 0, n, 3);
     if (fresh_cur || fresh_next) __syncthreads();
     PP_TRACE_MARK(trace_on, 0, n, 4);
   };
-  fused2_plane_loop<R, UNROLL>(step, nsteps);
+  fused2_plane_loop3<R, UNROLL>(step, nsteps, s_lo, s_hi);
   double r_ssd = (double)a_ssd, r_ssc = (double)a_ssc, r_n = (double)a_n;
   pp_block_sum3_shfl<NTH>(r_ssd, r_ssc, r_n, reinterpret_cast<double*>(s_u));
   if (t == 0) {
