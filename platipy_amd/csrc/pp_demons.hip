@@ -387,6 +387,7 @@ struct fused_args {
   int gx, gy, gz;   // tile grid
   int per_xcd;      // ceil(gx * gy * gz / 8)
   int streaming;    // generation 2: non-temporal output stores (volumes far beyond the infinity cache)
+  int masked;       // generation 2: the MASK kernels (even rows, a whole field under 2^31 bytes; pp_demons_fused2.h)
   pp_taps_small wx, wy, wz;
 };
 
@@ -931,8 +932,11 @@ int launch_warp(pp_ctx* ctx, int sh, const float* D, const float* Us, const floa
 #define PP_BY_RADIUS_A2(R, CALL) ((R) == 1 ? CALL(1) : ((R) == 2 ? CALL(2) : CALL(3)))
 #define PP_BY_RADIUS_B2(R, CALL) ((R) == 1 ? CALL(1) : ((R) == 2 ? CALL(2) : ((R) == 3 ? CALL(3) : CALL(4))))
 #endif
-#define PP_A2_KERNEL(SHV, SUMV, NTV) k_fused2_force_smooth<R, SHV, (R <= PP_RING_UNROLL_MAX_R), SUMV, NTV>
-#define PP_B2_KERNEL(SHV, SUMV, NTV) k_fused2_add_smooth_warp<R, SHV, (R <= PP_RING_UNROLL_MAX_R), SUMV, NTV>
+#define PP_A2_KERNEL(SHV, SUMV, NTV, MASKV) k_fused2_force_smooth<R, SHV, (R <= PP_RING_UNROLL_MAX_R), SUMV, NTV, MASKV>
+#define PP_B2_KERNEL(SHV, SUMV, NTV, MASKV) k_fused2_add_smooth_warp<R, SHV, (R <= PP_RING_UNROLL_MAX_R), SUMV, NTV, MASKV>
+#ifndef PP_MINI_MASK
+#define PP_MINI_MASK true
+#endif
 
 template <int R>
 int occ_force2(int sh) {   // (cached: the answer depends on the kernel binary only, and the query costs ~10 us per call)
@@ -940,10 +944,10 @@ int occ_force2(int sh) {   // (cached: the answer depends on the kernel binary o
   if (cache[sh ? 1 : 0]) return cache[sh ? 1 : 0];
   int a = 0;
 #ifdef PP_MINI
-  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(0, true, true), 512, 0);
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(0, true, true, PP_MINI_MASK), 512, 0);
 #else
-  const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(1, true, false), 512, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(0, true, false), 512, 0);
+  const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(1, true, false, true), 512, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(0, true, false, true), 512, 0);
 #endif
   if (e != hipSuccess) a = 2;
   (void)hipGetLastError();
@@ -955,10 +959,10 @@ int occ_warp2(int sh) {   // (cached: the answer depends on the kernel binary on
   if (cache[sh ? 1 : 0]) return cache[sh ? 1 : 0];
   int a = 0;
 #ifdef PP_MINI
-  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(0, true, true), 512, 0);
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(0, true, true, PP_MINI_MASK), 512, 0);
 #else
-  const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(1, true, false), 512, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(0, true, false), 512, 0);
+  const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(1, true, false, true), 512, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(0, true, false, true), 512, 0);
 #endif
   if (e != hipSuccess) a = 2;
   (void)hipGetLastError();
@@ -969,18 +973,21 @@ int launch_force2(pp_ctx* ctx, int sh, bool sum, const float* F, const float* Mw
                   const pp_esm_consts& K, double* partials, pp_dev_stats* st, const double* prev, int nprev, double max_rms) {
   pp_prof_scope ps(ctx, sum ? "k_fused2_force_smooth" : "k_fused2_force_smooth/sep");   // (bench.py keys its byte model on the name)
   const dim3 grid(8u * (unsigned)fu.per_xcd), block(512);
-#define PP_GO(SHV, SUMV, NTV) \
-  hipLaunchKernelGGL((PP_A2_KERNEL(SHV, SUMV, NTV)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, st, prev, nprev, max_rms)
+#define PP_GO(SHV, SUMV, NTV, MASKV) \
+  hipLaunchKernelGGL((PP_A2_KERNEL(SHV, SUMV, NTV, MASKV)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, st, prev, nprev, max_rms)
 #ifdef PP_MINI
   (void)sh;
-  PP_GO(0, true, true);
+  PP_GO(0, true, true, PP_MINI_MASK);
 #else
   if (!sum) {   // (PP_FUSED_SUM=0, a measurement path: cached stores only)
-    if (sh) PP_GO(1, false, false); else PP_GO(0, false, false);
+    if (sh) PP_GO(1, false, false, false); else PP_GO(0, false, false, false);
+  } else if (fu.masked) {
+    if (fu.streaming) { if (sh) PP_GO(1, true, true, true); else PP_GO(0, true, true, true); }
+    else { if (sh) PP_GO(1, true, false, true); else PP_GO(0, true, false, true); }
   } else if (fu.streaming) {
-    if (sh) PP_GO(1, true, true); else PP_GO(0, true, true);
+    if (sh) PP_GO(1, true, true, false); else PP_GO(0, true, true, false);
   } else {
-    if (sh) PP_GO(1, true, false); else PP_GO(0, true, false);
+    if (sh) PP_GO(1, true, false, false); else PP_GO(0, true, false, false);
   }
 #endif
 #undef PP_GO
@@ -991,17 +998,20 @@ int launch_warp2(pp_ctx* ctx, int sh, bool sum, const float* D, const float* Us,
                  const fused_args& fd, const pp_warp_scale& sc, const int* halt) {
   pp_prof_scope ps(ctx, sum ? "k_fused2_add_smooth_warp" : "k_fused2_add_smooth_warp/sep");
   const dim3 grid(8u * (unsigned)fd.per_xcd), block(512);
-#define PP_GO(SHV, SUMV, NTV) hipLaunchKernelGGL((PP_B2_KERNEL(SHV, SUMV, NTV)), grid, block, 0, ctx->stream, D, Us, M, Dn, Mw_out, fd, sc, halt)
+#define PP_GO(SHV, SUMV, NTV, MASKV) hipLaunchKernelGGL((PP_B2_KERNEL(SHV, SUMV, NTV, MASKV)), grid, block, 0, ctx->stream, D, Us, M, Dn, Mw_out, fd, sc, halt)
 #ifdef PP_MINI
   (void)sh;
-  PP_GO(0, true, true);
+  PP_GO(0, true, true, PP_MINI_MASK);
 #else
   if (!sum) {
-    if (sh) PP_GO(1, false, false); else PP_GO(0, false, false);
+    if (sh) PP_GO(1, false, false, false); else PP_GO(0, false, false, false);
+  } else if (fd.masked) {
+    if (fd.streaming) { if (sh) PP_GO(1, true, true, true); else PP_GO(0, true, true, true); }
+    else { if (sh) PP_GO(1, true, false, true); else PP_GO(0, true, false, true); }
   } else if (fd.streaming) {
-    if (sh) PP_GO(1, true, true); else PP_GO(0, true, true);
+    if (sh) PP_GO(1, true, true, false); else PP_GO(0, true, true, false);
   } else {
-    if (sh) PP_GO(1, true, false); else PP_GO(0, true, false);
+    if (sh) PP_GO(1, true, false, false); else PP_GO(0, true, false, false);
   }
 #endif
 #undef PP_GO
@@ -1021,6 +1031,8 @@ void fused_grid(fused_args* f, const pp_dims& d, int occupancy, int sh, char ker
   // nt stores, 113 MB -1.5 %, 180 MB -2 %, 268 MB -2.7 %.
   f->streaming = (size_t)d.nx * d.ny * d.nz * sizeof(float) > ((size_t)100 << 20);
   if (const char* e = getenv("PP_FUSED_NT")) f->streaming = atoi(e) != 0;
+  f->masked = (d.nx % 2 == 0) && 3 * (size_t)d.nx * d.ny * d.nz * sizeof(float) < ((size_t)1 << 31);
+  if (const char* e = getenv("PP_FUSED_MASK")) f->masked = f->masked && atoi(e) != 0;   // (0: the branchy kernels, for A/B runs)
 }
 
 int check_demons_args(pp_ctx* ctx, const pp_geom* g, const pp_demons_params* p) {

@@ -45,6 +45,14 @@ typedef unsigned pp_u2 __attribute__((vector_size(8)));
 __device__ __forceinline__ pp_rsrc pp_make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
 }
+// Resource over the first 2^31 bytes only: a lane whose per-lane offset is PP_OOB (= 2^31) is outside it and the hardware
+// drops its store -- the lane mask of a store without a branch around it.  (Raw buffers range-check the per-lane offset;
+// whether the scalar offset takes part differs between ISA generations, so callers keep offset + scalar offset < 2^32 and
+// whole arrays under 2^31 bytes: then a valid lane is inside and a masked lane outside under either rule.)
+constexpr unsigned PP_OOB = 0x80000000u;
+__device__ __forceinline__ pp_rsrc pp_make_rsrc_masked(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)PP_OOB, 0x00020000);
+}
 __device__ __forceinline__ float pp_bld(pp_rsrc r, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
@@ -485,13 +493,19 @@ struct pp_steady_unroll<W, W> {
   static __device__ __forceinline__ void run(F&, int) {}
 };
 #ifndef PP_STEADY
-#define PP_STEADY 1
+#define PP_STEADY 0
+#endif
+#ifndef PP_B_FINISH_AFTER_BARRIER
+#define PP_B_FINISH_AFTER_BARRIER 1
+#endif
+#ifndef PP_A_STEADY
+#define PP_A_STEADY 0
 #endif
 template <int R, bool UNROLL, class F>
 __device__ __forceinline__ void fused2_plane_loop3(F& step, int nsteps, int s_lo, int s_hi) {
   constexpr int W = 2 * R + 1;
   int n = 0;
-  if (PP_STEADY != 0 && s_hi - s_lo >= (UNROLL ? W : 1)) {
+  if (s_hi - s_lo >= (UNROLL ? W : 1)) {
     for (; n < s_lo; ++n) step(n, pp_phase<-1>{}, pp_steady<false>{});
     if constexpr (UNROLL) {
       for (; n + W <= s_hi; n += W) pp_steady_unroll<0, W>::run(step, n);
@@ -505,7 +519,14 @@ __device__ __forceinline__ void fused2_plane_loop3(F& step, int nsteps, int s_lo
 // ---- kernel B, generation 2: D' = G_d * (D + U), then the next iteration's warped moving image --------
 // SUM: `Us` already holds D + U (kernel A<SUM> added D at its own output voxels, where it needs no halo), `D` is not read:
 // three halo'd arrays instead of six.  The sum is the same fp32 add on the same operands, so the fields are bit-identical.
-template <int R, int SH, bool UNROLL, bool SUM, bool NT>
+// MASK (round 4): every memory instruction of a plane step is issued by every wave on every step -- loads from clamped
+// addresses, stores with the lane mask carried by the offset (PP_OOB) -- so that no branch surrounds one.  The s_waitcnt pass
+// merges the counter states of all paths into a point, and vmcnt retires loads AND stores in issue order: with the stores
+// and gathers inside `if (emit)` / `if (out_ok)` regions every wait for an old load was emitted as the wait of the worst
+// path (vmcnt(0) right behind the warp's gathers, between the field stores, at the top of a step), and each wave sat out the
+// acknowledgement of its own stores and the HBM latency of the loads it had just issued.  The host picks MASK when rows are
+// even (8-byte buffer stores need 8-byte alignment) and a whole field spans < 2^31 bytes.
+template <int R, int SH, bool UNROLL, bool SUM, bool NT, bool MASK>
 __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(const float* __restrict__ D, const float* __restrict__ Us,
                                                                             const float* __restrict__ M, float* __restrict__ Dn,
                                                                             float* __restrict__ Mw, fused_args a, pp_warp_scale sc,
@@ -551,7 +572,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
   const unsigned o_xy = ((unsigned)y * sy + (unsigned)x) * 4u;
   const pp_warp_dims wd{d.nx, d.ny, d.nz, (unsigned)d.nx * 4u, sz * 4u};
   const char* const rm = reinterpret_cast<const char*>(M);
-  const pp_rsrc r_dn = pp_make_rsrc(Dn), r_mw = pp_make_rsrc(Mw);   // one resource per output array (PP_SOFF)
+  const pp_rsrc r_dn = MASK ? pp_make_rsrc_masked(Dn) : pp_make_rsrc(Dn), r_mw = MASK ? pp_make_rsrc_masked(Mw) : pp_make_rsrc(Mw);   // one resource per output array (PP_SOFF)
 
   const int zs = z0 - R;
   const int zo_last = (z0 + a.zchunk - 1 < d.nz - 1) ? z0 + a.zchunk - 1 : d.nz - 1;
@@ -659,6 +680,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
     fused2_ring<R, P>(rg, v, a.wz, dn);
     const int zo = zi - R;
     const bool emit = ST || ((zo >= z0) && (zo <= zo_last));
+    constexpr bool UNC = MASK || ST;   // memory instructions issued unconditionally (see MASK above the kernel)
     float mw0 = FLT_MAX, mw1 = FLT_MAX;
 #ifdef PP_ABL_NOGATHER
     if (emit) {
@@ -666,10 +688,11 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
       mw1 = dn[0][1] + dn[1][1] * dn[2][1];
     }
 #else
-    // The 8 corner loads of the two samples are issued here and consumed after the next plane's x pass (PP_B_DEFER):
-    // their latency hides behind the field stores, a barrier and the x pass instead of stalling the wave at once.
+    // The 8 corner loads of the two samples are issued here and consumed after the barrier (PP_B_DEFER): their latency hides
+    // behind the strip loads, the field stores and the barrier instead of stalling the wave at once.  (UNC: also on steps
+    // that emit nothing -- the displacement is clamped, so the addresses are valid, and the result is never stored.)
     pp_warp_pending g0, g1;
-    if (emit) {
+    if (UNC || emit) {
       fused2_warp_issue(rm, wd, x, dn[0][0] * sc.ix, y, dn[1][0] * sc.iy, zo, dn[2][0] * sc.iz, ST || out_ok, g0);
       fused2_warp_issue(rm, wd, x + 1, dn[0][1] * sc.ix, y, dn[1][1] * sc.iy, zo, dn[2][1] * sc.iz, ST || (out_ok && (x + 1 < d.nx)), g1);
 #if !PP_B_DEFER
@@ -678,20 +701,33 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
 #endif
     }
 #endif
-    // the plane after `nxt` goes in flight behind the gathers
-    // (steady steps pin the issue order gathers -> strip loads -> field stores: vmcnt retires in issue order, so the wait for
-    // the gathers behind the barrier must not have the younger HBM loads ahead of it)
-    if constexpr (ST) __builtin_amdgcn_sched_barrier(0);
-    if (ST || (fresh_next && nxt < zhi)) load_plane(nxt + 1, pp_steady<(ST && G::NSL == 1)>{});
-    if constexpr (ST) __builtin_amdgcn_sched_barrier(0);
-    const size_t po = (size_t)zo * sz;
-    const unsigned po4 = (unsigned)zo * sz * 4u, N4 = (unsigned)N * 4u;   // (3 N * 4 < 2^32: checked on the host)
+    // the plane after `nxt` goes in flight behind the gathers.  UNC pins the issue order gathers -> strip loads -> field
+    // stores: vmcnt retires in issue order, so the wait for the gathers must not have the younger HBM loads ahead of it.
+    if constexpr (UNC) {
+      __builtin_amdgcn_sched_barrier(0);
+      // (steps that would not load re-read the plane the strips already hold: min(nxt + 1, zhi))
+      const int zl = ST ? nxt + 1 : (nxt + 1 < zhi ? nxt + 1 : zhi);
+      load_plane(zl, pp_steady<(G::NSL == 1)>{});
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      if (fresh_next && nxt < zhi) load_plane(nxt + 1, pp_steady<false>{});
+    }
+    const int zoc = (UNC && !ST) ? pp_clampi(zo, z0, zo_last) : zo;   // (a plane of this chunk also when nothing is stored)
+    const size_t po = (size_t)zoc * sz;
+    const unsigned po4 = (unsigned)zoc * sz * 4u, N4 = (unsigned)N * 4u;   // (3 N * 4 < 2^32: checked on the host)
+#ifdef PP_ABL_NOSTORE
+    const bool do_store = emit && out_ok && dn[0][0] == 3.21e-29f && dn[1][1] == 1e-31f && dn[2][0] == 7e-33f && dn[0][1] == 2e-30f && dn[1][0] == 3e-30f && dn[2][1] == 4e-30f;
+#else
+    const bool do_store = ST || (emit && out_ok);
+#endif
+    // UNC: one store form (even rows), the lane mask in the offset
+    const unsigned o_st = (MASK && !do_store) ? PP_OOB : o_xy;
     auto store_field = [&]() {
-      if (ST || pair_ok) {
+      if (UNC || pair_ok) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          if constexpr (PP_SOFF != 0) pp_bst2ss<NT>(r_dn, o_xy, c * N4 + po4, dn[c][0], dn[c][1]);
-          else pp_bst2s<NT>(pp_make_rsrc(Dn + c * N + po), o_xy, dn[c][0], dn[c][1]);
+          if constexpr (PP_SOFF != 0) pp_bst2ss<NT>(r_dn, o_st, c * N4 + po4, dn[c][0], dn[c][1]);
+          else pp_bst2s<NT>(pp_make_rsrc(Dn + c * N + po), o_st, dn[c][0], dn[c][1]);
         }
       } else if (x + 1 < d.nx) {   // odd row length: pairs at 4-byte alignment
 #pragma unroll
@@ -705,9 +741,9 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
       }
     };
     auto store_image = [&]() {
-      if (ST || pair_ok) {
-        if constexpr (PP_SOFF != 0) pp_bst2ss<NT>(r_mw, o_xy, po4, mw0, mw1);
-        else pp_bst2s<NT>(pp_make_rsrc(Mw + po), o_xy, mw0, mw1);
+      if (UNC || pair_ok) {
+        if constexpr (PP_SOFF != 0) pp_bst2ss<NT>(r_mw, o_st, po4, mw0, mw1);
+        else pp_bst2s<NT>(pp_make_rsrc(Mw + po), o_st, mw0, mw1);
       } else if (x + 1 < d.nx) {
         pp_gst2(reinterpret_cast<char*>(Mw + po), o_xy, mw0, mw1);
       } else {
@@ -715,18 +751,13 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
         else pp_bst(pp_make_rsrc(Mw + po), o_xy, mw0);
       }
     };
-#ifdef PP_ABL_NOSTORE
-    const bool do_store = emit && out_ok && dn[0][0] == 3.21e-29f && dn[1][1] == 1e-31f && dn[2][0] == 7e-33f && dn[0][1] == 2e-30f && dn[1][0] == 3e-30f && dn[2][1] == 4e-30f;
-#else
-    const bool do_store = ST || (emit && out_ok);
-#endif
-    if (do_store) {
+    if (UNC || do_store) {
       store_field();
 #if !PP_B_DEFER || defined(PP_ABL_NOGATHER)
       store_image();
 #endif
     }
-    if constexpr (ST) __builtin_amdgcn_sched_barrier(0);
+    if constexpr (UNC) __builtin_amdgcn_sched_barrier(0);
     // ---- interval 2: x pass of plane `nxt` (XS: already done above; one barrier hands the buffers over) ----
     PP_TRACE_MARK(trace_on, 1, n, 1);
     if (fresh_next) {
@@ -740,15 +771,25 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
       }
     }
 #if PP_B_DEFER && !defined(PP_ABL_NOGATHER)
-    if (emit) {
+#if PP_B_FINISH_AFTER_BARRIER
+    if constexpr (UNC) __builtin_amdgcn_sched_barrier(0);   // (keep the gathers' wait behind the barrier, where the source has it)
+#endif
+    if (UNC || emit) {
       mw0 = fused2_warp_finish(g0);
       mw1 = fused2_warp_finish(g1);
     }
-    if (do_store) store_image();
+    if (UNC || do_store) store_image();
 #endif
     PP_TRACE_MARK(trace_on, 1, n, 3);
   };
+#if PP_STEADY
   fused2_plane_loop3<R, UNROLL>(step, nsteps, s_lo, s_hi);
+#else
+  (void)s_lo;
+  (void)s_hi;
+  auto step_general = [&](int n, auto phase_tag) { step(n, phase_tag, pp_steady<false>{}); };
+  fused2_plane_loop<R, UNROLL>(step_general, nsteps);
+#endif
 }
 
 // pp_esm_axis with the border rules carried by DATA instead of per-lane flags (the hoisted flag masks cost kernel A ~36
@@ -766,7 +807,8 @@ __device__ __forceinline__ float pp_esm_axis_data(float fm, float fp, float mc, 
 
 // ---- kernel A, generation 2: ESM update + 3-D Gaussian of the update -----------------------------------
 // SUM: the stored volume is D + G_u * update (D read at the thread's own output voxels), what kernel B<SUM> smooths.
-template <int R, int SH, bool UNROLL, bool SUM, bool NT>
+// MASK: as in kernel B -- every memory instruction of a plane step issued on every step, lane masks in the offsets.
+template <int R, int SH, bool UNROLL, bool SUM, bool NT, bool MASK>
 __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(const float* __restrict__ F, const float* __restrict__ Mw,
                                                                          const float* __restrict__ D, float* __restrict__ Us,
                                                                          fused_args a, pp_esm_consts K,
@@ -825,7 +867,8 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
   const int cx = t % G::LX, cy = t / G::LX;
   const unsigned sy = d.nx, sz = (unsigned)d.nx * d.ny;
   const size_t N = (size_t)sz * d.nz;
-  const pp_rsrc r_f = pp_make_rsrc(F), r_mw = pp_make_rsrc(Mw), r_d = pp_make_rsrc(D), r_us = pp_make_rsrc(Us);   // (PP_SOFF)
+  const pp_rsrc r_f = pp_make_rsrc(F), r_mw = pp_make_rsrc(Mw);   // (PP_SOFF)
+  const pp_rsrc r_d = pp_make_rsrc(D), r_us = MASK ? pp_make_rsrc_masked(Us) : pp_make_rsrc(Us);
 
   // Owned smoothing-input voxels.  Image values are fetched at the clamped position, so out-of-volume halo slots
   // replicate the edge update (ZeroFluxNeumann on the smoothing input).
@@ -907,7 +950,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
         min_[k] = pp_blds(r_mw, own_g[k], s2);
         fin_[k] = pp_blds(r_f, own_g[k], s2);
       }
-      if (brd_w >= 0) {
+      if (MASK || brd_w >= 0) {   // (MASK: lanes without a ring element read voxel 0 of the plane)
         bm_n = pp_blds(r_mw, brd_g, s1);
         bf_n = pp_blds(r_f, brd_g, s1);
       }
@@ -918,7 +961,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
         min_[k] = pp_bld(rm2, own_g[k]);
         fin_[k] = pp_bld(rf2, own_g[k]);
       }
-      if (brd_w >= 0) {
+      if (MASK || brd_w >= 0) {
         bm_n = pp_bld(pp_make_rsrc(Mw + p1), brd_g);
         bf_n = pp_bld(pp_make_rsrc(F + p1), brd_g);
       }
@@ -972,7 +1015,16 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
   float2 dsum[SUM ? 3 : 1];
   const unsigned o_xy1 = (x + 1 < d.nx) ? o_xy + 4u : o_xy;
   auto load_dsum = [&](int zo, auto always_tag) {
-    if (decltype(always_tag)::value || (zo >= z0 && zo <= zo_last && out_ok)) {
+    if constexpr (MASK) {
+      // One 8-byte load per component (rows are even, so the pair is aligned) on every step: a plane of this chunk, lanes
+      // outside the volume read voxel 0 of it.  (A global load through the array's base: hipcc 7.2 lowers
+      // __builtin_amdgcn_raw_buffer_load_b64 to buffer_load_dword and broadcasts the first element -- tools/probes/unaligned.hip
+      // met the same thing in round 2 and took it for an alignment rule.)
+      const unsigned po = (unsigned)pp_clampi(zo, z0, zo_last) * sz;
+      const unsigned o_ld = out_ok ? o_xy : 0u;
+#pragma unroll
+      for (int c = 0; c < (SUM ? 3 : 1); ++c) dsum[c] = pp_gld2(reinterpret_cast<const char*>(D), o_ld + ((unsigned)c * (unsigned)N + po) * 4u);
+    } else if (decltype(always_tag)::value || (zo >= z0 && zo <= zo_last && out_ok)) {
       const size_t po = (size_t)zo * sz;
 #pragma unroll
       for (int c = 0; c < (SUM ? 3 : 1); ++c) {   // two 4-byte buffer loads: no alignment case, no branch (x + 1 == nx re-reads x)
@@ -1050,10 +1102,26 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     if (fresh_next) esm(nxt, steady_tag);
     float us[3][2];
     fused2_ring<R, P>(rg, v, a.wz, us);
-    if (emit) {
+    constexpr bool UNC = MASK || ST;   // memory instructions issued unconditionally
+    if constexpr (UNC) {
+      // all three adds before the first store: the adds wait for the D loads of the previous step, and a wait placed between
+      // two stores also waits for the first store's acknowledgement (vmcnt retires in issue order).  One store form (even
+      // rows); the lane mask -- inside the volume, an output plane of this chunk -- travels in the offset.
+      if constexpr (SUM) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          us[c][0] = dsum[c].x + us[c][0];
+          us[c][1] = dsum[c].y + us[c][1];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink each add to its store again)
+      const unsigned po4 = (unsigned)(ST ? zo : pp_clampi(zo, z0, zo_last)) * sz * 4u, N4 = (unsigned)N * 4u;
+      const unsigned o_st = (ST || emit) ? o_xy : PP_OOB;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pp_bst2ss<NT>(r_us, o_st, (unsigned)c * N4 + po4, us[c][0], us[c][1]);
+      __builtin_amdgcn_sched_barrier(0);   // (the next step's loads go behind the stores)
+    } else if (emit) {
       const size_t po = (size_t)zo * sz;
-      // (all three adds before the first store: the adds wait for the D loads of the previous step, and a wait placed
-      // between two stores also waits for the first store's acknowledgement -- vmcnt counts in issue order)
       if constexpr (SUM) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -1088,14 +1156,21 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     // pending: the image planes are consumed by the next ESM pass, D (SUM) by the next stores.
     {
       const int nxt2 = ST ? zi + 2 : pp_clampi(zi + 2, 0, d.nz - 1);
-      if (ST || ((n + 2 < nsteps) && (nxt2 != nxt))) prefetch(nxt2);
+      if (UNC || ((n + 2 < nsteps) && (nxt2 != nxt))) prefetch(nxt2);   // (UNC: a step that would not load re-reads the planes it holds)
     }
     if constexpr (SUM) load_dsum(zo + 1, steady_tag);
     PP_TRACE_MARK(trace_on, 0, n, 3);
     if (fresh_cur || fresh_next) __syncthreads();
     PP_TRACE_MARK(trace_on, 0, n, 4);
   };
+#if PP_A_STEADY
   fused2_plane_loop3<R, UNROLL>(step, nsteps, s_lo, s_hi);
+#else
+  (void)s_lo;
+  (void)s_hi;
+  auto step_general = [&](int n, auto phase_tag) { step(n, phase_tag, pp_steady<false>{}); };
+  fused2_plane_loop<R, UNROLL>(step_general, nsteps);
+#endif
   double r_ssd = (double)a_ssd, r_ssc = (double)a_ssc, r_n = (double)a_n;
   pp_block_sum3_shfl<NTH>(r_ssd, r_ssc, r_n, reinterpret_cast<double*>(s_u));
   if (t == 0) {

@@ -160,25 +160,29 @@ static inline void __builtin_amdgcn_sched_barrier(int) {}                  // (a
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // (only ever applied to wave-uniform values)
 static inline unsigned __umul24(unsigned a, unsigned b) { return (unsigned)((unsigned long long)(a & 0xffffffu) * (b & 0xffffffu)); }
 
-// buffer resources: base pointer + 32-bit byte offsets (the stand-in ignores the range / format words)
-struct __amdgpu_buffer_rsrc_t { char* base; };
-static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int, int) { return __amdgpu_buffer_rsrc_t{static_cast<char*>(p)}; }
+// buffer resources: base pointer + 32-bit byte offsets + the range word (raw buffers: a lane whose per-lane offset reaches
+// num_records is out of range -- its load returns 0, its store is dropped; the scalar offset takes no part in the check, the
+// reading of the ISA the kernels are written to be independent of: they keep offset + scalar offset below 2^32 and arrays
+// below 2^31 bytes).  The format word is ignored.
+struct __amdgpu_buffer_rsrc_t { char* base; unsigned num_records; };
+static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int n, int) { return __amdgpu_buffer_rsrc_t{static_cast<char*>(p), (unsigned)n}; }
+static inline bool hipemu_buf_in_range(const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned bytes) { return (unsigned long long)voff + bytes <= r.num_records; }
 static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int) {
-  unsigned v;
-  memcpy(&v, r.base + (size_t)voff + soff, 4);
+  unsigned v = 0;
+  if (hipemu_buf_in_range(r, voff, 4)) memcpy(&v, r.base + (size_t)voff + soff, 4);
   return v;
 }
 static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int) {
-  memcpy(r.base + (size_t)voff + soff, &v, 4);
+  if (hipemu_buf_in_range(r, voff, 4)) memcpy(r.base + (size_t)voff + soff, &v, 4);
 }
 typedef unsigned hipemu_u2 __attribute__((vector_size(8)));
 static inline hipemu_u2 __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int) {
-  hipemu_u2 v;
-  memcpy(&v, r.base + (size_t)voff + soff, 8);
+  hipemu_u2 v = {0u, 0u};
+  if (hipemu_buf_in_range(r, voff, 8)) memcpy(&v, r.base + (size_t)voff + soff, 8);
   return v;
 }
 static inline void __builtin_amdgcn_raw_buffer_store_b64(hipemu_u2 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int) {
-  memcpy(r.base + (size_t)voff + soff, &v, 8);
+  if (hipemu_buf_in_range(r, voff, 8)) memcpy(r.base + (size_t)voff + soff, &v, 8);
 }
 
 // Wavefront shuffle (64 lanes).  Every live lane of the WAVEFRONT must reach the call: the value is exchanged through a

@@ -402,6 +402,40 @@ def test_fused_demons_store_policy_does_not_change_the_field(backend, monkeypatc
     assert out["0"][1:] == out["1"][1:]
 
 
+EVEN_ROWS = [GRIDS[1], HIRES, ((13, 22, 46), (0.9, 1.1, 2.5), (320.0, -52.0, 60.0))]   # nx % 4 == 0 and nx % 4 == 2
+
+
+@pytest.mark.parametrize("tile", ["0", "1"])
+@pytest.mark.parametrize("grid", EVEN_ROWS)
+def test_fused_demons_masked_kernels_equal_the_branchy_ones(backend, grid, tile, monkeypatch):
+    """Round 4: on grids with even rows generation 2 runs its MASK instances -- every memory instruction of a plane step
+    issued on every step, loads from clamped addresses, the lane mask of a store carried by an out-of-range buffer offset
+    -- so that the compiler's s_waitcnt pass sees straight-line code.  Same arithmetic: the field, the warped image it
+    feeds the next iteration and the statistics equal those of the branchy instances (PP_FUSED_MASK=0) bit for bit, on
+    grids whose tiles overhang the volume in x and y, with z-chunks shorter than the halo included."""
+    shape, spacing, origin = grid
+    assert shape[2] % 2 == 0, "the masked instances need even rows"
+    fix = phantom(shape, seed=40)
+    dv = random_dvf(shape, spacing, seed=41, max_mm=2.5)
+    mov = O.warp_image(O.Vol(fix, spacing, origin), dv.astype(np.float64), edge_value=-1000.0).arr.astype(np.float32)
+    p = _demons_params(backend.ctx, 3, spacing, _lib.DEMONS_FUSED, max_rms=0.0)
+    monkeypatch.setenv("PP_FUSED_TILE", tile)
+    for zchunk in (None, "2"):
+        if zchunk is None:
+            monkeypatch.delenv("PP_FUSED_ZCHUNK", raising=False)
+        else:
+            monkeypatch.setenv("PP_FUSED_ZCHUNK", zchunk)
+        out = {}
+        for mask in ("0", "1"):
+            monkeypatch.setenv("PP_FUSED_MASK", mask)
+            f = backend.empty((3,) + shape)
+            st = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, f)
+            out[mask] = (backend.host(f).copy(), st.metric, st.rms_change, st.n_pixels, st.elapsed_iterations)
+        np.testing.assert_array_equal(out["0"][0], out["1"][0])
+        assert out["0"][1:] == out["1"][1:]
+        assert np.abs(out["1"][0]).max() > 0.1
+
+
 @pytest.mark.parametrize("zchunk", [1, 2, 3, 5, 100])
 def test_fused_demons_is_independent_of_the_z_chunking(backend, zchunk, monkeypatch):
     """The fused schedule splits z into chunks (halo planes recomputed at the seams); any chunk length, shorter

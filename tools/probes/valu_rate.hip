@@ -22,6 +22,7 @@ __global__ void __launch_bounds__(512) k_rate(float* out, float a, float b) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) p[i] = f2{v[2 * i], v[2 * i + 1]};
   const f2 pa = f2{a, a}, pb = f2{b, b};
+  if constexpr (KIND == 15) asm volatile("s_mov_b64 vcc, 0x55555555" ::: "vcc");
   for (int it = 0; it < ITER; ++it) {
     if constexpr (KIND == 0) {   // v_fma_f32
 #pragma unroll
@@ -73,6 +74,27 @@ __global__ void __launch_bounds__(512) k_rate(float* out, float a, float b) {
     } else if constexpr (KIND == 13) {  // integer v_add_u32
 #pragma unroll
       for (int i = 0; i < 16; ++i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+    } else if constexpr (KIND == 15) {  // v_cndmask_b32 reading a vcc that was written ONCE before the loop (round 4: KIND 2's
+                                        // clobber made the compiler put an s_nop behind every select -- it timed the pair)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(a));
+    } else if constexpr (KIND == 16) {  // v_fma_f32 + s_nop 0: the price of a hazard no-op behind a vector instruction
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_nop 0" : "+v"(v[i]) : "v"(a), "v"(b));
+    } else if constexpr (KIND == 17) {  // the compiler's own select: v_cmp -> vcc, s_nop 1, v_cndmask ..., vcc (as in the shipped ISA)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        asm volatile("v_cmp_neq_f32 vcc, %0, %1\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(a) : "vcc");
+    } else if constexpr (KIND == 18) {  // the same pair without the no-op (is the hazard real? compare the RESULT, not only the time)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        asm volatile("v_cmp_neq_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(a) : "vcc");
+    } else if constexpr (KIND == 19) {  // arithmetic blend instead of a select: v_fma with a 0/1 factor
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(v[i]) : "v"(a), "v"(b));
+    } else if constexpr (KIND == 20) {  // v_fma_f32 + s_nop 1
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_nop 1" : "+v"(v[i]) : "v"(a), "v"(b));
     } else if constexpr (KIND == 14) {  // v_mul_u32_u24
 #pragma unroll
       for (int i = 0; i < 16; ++i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(v[i]) : "v"(a));
@@ -121,6 +143,11 @@ int main() {
   run<10>("v_pk_add_f32", 16, cus, ghz, out);
   run<2>("v_cndmask_b32 (vcc)", 16, cus, ghz, out);
   run<6>("v_cmp + v_cndmask (sgpr)", 16, cus, ghz, out);
+  run<15>("v_cndmask_b32 (static vcc)", 16, cus, ghz, out);
+  run<17>("v_cmp vcc + s_nop 1 + cndmask", 16, cus, ghz, out);
+  run<18>("v_cmp vcc + cndmask (no nop)", 16, cus, ghz, out);
+  run<16>("v_fma_f32 + s_nop 0", 16, cus, ghz, out);
+  run<20>("v_fma_f32 + s_nop 1", 16, cus, ghz, out);
   run<3>("v_mov_b32_dpp wave_shr:1", 16, cus, ghz, out);
   run<7>("v_rcp_f32", 16, cus, ghz, out);
   run<11>("v_max_f32", 16, cus, ghz, out);
