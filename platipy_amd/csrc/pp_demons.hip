@@ -85,10 +85,12 @@ struct pp_esm_out {
   int counted;
 };
 
+// MAPPED: the caller knows that mc is not the sentinel (the voted path of the generation-2 kernel A).
+template <bool MAPPED = false>
 __device__ __forceinline__ pp_esm_out pp_esm_voxel(const pp_esm_consts& K, float fc, float mc, float gx, float gy, float gz) {
   // Straight-line: every guard of ComputeUpdate becomes a select (a zero denominator only feeds a lane whose
   // result is discarded).  mc == sentinel: no update and the voxel is not counted.
-  const bool mapped = (mc != FLT_MAX);
+  const bool mapped = MAPPED || (mc != FLT_MAX);
   const float speed = fc - mc;
   const float g2 = gx * gx + gy * gy + gz * gz;
   const float denom = g2 + speed * speed * K.inv_norm;

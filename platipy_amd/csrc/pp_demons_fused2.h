@@ -495,6 +495,12 @@ struct pp_steady_unroll<W, W> {
 #ifndef PP_STEADY
 #define PP_STEADY 0
 #endif
+#ifndef PP_B_VOTE
+#define PP_B_VOTE 1
+#endif
+#ifndef PP_A_VOTE
+#define PP_A_VOTE 1
+#endif
 #ifndef PP_B_FINISH_AFTER_BARRIER
 #define PP_B_FINISH_AFTER_BARRIER 1
 #endif
@@ -692,12 +698,23 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
     // behind the strip loads, the field stores and the barrier instead of stalling the wave at once.  (UNC: also on steps
     // that emit nothing -- the displacement is clamped, so the addresses are valid, and the result is never stored.)
     pp_warp_pending g0, g1;
+    bool wfast = false;   // (wave-uniform: the vote of fused2_warp_issue_pair)
     if (UNC || emit) {
+#if PP_B_VOTE
+      wfast = fused2_warp_issue_pair(rm, wd, x, y, zo, dn[0][0] * sc.ix, dn[1][0] * sc.iy, dn[2][0] * sc.iz, dn[0][1] * sc.ix,
+                                     dn[1][1] * sc.iy, dn[2][1] * sc.iz, ST || out_ok, ST || (out_ok && (x + 1 < d.nx)), g0, g1);
+#else
       fused2_warp_issue(rm, wd, x, dn[0][0] * sc.ix, y, dn[1][0] * sc.iy, zo, dn[2][0] * sc.iz, ST || out_ok, g0);
       fused2_warp_issue(rm, wd, x + 1, dn[0][1] * sc.ix, y, dn[1][1] * sc.iy, zo, dn[2][1] * sc.iz, ST || (out_ok && (x + 1 < d.nx)), g1);
+#endif
 #if !PP_B_DEFER
-      mw0 = fused2_warp_finish(g0);
-      mw1 = fused2_warp_finish(g1);
+      if (wfast) {
+        mw0 = fused2_warp_finish_interior(g0);
+        mw1 = fused2_warp_finish_interior(g1);
+      } else {
+        mw0 = fused2_warp_finish(g0);
+        mw1 = fused2_warp_finish(g1);
+      }
 #endif
     }
 #endif
@@ -775,8 +792,13 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
     if constexpr (UNC) __builtin_amdgcn_sched_barrier(0);   // (keep the gathers' wait behind the barrier, where the source has it)
 #endif
     if (UNC || emit) {
-      mw0 = fused2_warp_finish(g0);
-      mw1 = fused2_warp_finish(g1);
+      if (wfast) {
+        mw0 = fused2_warp_finish_interior(g0);
+        mw1 = fused2_warp_finish_interior(g1);
+      } else {
+        mw0 = fused2_warp_finish(g0);
+        mw1 = fused2_warp_finish(g1);
+      }
     }
     if (UNC || do_store) store_image();
 #endif
@@ -802,6 +824,15 @@ __device__ __forceinline__ float pp_esm_axis_data(float fm, float fp, float mc, 
   const float hi_v = up ? mp : mc, lo_v = um ? mm : mc;
   const float wg = (hi_v - lo_v) * ((up && um) ? h : inv_sp);
   const float fg = (fp - fm) * hf;
+  return fg + wg;
+}
+
+// One axis of the gradient where both neighbours exist and neither warped value is the sentinel: pp_esm_axis /
+// pp_esm_axis_data with `up`, `um` true and the first / last-index factor h -- the same two statements, so the same roundings.
+__device__ __forceinline__ float pp_esm_axis_plain(float fm, float fp, float mm, float mp, float inv_sp) {
+  const float h = 0.5f * inv_sp;
+  const float wg = (mp - mm) * h;
+  const float fg = (fp - fm) * h;
   return fg + wg;
 }
 
@@ -971,6 +1002,51 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     constexpr bool ZIN = decltype(interior_tag)::value;   // 0 < zc < nz - 1 known at compile time (steady steps)
     const bool count_plane = (zc >= z0 && zc <= zo_last);
     const bool zlo_b = ZIN ? false : (zc == 0), zhi_b = ZIN ? false : (zc == d.nz - 1);
+#if PP_A_VOTE
+    // Round 4: one wavefront vote per round.  Where no lane of the wavefront sits on a first / last index and none of its seven
+    // warped-image values is the sentinel -- everywhere but next to the volume's border and to voxels the warp mapped outside
+    // the moving image -- ITK's case analysis selects the central difference on every axis, and the three gradients are five
+    // vector instructions each instead of ~13 (pp_esm_axis_plain: the same expressions with the selects resolved).  Every lane
+    // of the wavefront reaches both votes: lanes without a voxel (the last round only) compute on slot 0 and store nothing.
+    const bool z_inner = !(zlo_b || zhi_b);
+#pragma unroll
+    for (int k = 0; k < G::KU; ++k) {
+      const unsigned fl = uflag[k] >> 16;
+      const bool full_round = (k + 1) * NTH <= G::NU;
+      const bool valid = full_round || (fl & F_VALID);
+      if (full_round || __any(valid)) {
+        const int l = (int)(slots[k] & 0xffffu);
+        const float2 xm = s_mf[l - 1], xp = s_mf[l + 1], ym = s_mf[l - G::MWP], yp = s_mf[l + G::MWP];
+        const unsigned flb = pp_opaque(fl);   // (predicates formed here: hoisted, they would hold six scalar registers per voxel)
+        const float mmax = fmaxf(fmaxf(fmaxf(xm.x, xp.x), fmaxf(ym.x, yp.x)), fmaxf(fmaxf(mprev[k], mnext[k]), mcur[k]));
+        const bool plain = !valid || (((flb & (F_XLO | F_XHI | F_YLO | F_YHI)) == 0u) & (mmax < FLT_MAX));
+        pp_esm_out o;
+        if (z_inner && !__any(!plain)) {
+          const float gx = pp_esm_axis_plain(xm.y, xp.y, xm.x, xp.x, K.ix);
+          const float gy = pp_esm_axis_plain(ym.y, yp.y, ym.x, yp.x, K.iy);
+          const float gz = pp_esm_axis_plain(fprev[k], fnext[k], mprev[k], mnext[k], K.iz);
+          o = pp_esm_voxel<true>(K, fcur[k], mcur[k], gx, gy, gz);
+        } else {
+          const float hfx = (flb & (F_XLO | F_XHI)) ? 0.0f : 0.5f * K.ix, hfy = (flb & (F_YLO | F_YHI)) ? 0.0f : 0.5f * K.iy;
+          const float gx = pp_esm_axis_data(xm.y, xp.y, mcur[k], xm.x, xp.x, hfx, K.ix);
+          const float gy = pp_esm_axis_data(ym.y, yp.y, mcur[k], ym.x, yp.x, hfy, K.iy);
+          const float gz = pp_esm_axis(fprev[k], fnext[k], mcur[k], mprev[k], mnext[k], zlo_b, zhi_b, K.iz);
+          o = pp_esm_voxel(K, fcur[k], mcur[k], gx, gy, gz);
+        }
+        if (valid) {
+          const int u = (int)(uflag[k] & 0xffffu);
+          s_u[u] = o.ux;
+          s_u[G::UH * G::UWP + u] = o.uy;
+          s_u[2 * G::UH * G::UWP + u] = o.uz;
+          if (count_plane && (fl & F_CNT)) {
+            a_ssd += o.sq_speed;
+            a_ssc += o.sq_update;
+            a_n += (float)o.counted;
+          }
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int k = 0; k < G::KU; ++k) {
       const unsigned fl = uflag[k] >> 16;
@@ -994,6 +1070,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
         }
       }
     }
+#endif
 #pragma unroll
     for (int k = 0; k < G::KU; ++k) {
       mprev[k] = mcur[k]; mcur[k] = mnext[k]; mnext[k] = min_[k];

@@ -85,6 +85,58 @@ __device__ __forceinline__ void fused2_warp_issue(const char* rm, const pp_warp_
   fused2_warp_setup(wd, xi, dvx, yi, dvy, zi, dvz, lane_ok, a);
   fused2_warp_load(rm, a, g);
 }
+// Both samples of a thread behind ONE wavefront vote (round 4).  When every lane's two base cells lie inside the volume with an
+// upper neighbour on every axis -- all but the wavefronts that touch the volume's border -- the displacement clamp, the index
+// clamps, the zero weight below index 0, the repeated corner of a last index and the buffer test are identities / true, and
+// the address half of a sample is 3 floors, 3 conversions, 3 subtractions and 9 integer operations instead of ~60 vector
+// instructions (the warp's address / weight arithmetic was ~190 of kernel B's ~300 vector instructions per thread and plane).
+// Same values on that path: the clamps do not bind, the weights are the fractions, the four offsets are the slow path's with
+// dy = row pitch, dz = plane pitch.  A NaN displacement fails the vote (s != s) and is sampled -- as outside -- by the slow path.
+// Returns the vote; `fused2_warp_finish_pair` must be given it back.  Every lane of the wavefront must reach the call.
+__device__ __forceinline__ bool fused2_warp_issue_pair(const char* rm, const pp_warp_dims& wd, int xi, int yi, int zi, float ax, float ay,
+                                                       float az, float bx, float by, float bz, bool ok_a, bool ok_b, pp_warp_pending& ga,
+                                                       pp_warp_pending& gb) {
+  const float fax = floorf(ax), fay = floorf(ay), faz = floorf(az), fbx = floorf(bx), fby = floorf(by), fbz = floorf(bz);
+  const int iax = xi + (int)fax, iay = yi + (int)fay, iaz = zi + (int)faz;
+  const int ibx = xi + 1 + (int)fbx, iby = yi + (int)fby, ibz = zi + (int)fbz;
+  const float s = ((ax + ay) + az) + ((bx + by) + bz);
+  const unsigned lx = (unsigned)(wd.nx - 1), ly = (unsigned)(wd.ny - 1), lz = (unsigned)(wd.nz - 1);
+  const bool interior = ok_a & ok_b & ((unsigned)iax < lx) & ((unsigned)iay < ly) & ((unsigned)iaz < lz) & ((unsigned)ibx < lx) &
+                        ((unsigned)iby < ly) & ((unsigned)ibz < lz) & (s == s);
+  pp_warp_addr a, b;
+  const bool fast = !__any(!interior);
+  if (fast) {
+    a.wx = ax - fax; a.wy = ay - fay; a.wz = az - faz;
+    b.wx = bx - fbx; b.wy = by - fby; b.wz = bz - fbz;
+    const unsigned ra = __umul24(__umul24((unsigned)iaz, (unsigned)wd.ny) + (unsigned)iay, wd.nx4), ca = (unsigned)iax * 4u;
+    const unsigned rb = __umul24(__umul24((unsigned)ibz, (unsigned)wd.ny) + (unsigned)iby, wd.nx4), cb = (unsigned)ibx * 4u;
+    a.o00 = ra + ca; a.o10 = ra + wd.nx4 + ca; a.o01 = ra + wd.sz4 + ca; a.o11 = ra + wd.sz4 + wd.nx4 + ca;
+    b.o00 = rb + cb; b.o10 = rb + wd.nx4 + cb; b.o01 = rb + wd.sz4 + cb; b.o11 = rb + wd.sz4 + wd.nx4 + cb;
+    a.flags = 1u;
+    b.flags = 1u;
+  } else {
+    fused2_warp_setup(wd, xi, ax, yi, ay, zi, az, ok_a, a);
+    fused2_warp_setup(wd, xi + 1, bx, yi, by, zi, bz, ok_b, b);
+  }
+  fused2_warp_load(rm, a, ga);   // (the eight loads are common to both paths: no memory instruction inside the branch)
+  fused2_warp_load(rm, b, gb);
+  return fast;
+}
+// fused2_warp_finish on the voted path: every sample is inside and no lane sits on a last x index -- the same lerps without
+// the five selects.
+__device__ __forceinline__ float fused2_warp_finish_interior(const pp_warp_pending& g) {
+  const float a000 = g.p00.x, a100 = g.p00.y;
+  const float a010 = g.p10.x, a110 = g.p10.y;
+  const float a001 = g.p01.x, a101 = g.p01.y;
+  const float a011 = g.p11.x, a111 = g.p11.y;
+  const float v00 = a000 + (a100 - a000) * g.wx;
+  const float v10 = a010 + (a110 - a010) * g.wx;
+  const float v01 = a001 + (a101 - a001) * g.wx;
+  const float v11 = a011 + (a111 - a011) * g.wx;
+  const float v0 = v00 + (v10 - v00) * g.wy;
+  const float v1 = v01 + (v11 - v01) * g.wy;
+  return v0 + (v1 - v0) * g.wz;
+}
 __device__ __forceinline__ float fused2_warp_finish(const pp_warp_pending& g) {
   const bool xlast = (g.flags & 2u) != 0;
   const float a000 = xlast ? g.p00.y : g.p00.x, a100 = g.p00.y;

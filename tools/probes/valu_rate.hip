@@ -23,6 +23,8 @@ __global__ void __launch_bounds__(512) k_rate(float* out, float a, float b) {
   for (int i = 0; i < 8; ++i) p[i] = f2{v[2 * i], v[2 * i + 1]};
   const f2 pa = f2{a, a}, pb = f2{b, b};
   if constexpr (KIND == 15) asm volatile("s_mov_b64 vcc, 0x55555555" ::: "vcc");
+  if constexpr (KIND == 21 || KIND == 25) asm volatile("s_mov_b64 s[20:21], 0x33333333" ::: "s20", "s21");
+  if constexpr (KIND == 22) asm volatile("v_cmp_neq_f32 s[20:21], %0, %1\n\ts_nop 4" : : "v"(v[0]), "v"(v[1]) : "s20", "s21");
   for (int it = 0; it < ITER; ++it) {
     if constexpr (KIND == 0) {   // v_fma_f32
 #pragma unroll
@@ -95,6 +97,34 @@ __global__ void __launch_bounds__(512) k_rate(float* out, float a, float b) {
     } else if constexpr (KIND == 20) {  // v_fma_f32 + s_nop 1
 #pragma unroll
       for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_nop 1" : "+v"(v[i]) : "v"(a), "v"(b));
+    } else if constexpr (KIND == 21) {  // mask in an SGPR pair written by the SCALAR unit just before each select
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        asm volatile("s_not_b64 s[20:21], s[20:21]\n\ts_nop 3\n\tv_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(v[i]) : "v"(a) : "s20", "s21");
+    } else if constexpr (KIND == 22) {  // mask written by a VALU compare ONCE before the loop (static, but vector-written)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(v[i]) : "v"(a));
+    } else if constexpr (KIND == 23) {  // compare -> 8 unrelated vector instructions -> select on that compare's mask
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        asm volatile("v_cmp_neq_f32 s[20:21], %0, %1" : : "v"(v[8 * i]), "v"(a) : "s20", "s21");
+#pragma unroll
+        for (int j = 1; j < 8; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[8 * i + j]) : "v"(a), "v"(b));
+        asm volatile("v_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(v[8 * i]) : "v"(a));
+      }
+    } else if constexpr (KIND == 24) {  // one compare feeding eight selects (the mask is read eight times)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        asm volatile("v_cmp_neq_f32 s[20:21], %0, %1" : : "v"(v[8 * i]), "v"(a) : "s20", "s21");
+#pragma unroll
+        for (int j = 0; j < 7; ++j) asm volatile("v_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(v[8 * i + j + 1]) : "v"(a));
+      }
+    } else if constexpr (KIND == 25) {  // v_fma_f32 with a scalar-register operand (are static SGPR reads slow in general?)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, s20, %1" : "+v"(v[i]) : "v"(b));
+    } else if constexpr (KIND == 26) {  // v_cndmask with exec as the mask
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_cndmask_b32 %0, %0, %1, exec" : "+v"(v[i]) : "v"(a));
     } else if constexpr (KIND == 14) {  // v_mul_u32_u24
 #pragma unroll
       for (int i = 0; i < 16; ++i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(v[i]) : "v"(a));
@@ -141,11 +171,17 @@ int main() {
   run<4>("v_mul_f32", 16, cus, ghz, out);
   run<5>("v_pk_mul_f32", 16, cus, ghz, out);
   run<10>("v_pk_add_f32", 16, cus, ghz, out);
-  run<2>("v_cndmask_b32 (vcc)", 16, cus, ghz, out);
+  run<2>("v_cndmask_b32 (vcc, undefined)", 16, cus, ghz, out);
   run<6>("v_cmp + v_cndmask (sgpr)", 16, cus, ghz, out);
   run<15>("v_cndmask_b32 (static vcc)", 16, cus, ghz, out);
   run<17>("v_cmp vcc + s_nop 1 + cndmask", 16, cus, ghz, out);
   run<18>("v_cmp vcc + cndmask (no nop)", 16, cus, ghz, out);
+  run<21>("s_not mask + cndmask (SALU-fresh)", 16, cus, ghz, out);
+  run<22>("cndmask, mask v_cmp'd once", 16, cus, ghz, out);
+  run<23>("v_cmp, 7 fma, cndmask", 16, cus, ghz, out);
+  run<24>("v_cmp + 7 cndmask on it", 16, cus, ghz, out);
+  run<26>("v_cndmask_b32 (exec)", 16, cus, ghz, out);
+  run<25>("v_fma_f32 with an SGPR operand", 16, cus, ghz, out);
   run<16>("v_fma_f32 + s_nop 0", 16, cus, ghz, out);
   run<20>("v_fma_f32 + s_nop 1", 16, cus, ghz, out);
   run<3>("v_mov_b32_dpp wave_shr:1", 16, cus, ghz, out);
