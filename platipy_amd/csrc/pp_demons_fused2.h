@@ -495,6 +495,9 @@ struct pp_steady_unroll<W, W> {
 #ifndef PP_STEADY
 #define PP_STEADY 0
 #endif
+#ifndef PP_B_XLATE
+#define PP_B_XLATE 1
+#endif
 #ifndef PP_B_VOTE
 #define PP_B_VOTE 1
 #endif
@@ -674,14 +677,21 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
 #pragma unroll
       for (int c = 0; c < 3; ++c) fused2_ypass_strips<R, G>(XS ? smem + ybuf * G::SZ_X : s_x, c, yb, a.wy, v[c]);
     }
-    if constexpr (XS) {
-      if (fresh_next) {   // x pass of plane `nxt` in registers, into the other buffer
-        const float4 s3[3] = {ul[0][0], ul[1][0], ul[2][0]};
-        fused2_xpass_shfl<R, G>(s3, st[0].jm, xs_out, xs_off, smem + (ybuf ^ 1) * G::SZ_X, a.wx);
+    // Round 4 (PP_B_XLATE): the x pass of plane `nxt` -- the consumer of the strips -- runs at the END of the interval, and the
+    // next strips are requested right behind it: a strip load then has a whole plane step to arrive (it used to be issued
+    // two thirds into a step and consumed at the top of the next one, ~1.4 us later: less than the loaded HBM latency).
+    auto xpass_next = [&]() {
+      if constexpr (XS) {
+        if (fresh_next) {   // x pass of plane `nxt` in registers, into the other buffer
+          const float4 s3[3] = {ul[0][0], ul[1][0], ul[2][0]};
+          fused2_xpass_shfl<R, G>(s3, st[0].jm, xs_out, xs_off, smem + (ybuf ^ 1) * G::SZ_X, a.wx);
+        }
+      } else {
+        if (fresh_next) publish();
       }
-    } else {
-      if (fresh_next) publish();
-    }
+    };
+    constexpr bool XLATE = XS && (PP_B_XLATE != 0);
+    if constexpr (!XLATE) xpass_next();
     float dn[3][2];
     fused2_ring<R, P>(rg, v, a.wz, dn);
     const int zo = zi - R;
@@ -720,15 +730,18 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
 #endif
     // the plane after `nxt` goes in flight behind the gathers.  UNC pins the issue order gathers -> strip loads -> field
     // stores: vmcnt retires in issue order, so the wait for the gathers must not have the younger HBM loads ahead of it.
-    if constexpr (UNC) {
-      __builtin_amdgcn_sched_barrier(0);
-      // (steps that would not load re-read the plane the strips already hold: min(nxt + 1, zhi))
-      const int zl = ST ? nxt + 1 : (nxt + 1 < zhi ? nxt + 1 : zhi);
-      load_plane(zl, pp_steady<(G::NSL == 1)>{});
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      if (fresh_next && nxt < zhi) load_plane(nxt + 1, pp_steady<false>{});
-    }
+    auto load_next = [&]() {
+      if constexpr (UNC) {
+        __builtin_amdgcn_sched_barrier(0);
+        // (steps that would not load re-read the plane the strips already hold: min(nxt + 1, zhi))
+        const int zl = ST ? nxt + 1 : (nxt + 1 < zhi ? nxt + 1 : zhi);
+        load_plane(zl, pp_steady<(G::NSL == 1)>{});
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        if (fresh_next && nxt < zhi) load_plane(nxt + 1, pp_steady<false>{});
+      }
+    };
+    if constexpr (!XLATE) load_next();
     const int zoc = (UNC && !ST) ? pp_clampi(zo, z0, zo_last) : zo;   // (a plane of this chunk also when nothing is stored)
     const size_t po = (size_t)zoc * sz;
     const unsigned po4 = (unsigned)zoc * sz * 4u, N4 = (unsigned)N * 4u;   // (3 N * 4 < 2^32: checked on the host)
@@ -773,6 +786,11 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
 #if !PP_B_DEFER || defined(PP_ABL_NOGATHER)
       store_image();
 #endif
+    }
+    if constexpr (XLATE) {
+      if constexpr (UNC) __builtin_amdgcn_sched_barrier(0);
+      xpass_next();
+      load_next();
     }
     if constexpr (UNC) __builtin_amdgcn_sched_barrier(0);
     // ---- interval 2: x pass of plane `nxt` (XS: already done above; one barrier hands the buffers over) ----
