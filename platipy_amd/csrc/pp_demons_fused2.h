@@ -495,6 +495,9 @@ struct pp_steady_unroll<W, W> {
 #ifndef PP_STEADY
 #define PP_STEADY 0
 #endif
+#ifndef PP_A_SPLIT_LDS
+#define PP_A_SPLIT_LDS 1
+#endif
 #ifndef PP_B_XLATE
 #define PP_B_XLATE 1
 #endif
@@ -867,10 +870,23 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
   constexpr int NTH = G::NTH, TX = G::TX, TY = G::TY, W = 2 * R + 1;
   constexpr int NXI = (3 * G::XI + NTH - 1) / NTH;
   constexpr int SZ_IMG2 = (2 * G::MH * G::MWP + 3) / 4 * 4;   // packed (moving, fixed) tile, floats
+#if PP_A_SPLIT_LDS
+  // three objects instead of one carved array: the compiler may then move the image-tile reads of one ESM round above the
+  // update stores of the previous one (as slices of one array it must keep them in order, and each wave pays the LDS round
+  // trip once per round)
+  __shared__ __attribute__((aligned(16))) float2 s_mf_[SZ_IMG2 / 2];
+  __shared__ __attribute__((aligned(16))) float s_u_[G::SZ_U];
+  __shared__ __attribute__((aligned(16))) float s_x_[G::SZ_X];
+  float2* const s_mf = s_mf_;
+  float* const s_u = s_u_;
+  float* const s_x = s_x_;
+  float* const smem = s_u_;   // (the reduction scratch of the prologue: 3 * 8 doubles)
+#else
   __shared__ __attribute__((aligned(16))) float smem[SZ_IMG2 + G::SZ_U + G::SZ_X];
   float2* const s_mf = reinterpret_cast<float2*>(smem);
   float* const s_u = smem + SZ_IMG2;
   float* const s_x = smem + SZ_IMG2 + G::SZ_U;
+#endif
   if (st->halt) return;   // (written by an earlier launch)
   // End of the PREVIOUS iteration, folded into this launch instead of a one-block kernel of its own (k_demons_finalize:
   // 5 us plus a launch gap per iteration, a fifth of an iteration on the coarse pyramid levels): every block adds the
@@ -991,6 +1007,18 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     if (brd_w >= 0) s_mf[brd_w] = make_float2(fmaxf(bm, brd_oov), bf);
   };
   auto prefetch = [&](int zc) {   // own voxels of plane zc + 2, border ring of plane zc + 1
+#ifdef PP_ABL_A_NOLOAD
+    {   // (measurement builds: no image loads)
+#pragma unroll
+      for (int k = 0; k < G::KU; ++k) {
+        min_[k] = (float)own_g[k] * 1e-3f + (float)zc;
+        fin_[k] = (float)own_g[k] * 2e-3f - (float)zc;
+      }
+      bm_n = 1.0f;
+      bf_n = 2.0f;
+      return;
+    }
+#endif
     const size_t p2 = (size_t)pp_clampi(zc + 2, 0, d.nz - 1) * sz, p1 = (size_t)pp_clampi(zc + 1, 0, d.nz - 1) * sz;
     if constexpr (PP_SOFF != 0) {
       const unsigned s2 = (unsigned)p2 * 4u, s1 = (unsigned)p1 * 4u;
@@ -1020,7 +1048,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     constexpr bool ZIN = decltype(interior_tag)::value;   // 0 < zc < nz - 1 known at compile time (steady steps)
     const bool count_plane = (zc >= z0 && zc <= zo_last);
     const bool zlo_b = ZIN ? false : (zc == 0), zhi_b = ZIN ? false : (zc == d.nz - 1);
-#if PP_A_VOTE
+    if constexpr ((PP_A_VOTE != 0) && MASK) {   // (the branchy instances have no registers left for it: 6 spills, +11 % measured)
     // Round 4: one wavefront vote per round.  Where no lane of the wavefront sits on a first / last index and none of its seven
     // warped-image values is the sentinel -- everywhere but next to the volume's border and to voxels the warp mapped outside
     // the moving image -- ITK's case analysis selects the central difference on every axis, and the three gradients are five
@@ -1064,7 +1092,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
         }
       }
     }
-#else
+    } else {
 #pragma unroll
     for (int k = 0; k < G::KU; ++k) {
       const unsigned fl = uflag[k] >> 16;
@@ -1088,7 +1116,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
         }
       }
     }
-#endif
+    }
 #pragma unroll
     for (int k = 0; k < G::KU; ++k) {
       mprev[k] = mcur[k]; mcur[k] = mnext[k]; mnext[k] = min_[k];
@@ -1118,7 +1146,11 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
       const unsigned po = (unsigned)pp_clampi(zo, z0, zo_last) * sz;
       const unsigned o_ld = out_ok ? o_xy : 0u;
 #pragma unroll
+#ifdef PP_ABL_A_NOLOAD
+      for (int c = 0; c < (SUM ? 3 : 1); ++c) dsum[c] = make_float2((float)(o_ld + po) * 1e-6f, (float)c);
+#else
       for (int c = 0; c < (SUM ? 3 : 1); ++c) dsum[c] = pp_gld2(reinterpret_cast<const char*>(D), o_ld + ((unsigned)c * (unsigned)N + po) * 4u);
+#endif
     } else if (decltype(always_tag)::value || (zo >= z0 && zo <= zo_last && out_ok)) {
       const size_t po = (size_t)zo * sz;
 #pragma unroll
@@ -1211,7 +1243,11 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
       }
       __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink each add to its store again)
       const unsigned po4 = (unsigned)(ST ? zo : pp_clampi(zo, z0, zo_last)) * sz * 4u, N4 = (unsigned)N * 4u;
+#ifdef PP_ABL_A_NOSTORE
+      const unsigned o_st = PP_OOB;   // (measurement builds: every store dropped by the range check)
+#else
       const unsigned o_st = (ST || emit) ? o_xy : PP_OOB;
+#endif
 #pragma unroll
       for (int c = 0; c < 3; ++c) pp_bst2ss<NT>(r_us, o_st, (unsigned)c * N4 + po4, us[c][0], us[c][1]);
       __builtin_amdgcn_sched_barrier(0);   // (the next step's loads go behind the stores)
