@@ -359,6 +359,43 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
+def self_launch(n):
+    """Re-run this command as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same flags>` on
+    127.0.0.1 with a free port, and return its exit status.  The children see WORLD_SIZE and do not come here again."""
+    import socket
+    import subprocess
+    import sys
+
+    if os.environ.get("PP_BENCH_SELF_LAUNCHED") == "1":
+        raise SystemExit("bench.py: launched itself but WORLD_SIZE is still unset")
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, PP_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (dmabuf IPC: what RCCL needs on this host driver)
+    return subprocess.call(cmd, env=env)
+
+
+def stub_main(args, world, rank):
+    """PP_BENCH_STUB=1 (tests/test_bench_plumbing.py only): everything around the timed work -- process group, barrier-
+    bracketed timing, maximum over ranks, gather, rank 0's single line -- with a sleep in place of the kernels, so that the
+    way `--gpus N` starts can be exercised where no GPU exists.  The line says so and carries no value."""
+    ranks = Ranks(world, torch.device("cpu"), backend=os.environ.get("PP_BENCH_BACKEND", "gloo"))
+    try:
+        for _ in range(args.warmup):
+            time.sleep(0.001)
+        dt, per_rank, balance = ranks.timed(lambda: time.sleep(0.002 * args.steps * (1 + rank)), lambda: None)
+        n = ranks.count()
+        if rank == 0:
+            print(json.dumps({"metric": "Mvoxels/s per demons iter, 512x512x256 fp32", "value": None, "stub": True, "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "ranks": balance,
+                              "rccl_ranks": n, "data": "none: PP_BENCH_STUB=1, the kernels did not run"}), flush=True)
+    finally:
+        ranks.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -377,10 +414,17 @@ def main():
                          "command can calibrate FETCH_SIZE / WRITE_SIZE as MI355X_MICROARCH.md prescribes (tools/gpu_pmc2.sh)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` started plainly -- the way the driver starts N = 1 -- launches itself: one process per GPU
+    # under torch.distributed.run on this node (the driver's own N > 1 command sets WORLD_SIZE and comes straight through).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start it plainly, or under torch.distributed.run with --nproc-per-node {args.gpus})")
+    if os.environ.get("PP_BENCH_STUB") == "1":
+        return stub_main(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     local_rank = local_rank % torch.cuda.device_count()

@@ -66,3 +66,34 @@ def test_bench_refuses_to_run_without_a_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "needs a GPU" in (p.stderr + p.stdout)
+
+
+@pytest.mark.parametrize("n", [2])
+def test_bench_gpus_n_launches_itself(n):
+    """`python bench.py --gpus N` started plainly -- as the driver starts N = 1 -- re-runs itself under torch.distributed.run
+    with one process per GPU (round 3 died on an assert there).  Here over gloo with the kernels stubbed (PP_BENCH_STUB=1):
+    the single line comes from rank 0, names N ranks that answered a collective, and its time is the slowest rank's."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "PP_BENCH_SELF_LAUNCHED")}
+    env.update({"PP_BENCH_STUB": "1", "PP_BENCH_BACKEND": "gloo"})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["stub"] is True and r["value"] is None and r["n_gpus"] == n and r["rccl_ranks"] == n and r["steps"] == 5
+    assert len(r["ranks"]["per_rank_s"]) == n and r["ranks"]["slowest_rank"] == n - 1
+
+
+def test_bench_refuses_a_mismatched_world():
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0", PP_BENCH_STUB="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stderr + p.stdout)
