@@ -127,13 +127,15 @@ CARDIAC_SETTINGS_DEFAULTS = {   # cardiac/run.py:75-270
 }
 
 
-def run_cardiac_segmentation(img, guide_structure=None, settings=CARDIAC_SETTINGS_DEFAULTS, atlases=None, streams_per_gpu=1):
+def run_cardiac_segmentation(img, guide_structure=None, settings=CARDIAC_SETTINGS_DEFAULTS, atlases=None, streams_per_gpu=1,
+                             return_atlas_set=False):
     """Runs the atlas-based cardiac segmentation (reference cardiac/run.py:507-1147).
 
     img: target Image; guide_structure: optional binary Image on img's grid (e.g. a whole-heart mask) that
     switches on target cropping from the structure and structure-guided registration; settings: the reference's
     nested dict.  `atlases` / `streams_per_gpu` as in multiatlas.run_segmentation (atlases are read from
-    atlas_settings["atlas_path"] when not given).  Returns (results, results_prob).
+    atlas_settings["atlas_path"] when not given).  Returns (results, results_prob), with return_atlas_set also the per-atlas
+    propagated images / labels / weight maps (what the reference keeps in its atlas_set dictionary).
     """
     settings = copy.deepcopy(settings)
     vessels = settings.get("vessel_spline_settings", {}).get("vessel_name_list", [])
@@ -147,4 +149,6 @@ def run_cardiac_segmentation(img, guide_structure=None, settings=CARDIAC_SETTING
             "geometric_segmentation_settings['run_geometric_algorithms'] = False")
     out = atlas_pipeline(as_image(img), settings, guide_structure, atlases, streams_per_gpu, cardiac=True)
     run_cardiac_segmentation.last_iar_removed = out["iar_removed"]
+    if return_atlas_set:
+        return out["results"], out["results_prob"], out["atlas_set"]
     return out["results"], out["results_prob"]

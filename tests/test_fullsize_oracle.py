@@ -8,7 +8,10 @@
       sequential run bit for bit, and the fused probability / mask equal the ORACLE's combine_labels +
       process_probability_image fed the product's propagated labels and weight maps (multiatlas/run.py:312-404);
       8 atlases with iterative atlas selection at 256x256x128: the displaced atlases are removed, streams == sequential,
-      and the oracle's Q metric on the product's propagated labels agrees with the product's.
+      and the oracle's Q metric on the product's propagated labels agrees with the product's;
+  (d) round 4 -- BASELINE config 5 WHOLE, as one job at its stated size: 32 atlases of 512x512x256 on 4 HIP streams with
+      iterative atlas selection on and four displaced labels; and BASELINE config 4 through the cardiac entry point
+      (run_cardiac_segmentation, cardiac/run.py:507) with 8 atlases at 256x256x128, unguided and structure-guided.
 Every test writes its measured statistics through tests.helpers.record_stats (committed under profiles/).
 
 The oracle is parity-unpinned: these tests show HIP == oracle at full size, not HIP == SimpleITK."""
@@ -260,3 +263,126 @@ def _crop_of(target, crop):
     i0 = [int(round((crop.GetOrigin()[k] - target.GetOrigin()[k]) / crop.GetSpacing()[k])) for k in range(3)]
     nz, ny, nx = crop.shape
     return target.tensor[i0[2]:i0[2] + nz, i0[1]:i0[1] + ny, i0[0]:i0[0] + nx].contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# round 4: config 5 as ONE job at its stated size; config 4 through the cardiac entry point
+
+
+def _oracle_fusion_on_crop(aset, ids, structure, target, full_p, full_m):
+    """The oracle's combine_labels + process_probability_image (fusion.py:239-328) fed the PRODUCT's propagated labels and
+    weight maps of `ids`, against the product's fused volumes cut out on the crop grid.  -> statistics."""
+    from oracle import oracle as O
+
+    oset = {}
+    for cid in ids:
+        d = aset[cid]["DIR"]
+        sp, org = d[structure].GetSpacing(), d[structure].GetOrigin()
+        oset[cid] = {"DIR": {"Weight Map": O.Vol(d["Weight Map"].numpy(), sp, org), structure: O.Vol(d[structure].numpy(), sp, org)}}
+    crop_shape = oset[ids[0]]["DIR"][structure].arr.shape
+    want_p = O.combine_labels(oset, structure)[structure]
+    want_m = O.process_probability_image(want_p, 0.5)
+    org, sp = oset[ids[0]]["DIR"][structure].origin, oset[ids[0]]["DIR"][structure].spacing
+    i0 = [int(round((org[k] - target.GetOrigin()[k]) / sp[k])) for k in range(3)]
+    sl = tuple(slice(i0[2 - a], i0[2 - a] + crop_shape[a]) for a in range(3))
+    got_p, got_m = full_p.numpy()[sl], full_m.numpy()[sl]
+    return {"crop_shape_zyx": list(crop_shape), "prob_max_abs_vs_oracle": float(np.abs(got_p - want_p.arr).max()),
+            "mask_voxels_differing_vs_oracle": int((got_m != want_m.arr).sum()), "mask_voxels": int(want_m.arr.sum()),
+            "voxels_outside_crop": int(full_m.tensor.sum()) - int(got_m.sum())}
+
+
+def test_config5_whole_32_atlases_full_size_selection_streams_oracle(ctx):
+    """BASELINE config 5 in one piece on one GPU: 32 atlases of 512x512x256, 4 HIP streams, iterative atlas selection with
+    four displaced labels among them (multiatlas/run.py:261-404, label/iar.py:59-301).  The displaced atlases are removed and
+    no more than iar's fence allows; the 4-stream run equals the sequential one bit for bit; the fused mask equals the
+    oracle's combine_labels + process_probability_image on the survivors' propagated labels in every voxel; the oracle's Q
+    values of the first pass equal the product's."""
+    import platipy_amd as pa
+    from oracle import oracle as O
+    from platipy_amd.projects.multiatlas import run_segmentation
+
+    wrong = ("003", "011", "020", "029")
+    t0 = time.perf_counter()
+    ids, atlases, target, label, st = _atlas_job(ctx, SHAPE, 32, wrong=wrong)
+    st["iar_settings"].update({"reference_structure": "HEART", "min_best_atlases": 10})
+    torch.cuda.synchronize()
+    t_make = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    par, par_p, aset = run_segmentation(target, st, atlases=atlases, streams_per_gpu=4, return_atlas_set=True)
+    torch.cuda.synchronize()
+    t_par = time.perf_counter() - t0
+    removed_par = list(run_segmentation.last_iar_removed)
+    t0 = time.perf_counter()
+    seq, seq_p = run_segmentation(target, st, atlases=atlases, streams_per_gpu=1)
+    torch.cuda.synchronize()
+    t_seq = time.perf_counter() - t0
+    removed_seq = list(run_segmentation.last_iar_removed)
+    assert sorted(removed_par) == sorted(removed_seq)
+    assert set(wrong) <= set(removed_par) and len(removed_par) <= 8, removed_par
+    assert np.array_equal(par["HEART"].numpy(), seq["HEART"].numpy())                    # 4 streams == sequential, bit for bit
+    dp = float((seq_p["HEART"].tensor - par_p["HEART"].tensor).abs().max())
+    assert dp <= 2e-6, dp
+    kept = [i for i in ids if i not in removed_par]
+    stats = _oracle_fusion_on_crop(aset, kept, "HEART", target, par_p["HEART"], par["HEART"])
+    # first-pass Q values (iar.py:91-229), oracle against product, on the product's propagated labels with global-vote weights
+    crop = aset[ids[0]]["DIR"]["HEART"]
+    oset, gset = {}, {}
+    for cid in ids:
+        d = aset[cid]["DIR"]
+        sp, org = d["HEART"].GetSpacing(), d["HEART"].GetOrigin()
+        w = pa.label.compute_weight_map(crop.like(_crop_of(target, crop)), d["CT Image"], vote_type="global")
+        oset[cid] = {"DIR": {"Weight Map": O.Vol(w.numpy(), sp, org), "HEART": O.Vol(d["HEART"].numpy(), sp, org)}}
+        gset[cid] = {"DIR": {"Weight Map": w, "HEART": d["HEART"]}}
+    pa.label.run_iar(gset, "HEART", min_best_atlases=10, single_step=True)
+    q_g = dict(pa.label.run_iar.last_q_results)
+    q_o = O.iar_q_values(oset, "HEART")
+    rel = {k: abs(q_g[k] - q_o[k]) / max(abs(q_o[k]), 1e-12) for k in q_o}
+    stats.update({"atlases": 32, "size": [NX, NY, NZ], "hip_streams": 4, "displaced": list(wrong), "removed": removed_par,
+                  "streams_vs_sequential_prob_max": dp, "q_max_rel_diff": max(rel.values()),
+                  "dice_vs_template_label": _dice(par["HEART"].tensor, label), "seconds_make_atlases": t_make,
+                  "seconds_4_streams": t_par, "seconds_sequential": t_seq, "atlases_per_min_4_streams": 60.0 * 32 / t_par})
+    record_stats("fullsize_config5_whole_32_atlases", stats)
+    print("config 5 whole @512x512x256:", stats)
+    assert stats["prob_max_abs_vs_oracle"] <= 5e-6, stats
+    assert stats["mask_voxels_differing_vs_oracle"] == 0 and stats["voxels_outside_crop"] == 0, stats
+    assert list(q_g) == list(q_o) and stats["q_max_rel_diff"] <= 1e-3, stats
+    assert set(sorted(q_o, key=q_o.get)[-4:]) == set(wrong), q_o
+    assert stats["dice_vs_template_label"] > 0.95, stats
+
+
+@pytest.mark.parametrize("guided", [False, True])
+def test_config4_eight_atlases_through_the_cardiac_entry_point(ctx, guided):
+    """BASELINE config 4 is an 8-atlas CARDIAC segmentation (projects/cardiac/run.py:507): run_cardiac_segmentation with 8
+    atlases at 256x256x128, unguided and with the whole-heart guide structure (target cropped from the structure, distance-map
+    linear registration, structure-guided demons, masked intensity demons; cardiac/run.py:603-849).  The fused mask equals the
+    oracle's fusion of the product's propagated labels in every voxel and overlaps the template label."""
+    import platipy_amd as pa
+    from platipy_amd.projects.cardiac import CARDIAC_SETTINGS_DEFAULTS, run_cardiac_segmentation
+
+    shape = (128, 256, 256)
+    ids, atlases, target, label, _ = _atlas_job(ctx, shape, 8)
+    st = copy.deepcopy(CARDIAC_SETTINGS_DEFAULTS)
+    st["atlas_settings"].update({"atlas_id_list": ids, "atlas_structure_list": ["HEART"], "auto_crop_atlas": False,
+                                 "guide_structure_name": "HEART", "crop_atlas_to_structures": False})
+    st["iar_settings"]["reference_structure"] = None
+    st["label_fusion_settings"]["optimal_threshold"] = {"HEART": 0.5}
+    st["vessel_spline_settings"] = {"vessel_name_list": [], "vessel_radius_mm_dict": {}, "scan_direction_dict": {},
+                                    "stop_condition_type_dict": {}, "stop_condition_value_dict": {}}
+    st["postprocessing_settings"]["run_postprocessing"] = False
+    st["geometric_segmentation_settings"]["run_geometric_algorithms"] = False
+    guide = pa.Image(label, SPACING) if guided else None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res, prob, aset = run_cardiac_segmentation(target, guide, settings=st, atlases=atlases, streams_per_gpu=4, return_atlas_set=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    seq, _ = run_cardiac_segmentation(target, guide, settings=st, atlases=atlases, streams_per_gpu=1)
+    assert np.array_equal(res["HEART"].numpy(), seq["HEART"].numpy())
+    stats = _oracle_fusion_on_crop(aset, ids, "HEART", target, prob["HEART"], res["HEART"])
+    stats.update({"atlases": 8, "size": [shape[2], shape[1], shape[0]], "guided": guided, "seconds_4_streams": dt,
+                  "dice_vs_template_label": _dice(res["HEART"].tensor, label)})
+    record_stats("config4_cardiac_entry_%s_256x256x128" % ("guided" if guided else "unguided"), stats)
+    print("config 4 through run_cardiac_segmentation:", stats)
+    assert stats["prob_max_abs_vs_oracle"] <= 5e-6, stats
+    assert stats["mask_voxels_differing_vs_oracle"] == 0 and stats["voxels_outside_crop"] == 0, stats
+    assert stats["dice_vs_template_label"] > 0.95, stats
