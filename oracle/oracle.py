@@ -483,6 +483,23 @@ def rescale_intensity(a, out_min, out_max):
     return r.astype(np.float32)
 
 
+def binary_fillhole(mask_vol):
+    """sitk.BinaryFillhole(mask) with defaults (fusion.py:308): background reachable from the image border through faces stays
+    background (fullyConnected=False), every other background voxel becomes foreground."""
+    from scipy import ndimage
+
+    return mask_vol.like(ndimage.binary_fill_holes(mask_vol.arr != 0).astype(np.uint8))
+
+
+def connected_component(mask_vol):
+    """sitk.ConnectedComponent(mask) with defaults (fusion.py:311): face connectivity; [ITK-upstream] labels 1..n in raster order
+    of each component's first voxel.  -> int32 label volume."""
+    from scipy import ndimage
+
+    lab, _ = ndimage.label(mask_vol.arr != 0)
+    return mask_vol.like(lab.astype(np.int32))
+
+
 def process_probability_image(prob, threshold=0.5):
     """fusion.py:295-328: /max -> BinaryThreshold(>= thr) -> BinaryFillhole -> ConnectedComponent -> largest."""
     from scipy import ndimage

@@ -152,7 +152,16 @@ def _template_label(shape, device):
     return (((x - 0.5 * nx) / (0.2 * nx)) ** 2 + ((y - 0.5 * ny) / (0.18 * ny)) ** 2 + ((z - 0.5 * nz) / (0.25 * nz)) ** 2 < 1).to(torch.uint8)
 
 
-def _atlas_job(ctx, shape, n, wrong=()):
+def _inner_label(shape, device):
+    """A smaller ellipsoid inside the template label (a sub-structure of it)."""
+    nz, ny, nx = shape
+    x = torch.arange(nx, device=device, dtype=torch.float32).view(1, 1, nx)
+    y = torch.arange(ny, device=device, dtype=torch.float32).view(1, ny, 1)
+    z = torch.arange(nz, device=device, dtype=torch.float32).view(nz, 1, 1)
+    return (((x - 0.46 * nx) / (0.08 * nx)) ** 2 + ((y - 0.52 * ny) / (0.07 * ny)) ** 2 + ((z - 0.5 * nz) / (0.1 * nz)) ** 2 < 1).to(torch.uint8)
+
+
+def _atlas_job(ctx, shape, n, wrong=(), inner=False):
     """n atlases = independent smooth warps (seeds 2000 + i) of one template + its label seen through the
     same field; `wrong` atlases carry a displaced label (what iterative atlas selection exists to remove)."""
     import platipy_amd as pa
@@ -161,13 +170,16 @@ def _atlas_job(ctx, shape, n, wrong=()):
 
     device = torch.device("cuda", 0)
     label = _template_label(shape, device)
+    both = label + _inner_label(shape, device) * label if inner else label   # (inner: 2 inside the sub-structure, 1 in the rest)
     ids = [f"{i:03d}" for i in range(n)]
     atlases, target = {}, None
     for i, cid in enumerate(ids):
-        target, ct, _, lab = synth_pair(ctx, shape, SPACING, 1234, device, warp_seed=2000 + i, label=label)
+        target, ct, _, lab = synth_pair(ctx, shape, SPACING, 1234, device, warp_seed=2000 + i, label=both)
         if cid in wrong:
             lab = torch.roll(lab, (shape[0] // 6, -shape[1] // 7, shape[2] // 8), dims=(0, 1, 2)).contiguous()
-        atlases[cid] = {"CT Image": pa.Image(ct, SPACING), "HEART": pa.Image(lab, SPACING)}
+        atlases[cid] = {"CT Image": pa.Image(ct, SPACING), "HEART": pa.Image((lab > 0).to(torch.uint8), SPACING)}
+        if inner:
+            atlases[cid]["SUB"] = pa.Image((lab == 2).to(torch.uint8), SPACING)
     st = copy.deepcopy(MUTLIATLAS_SETTINGS_DEFAULTS)          # the reference pipeline's defaults (multiatlas/run.py:47-103)
     st["atlas_settings"]["atlas_id_list"] = ids
     st["atlas_settings"]["atlas_structure_list"] = ["HEART"]
@@ -274,21 +286,44 @@ def _oracle_fusion_on_crop(aset, ids, structure, target, full_p, full_m):
     weight maps of `ids`, against the product's fused volumes cut out on the crop grid.  -> statistics."""
     from oracle import oracle as O
 
+    # The oracle runs on the box around the propagated labels (+ MARGIN voxels): outside it every label is 0, so the weighted
+    # vote, its variance-1 blur (radius 3), the rescale's minimum (0) and maximum (inside the box) and the threshold are what
+    # they are on the whole crop grid -- the product's volumes are checked to be zero out there -- at a fraction of the cost.
+    MARGIN = 16
+    box = _label_box([aset[cid]["DIR"][structure].tensor for cid in ids], MARGIN)
     oset = {}
     for cid in ids:
         d = aset[cid]["DIR"]
         sp, org = d[structure].GetSpacing(), d[structure].GetOrigin()
-        oset[cid] = {"DIR": {"Weight Map": O.Vol(d["Weight Map"].numpy(), sp, org), structure: O.Vol(d[structure].numpy(), sp, org)}}
-    crop_shape = oset[ids[0]]["DIR"][structure].arr.shape
+        borg = tuple(org[k] + box[2 - k].start * sp[k] for k in range(3))
+        oset[cid] = {"DIR": {"Weight Map": O.Vol(d["Weight Map"].tensor[box].cpu().numpy(), sp, borg),
+                             structure: O.Vol(d[structure].tensor[box].cpu().numpy(), sp, borg)}}
+    crop_shape = tuple(aset[ids[0]]["DIR"][structure].shape)
     want_p = O.combine_labels(oset, structure)[structure]
     want_m = O.process_probability_image(want_p, 0.5)
-    org, sp = oset[ids[0]]["DIR"][structure].origin, oset[ids[0]]["DIR"][structure].spacing
+    org, sp = aset[ids[0]]["DIR"][structure].GetOrigin(), aset[ids[0]]["DIR"][structure].GetSpacing()
     i0 = [int(round((org[k] - target.GetOrigin()[k]) / sp[k])) for k in range(3)]
-    sl = tuple(slice(i0[2 - a], i0[2 - a] + crop_shape[a]) for a in range(3))
-    got_p, got_m = full_p.numpy()[sl], full_m.numpy()[sl]
-    return {"crop_shape_zyx": list(crop_shape), "prob_max_abs_vs_oracle": float(np.abs(got_p - want_p.arr).max()),
+    sl = tuple(slice(i0[2 - a] + box[a].start, i0[2 - a] + box[a].stop) for a in range(3))
+    got_p, got_m = full_p.tensor[sl].cpu().numpy(), full_m.tensor[sl].cpu().numpy()
+    return {"crop_shape_zyx": list(crop_shape), "oracle_box_zyx": [[b.start, b.stop] for b in box],
+            "prob_max_abs_vs_oracle": float(np.abs(got_p - want_p.arr).max()),
             "mask_voxels_differing_vs_oracle": int((got_m != want_m.arr).sum()), "mask_voxels": int(want_m.arr.sum()),
-            "voxels_outside_crop": int(full_m.tensor.sum()) - int(got_m.sum())}
+            "voxels_outside_crop": int(full_m.tensor.sum()) - int(got_m.sum()),
+            "prob_nonzero_outside_box": int((full_p.tensor != 0).sum()) - int((got_p != 0).sum())}
+
+
+def _label_box(tensors, margin):
+    """(z, y, x) slices of the bounding box of the union of the binary tensors, grown by `margin` voxels inside the grid."""
+    union = torch.zeros_like(tensors[0], dtype=torch.bool)
+    for t in tensors:
+        union |= t > 0
+    out = []
+    for a in range(3):
+        other = tuple(b for b in range(3) if b != a)
+        idx = torch.nonzero(union.sum(dim=other) > 0).flatten()
+        lo, hi = int(idx[0]), int(idx[-1]) + 1
+        out.append(slice(max(lo - margin, 0), min(hi + margin, union.shape[a])))
+    return tuple(out)
 
 
 def test_config5_whole_32_atlases_full_size_selection_streams_oracle(ctx):
@@ -325,14 +360,20 @@ def test_config5_whole_32_atlases_full_size_selection_streams_oracle(ctx):
     kept = [i for i in ids if i not in removed_par]
     stats = _oracle_fusion_on_crop(aset, kept, "HEART", target, par_p["HEART"], par["HEART"])
     # first-pass Q values (iar.py:91-229), oracle against product, on the product's propagated labels with global-vote weights
+    # (labels cut to the box around all of them: contours, distance maps and the samples between them lie inside it, so the Q
+    # values are those of the whole grid; the global-vote weight is one number per atlas, taken on the whole crop grid)
     crop = aset[ids[0]]["DIR"]["HEART"]
+    box = _label_box([aset[cid]["DIR"]["HEART"].tensor for cid in ids], 16)
     oset, gset = {}, {}
     for cid in ids:
         d = aset[cid]["DIR"]
         sp, org = d["HEART"].GetSpacing(), d["HEART"].GetOrigin()
+        borg = tuple(org[k] + box[2 - k].start * sp[k] for k in range(3))
         w = pa.label.compute_weight_map(crop.like(_crop_of(target, crop)), d["CT Image"], vote_type="global")
-        oset[cid] = {"DIR": {"Weight Map": O.Vol(w.numpy(), sp, org), "HEART": O.Vol(d["HEART"].numpy(), sp, org)}}
-        gset[cid] = {"DIR": {"Weight Map": w, "HEART": d["HEART"]}}
+        lab = pa.Image(d["HEART"].tensor[box].contiguous(), sp, borg)
+        wb = pa.Image(w.tensor[box].contiguous(), sp, borg)
+        oset[cid] = {"DIR": {"Weight Map": O.Vol(wb.numpy(), sp, borg), "HEART": O.Vol(lab.numpy(), sp, borg)}}
+        gset[cid] = {"DIR": {"Weight Map": wb, "HEART": lab}}
     pa.label.run_iar(gset, "HEART", min_best_atlases=10, single_step=True)
     q_g = dict(pa.label.run_iar.last_q_results)
     q_o = O.iar_q_values(oset, "HEART")
@@ -344,7 +385,7 @@ def test_config5_whole_32_atlases_full_size_selection_streams_oracle(ctx):
     record_stats("fullsize_config5_whole_32_atlases", stats)
     print("config 5 whole @512x512x256:", stats)
     assert stats["prob_max_abs_vs_oracle"] <= 5e-6, stats
-    assert stats["mask_voxels_differing_vs_oracle"] == 0 and stats["voxels_outside_crop"] == 0, stats
+    assert stats["mask_voxels_differing_vs_oracle"] == 0 and stats["voxels_outside_crop"] == 0 and stats["prob_nonzero_outside_box"] == 0, stats
     assert list(q_g) == list(q_o) and stats["q_max_rel_diff"] <= 1e-3, stats
     assert set(sorted(q_o, key=q_o.get)[-4:]) == set(wrong), q_o
     assert stats["dice_vs_template_label"] > 0.95, stats
@@ -360,12 +401,17 @@ def test_config4_eight_atlases_through_the_cardiac_entry_point(ctx, guided):
     from platipy_amd.projects.cardiac import CARDIAC_SETTINGS_DEFAULTS, run_cardiac_segmentation
 
     shape = (128, 256, 256)
-    ids, atlases, target, label, _ = _atlas_job(ctx, shape, 8)
+    ids, atlases, target, label, _ = _atlas_job(ctx, shape, 8, inner=True)
+    inner = _inner_label(shape, label.device) * label
+    # (with a guide structure the pipeline hands the guide back as that structure's result -- cardiac/run.py:940-941 -- so the
+    # fused structure compared with the oracle is the sub-structure; unguided it is the whole heart)
+    fused_name = "SUB" if guided else "HEART"
+    fused_truth = inner if guided else label
     st = copy.deepcopy(CARDIAC_SETTINGS_DEFAULTS)
-    st["atlas_settings"].update({"atlas_id_list": ids, "atlas_structure_list": ["HEART"], "auto_crop_atlas": False,
+    st["atlas_settings"].update({"atlas_id_list": ids, "atlas_structure_list": ["HEART", "SUB"], "auto_crop_atlas": False,
                                  "guide_structure_name": "HEART", "crop_atlas_to_structures": False})
     st["iar_settings"]["reference_structure"] = None
-    st["label_fusion_settings"]["optimal_threshold"] = {"HEART": 0.5}
+    st["label_fusion_settings"]["optimal_threshold"] = {"HEART": 0.5, "SUB": 0.5}
     st["vessel_spline_settings"] = {"vessel_name_list": [], "vessel_radius_mm_dict": {}, "scan_direction_dict": {},
                                     "stop_condition_type_dict": {}, "stop_condition_value_dict": {}}
     st["postprocessing_settings"]["run_postprocessing"] = False
@@ -377,12 +423,15 @@ def test_config4_eight_atlases_through_the_cardiac_entry_point(ctx, guided):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     seq, _ = run_cardiac_segmentation(target, guide, settings=st, atlases=atlases, streams_per_gpu=1)
-    assert np.array_equal(res["HEART"].numpy(), seq["HEART"].numpy())
-    stats = _oracle_fusion_on_crop(aset, ids, "HEART", target, prob["HEART"], res["HEART"])
-    stats.update({"atlases": 8, "size": [shape[2], shape[1], shape[0]], "guided": guided, "seconds_4_streams": dt,
-                  "dice_vs_template_label": _dice(res["HEART"].tensor, label)})
+    for name in ("HEART", "SUB"):
+        assert np.array_equal(res[name].numpy(), seq[name].numpy())
+    if guided:
+        assert np.array_equal(res["HEART"].numpy(), label.cpu().numpy())                 # the guide structure comes back as given
+    stats = _oracle_fusion_on_crop(aset, ids, fused_name, target, prob[fused_name], res[fused_name])
+    stats.update({"atlases": 8, "size": [shape[2], shape[1], shape[0]], "guided": guided, "seconds_4_streams": dt, "fused_structure": fused_name,
+                  "dice_vs_template_label": _dice(res[fused_name].tensor, fused_truth)})
     record_stats("config4_cardiac_entry_%s_256x256x128" % ("guided" if guided else "unguided"), stats)
     print("config 4 through run_cardiac_segmentation:", stats)
     assert stats["prob_max_abs_vs_oracle"] <= 5e-6, stats
     assert stats["mask_voxels_differing_vs_oracle"] == 0 and stats["voxels_outside_crop"] == 0, stats
-    assert stats["dice_vs_template_label"] > 0.95, stats
+    assert stats["dice_vs_template_label"] > (0.9 if guided else 0.95), stats
