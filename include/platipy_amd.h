@@ -184,8 +184,10 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
  * sitk.sitkIterationEvent, ...) printing GetElapsedIterations() / GetMetric() (deformable.py:260-264,
  * registration/utils.py:36-41).  The loop runs on the device without host round trips, so the per-iteration values are kept
  * in a device ring by the kernel that closes each iteration and read back here: entry k = GetMetric() / GetRMSChange() after
- * iteration k + 1 of the LAST pp_demons_execute_f32 on this ctx.  Returns the number of iterations that ran (entries written:
- * min(that, cap)), or a negative pp_status.  Synchronises the stream. */
+ * iteration k + 1 of the LAST pp_demons_execute_f32 on this ctx.  Returns the number of iterations that ran, or a negative
+ * pp_status; entries written: min(that, cap, PP_DEMONS_HISTORY_CAPACITY = 4096 -- the ring keeps the first 4096 iterations of an
+ * Execute, a return value above it says the later ones were not recorded).  Synchronises the stream. */
+#define PP_DEMONS_HISTORY_CAPACITY 4096
 int pp_demons_history(pp_ctx* ctx, double* metric, double* rms_change, int cap);
 
 /* ---- label fusion ------------------------------------------------------------------ */

@@ -19,6 +19,7 @@ INTERP_LINEAR = 2
 INTERP_BSPLINE = 3
 DEMONS_AUTO, DEMONS_STAGED, DEMONS_FUSED = 0, 1, 2
 ABI_VERSION = 1
+HISTORY_CAPACITY = 4096     # PP_DEMONS_HISTORY_CAPACITY: iterations of one Execute whose metric / RMS change the device ring keeps
 
 
 class Geom(C.Structure):
@@ -358,7 +359,14 @@ class Context:
         m, r = (C.c_double * cap)(), (C.c_double * cap)()
         n = self.lib.pp_demons_history(self.h, m, r, cap)
         self._chk(n if n < 0 else 0, "pp_demons_history")
-        return [(m[k], r[k]) for k in range(min(n, cap))]
+        kept = min(n, cap, HISTORY_CAPACITY)
+        if n > kept:
+            import warnings
+
+            warnings.warn(f"demons_history: {n} iterations ran, the device ring keeps the first {HISTORY_CAPACITY}; "
+                          f"{n - kept} later iterations have no recorded metric / RMS change", RuntimeWarning)
+        self.last_history_iterations = n     # iterations that ran (may exceed the number of entries)
+        return [(m[k], r[k]) for k in range(kept)]
 
     # -- fusion ---------------------------------------------------------------------
     def weight_map_local(self, target, moving, size, spacing, sigma, epsilon, out):

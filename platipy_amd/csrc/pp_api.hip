@@ -135,15 +135,21 @@ int pp_mail_take(pp_ctx* ctx, int writer, int n, unsigned long long seq, double*
   const auto t0 = std::chrono::steady_clock::now();
   bool synced = false;
   for (int k = 0; k < n; ++k) {
-    for (unsigned spins = 0; e[k].tag != seq; ++spins) {
+    for (unsigned spins = 0;; ++spins) {
+      // an entry is taken when its two words verify each other for THIS launch (pp_mail_tag): a torn or stale pair does not
+      const unsigned long long tag = e[k].tag;
+      std::atomic_thread_fence(std::memory_order_acquire);
+      const double value = e[k].value;
+      if (tag == pp_mail_tag(seq, value)) {
+        out[k] = value;
+        break;
+      }
       if ((spins & 1023u) != 1023u || std::chrono::steady_clock::now() - t0 <= std::chrono::milliseconds(200)) continue;
       // not there yet: wait for the stream the ordinary way (also surfaces a failed launch), then look once more
       if (synced) return pp_fail(ctx, PP_ERR_HIP, "kernel finished without posting its result");
       PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
       synced = true;
     }
-    std::atomic_thread_fence(std::memory_order_acquire);   // the value is read after the tag that validates it
-    out[k] = e[k].value;
   }
   return PP_OK;
 }

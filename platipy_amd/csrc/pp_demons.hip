@@ -37,11 +37,13 @@ struct pp_dev_stats {
 
 // One iteration's statistics into the history ring (called by the thread that publishes them, before elapsed is bumped).
 __device__ __forceinline__ void pp_stats_record(pp_dev_stats* st) {
-  if (st->hist && st->elapsed < st->hist_cap) {   // hist[0] = entries recorded, entry k at hist[2 + 2k], hist[3 + 2k]
+  if (!st->hist) return;
+  if (st->elapsed < st->hist_cap) {   // hist[0] = entries recorded, entry k at hist[2 + 2k], hist[3 + 2k]
     st->hist[2 + 2 * st->elapsed] = st->metric;
     st->hist[3 + 2 * st->elapsed] = st->rms;
     st->hist[0] = (double)(st->elapsed + 1);
   }
+  st->hist[1] = (double)(st->elapsed + 1);   // iterations that RAN (beyond the ring's capacity only this is kept)
 }
 
 __global__ void k_stats_init(pp_dev_stats* st, double* hist, int hist_cap) {
@@ -49,7 +51,10 @@ __global__ void k_stats_init(pp_dev_stats* st, double* hist, int hist_cap) {
   z.ssd = 0.0; z.ssc = 0.0; z.npx = 0; z.metric = 0.0; z.rms = 0.0; z.elapsed = 0; z.halt = 0;
   z.hist = hist;
   z.hist_cap = hist_cap;
-  if (hist) hist[0] = 0.0;
+  if (hist) {
+    hist[0] = 0.0;
+    hist[1] = 0.0;
+  }
   *st = z;
 }
 
@@ -1326,7 +1331,8 @@ int pp_demons_history(pp_ctx* ctx, double* metric, double* rms_change, int cap) 
   double head[2];
   int rc = pp_read_back(ctx, ctx->hist, head, sizeof(head));
   if (rc) return rc;
-  const int n = (int)head[0];
+  const int n = (int)head[0];                 // entries recorded (<= PP_HIST_CAP)
+  const int ran = (int)head[1];               // iterations that ran: the return value, also when the ring was too short
   const int take = n < cap ? n : cap;
   constexpr int CH = 4096 / (2 * (int)sizeof(double));   // entries per staged read-back
   double buf[2 * CH];
@@ -1339,7 +1345,7 @@ int pp_demons_history(pp_ctx* ctx, double* metric, double* rms_change, int cap) 
       rms_change[k + i] = buf[2 * i + 1];
     }
   }
-  return n;
+  return ran > n ? ran : n;
 }
 
 #ifdef PP_TRACE

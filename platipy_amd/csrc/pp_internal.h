@@ -112,12 +112,19 @@ constexpr int PP_MAIL_ENTRIES = (int)(PP_MAIL_SLOT / sizeof(pp_mail_entry));
 __host__ __device__ inline pp_mail_entry* pp_mail_slot(void* mailbox, int writer) {
   return reinterpret_cast<pp_mail_entry*>(static_cast<char*>(mailbox) + (size_t)writer * PP_MAIL_SLOT);
 }
+//   * The tag word is not the bare sequence number but pp_mail_tag(seq, value): the sequence number mixed with the value's
+//     own bits.  A 16-byte store is normally one transaction, but neither HIP nor PCIe promises it; if it ever tears, a new
+//     tag beside the previous launch's value (or the reverse) does not verify and the host keeps polling -- the protocol
+//     does not depend on the store being atomic.
+__host__ __device__ inline unsigned long long pp_mail_tag(unsigned long long seq, double value) {
+  return (seq * 0x9E3779B97F4A7C15ull) ^ __builtin_bit_cast(unsigned long long, value);
+}
 // one 16-byte store
-__device__ __forceinline__ void pp_mail_post(pp_mail_entry* e, double value, unsigned long long tag) {
+__device__ __forceinline__ void pp_mail_post(pp_mail_entry* e, double value, unsigned long long seq) {
   typedef unsigned long long u64x2 __attribute__((vector_size(16)));
   u64x2 w;
   w[0] = __builtin_bit_cast(unsigned long long, value);
-  w[1] = tag;
+  w[1] = pp_mail_tag(seq, value);
   *reinterpret_cast<u64x2*>(e) = w;
 }
 // -> the mailbox and the sequence number of the next launch

@@ -176,6 +176,31 @@ def _worker_streams(device, n):
     return pool[:n]
 
 
+def _hand_over(obj, stream, _seen=None):
+    """Tell the caching allocator that every tensor reachable from `obj` (dicts, sequences, Images, transforms and the fields
+    inside them) is now used on `stream` too (torch.Tensor.record_stream): a block a worker stream allocated is then not
+    handed out again -- to the worker's next atlas -- while work queued on the consumer's stream still reads it.  The
+    `done` -> `main.wait_event` ordering below already makes today's hand-over correct; this keeps it correct for whatever a
+    caller does with the results afterwards, whichever stream frees them."""
+    _seen = set() if _seen is None else _seen
+    if obj is None or id(obj) in _seen:
+        return
+    _seen.add(id(obj))
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _hand_over(v, stream, _seen)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _hand_over(v, stream, _seen)
+    else:
+        for name in ("tensor", "field", "transforms"):     # Image / DisplacementFieldTransform / CompositeTransform
+            if hasattr(obj, name):
+                _hand_over(getattr(obj, name), stream, _seen)
+
+
 def _map_atlases(fn, ids, streams_per_gpu, device):
     """Run fn(atlas_id) for this rank's atlases, `streams_per_gpu` at a time.  Each worker thread runs under its own
     long-lived HIP stream, hence its own pp_ctx (runtime.context follows torch's current stream), so one atlas's
@@ -209,6 +234,7 @@ def _map_atlases(fn, ids, streams_per_gpu, device):
     out = {}
     for i, (val, done) in res.items():
         main.wait_event(done)
+        _hand_over(val, main)
         out[i] = val
     return out
 

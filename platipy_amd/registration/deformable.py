@@ -156,8 +156,15 @@ class HipDemonsFilter:
         lazy = not self._commands and 0 < self._iterations <= 4096
         final = ctx.demons_execute(ft, mt, f.geom(), p, field, want_stats=not lazy)
         if self._commands:
-            for k, (metric, rms) in enumerate(ctx.demons_history()):
+            history = ctx.demons_history()
+            for k, (metric, rms) in enumerate(history):
                 self._stats = _IterationView(k + 1, metric, rms)
+                for fn in self._commands:
+                    fn()
+            # iterations beyond the ring's capacity (demons_history has warned): their events still fire, in order, with the
+            # iteration count right and the last measurements that exist
+            for k in range(len(history), int(getattr(ctx, "last_history_iterations", len(history)))):
+                self._stats = _IterationView(k + 1, final.metric, final.rms_change)
                 for fn in self._commands:
                     fn()
         self._stats = final
@@ -183,12 +190,14 @@ def multiscale_demons(registration_algorithm, fixed_image, moving_image, initial
     for resolution, smoothing_sigma in zip(resolution_staging, smoothing_sigmas):
         isotropic_voxel_size_mm = resolution if isotropic_resample else None
         shrink_factor = None if isotropic_resample else resolution
+        # (_share_input: the levels are only ever read below -- warped, differenced, never written in place --, so an unsmoothed
+        # shrink-1 level may be the caller's own tensor; tests/test_registration.py holds the inputs to be untouched)
         fixed_images.append(smooth_and_resample(fixed_image, isotropic_voxel_size_mm=isotropic_voxel_size_mm,
                                                 shrink_factor=shrink_factor, smoothing_sigma=smoothing_sigma,
-                                                interpolator=interp_order))
+                                                interpolator=interp_order, _share_input=True))
         moving_images.append(smooth_and_resample(moving_image, isotropic_voxel_size_mm=isotropic_voxel_size_mm,
                                                  shrink_factor=shrink_factor, smoothing_sigma=smoothing_sigma,
-                                                 interpolator=interp_order))
+                                                 interpolator=interp_order, _share_input=True))
 
     if initial_displacement_field is None:
         if initial_transform is not None:

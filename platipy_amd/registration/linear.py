@@ -23,7 +23,7 @@ trajectory is not a goal for this stage; it is judged by final metric / transfor
     histogram in 64-bit fixed point, so results do not depend on scheduling) and "joint_hist_mi" (20 bins, joint PDF
     smoothed with ITK's Gaussian operator of variance 1.5; the derivative differences the smoothed log-PDFs between
     neighbouring moving-bin centres -- this build's estimator under ITK's parameters, not a restatement of ITK's
-    interpolated-PDF derivative).  Intensity ranges are taken over the whole images (ITK: inside the masks);
+    interpolated-PDF derivative).  Intensity ranges are taken inside the masks when masks are given, as ITK does;
   * the "exhaustive" optimiser walks the grid of SetOptimizerAsExhaustive (2 n_i + 1 steps per parameter, step length in
     units of the physical-shift scales) in batches of 16 evaluations per launch; numberOfSteps defaults to the reference's
     six tens and can be passed (exhaustive_steps); grids above exhaustive_max_evaluations (EXHAUSTIVE_MAX_EVALUATIONS) raise

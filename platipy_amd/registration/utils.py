@@ -1,6 +1,7 @@
 """Drop-in for platipy/imaging/registration/utils.py:54-267 (apply_transform, its two wrappers and
 smooth_and_resample), on torch tensors in HBM through the HIP C ABI."""
 import functools
+import threading
 import logging
 
 import numpy as np
@@ -78,14 +79,20 @@ def _total_field(parts, reference):
             ctx.transform_to_field(geom, A, off, None, D)        # (A - I) p + off; zeros for the identity
         F = part.field
         Ft = (F.tensor if F.tensor.dtype == torch.float32 else F.tensor.float()).contiguous()
-        if F.same_grid(reference):
+        if F.same_grid(reference) and _identity_direction(reference):
             ctx.compose_field(D, Ft, geom)                       # D(p) += F(p + D(p))
-        else:   # the member's own grid: each component sampled at p + D(p), linear, 0 outside
+        else:   # the member's own grid -- or an oblique / flipped one, which pp_compose_field_f32 does not take (ADVICE round 3:
+            # the same composite must not work or fail depending on whether a member happens to share the grid) --: each
+            # component sampled at p + D(p) through the general resampler, linear, 0 outside
             add = torch.empty_like(D)
             for c in range(3):
                 ctx.resample(Ft[c].contiguous(), F.geom(), geom, add[c], field=D, interp=_lib.INTERP_LINEAR, default_value=0.0, u8=False)
             D = D + add
     return D
+
+
+def _identity_direction(image):
+    return np.allclose(np.asarray(image.GetDirection(), dtype=np.float64).reshape(3, 3), np.eye(3), rtol=0.0, atol=1e-12)
 
 
 def transform_to_displacement_field(transform, reference):
@@ -205,31 +212,60 @@ def _rows_read_by_resample(n_in, n_out, ratio):
     return need
 
 
-@functools.lru_cache(maxsize=64)
+_NEED_MASKS = {}            # (sizes_in, sizes_out, ratios, device) -> masks; entries are NEVER evicted (see _need_masks)
+_NEED_MASKS_LOCK = threading.Lock()
+_NEED_MASKS_MAX = 256
+
+
 def _need_masks(sizes_in, sizes_out, ratios, device):
     """(need_y, need_z) as uint8 device tensors for a pyramid level's geometry, or None when hardly anything can be skipped.
     Cached: a pipeline registers many pairs on the same grids, and each upload is a host-device round trip in front of
-    the level's first kernel."""
+    the level's first kernel.  A cached tensor is read by kernels on whatever stream its caller runs on, so it must never go
+    back to the allocator while such a kernel may be queued: entries are not evicted (a few hundred bytes each; past
+    _NEED_MASKS_MAX geometries new ones are simply not cached) and the dictionary is dropped only by runtime.release_all(),
+    which synchronises the device first (an LRU eviction could free a mask under another stream's kernel)."""
+    key = (sizes_in, sizes_out, ratios, device)
+    hit = _NEED_MASKS.get(key, False)
+    if hit is not False:
+        return hit
     need = [_rows_read_by_resample(n_in, n_out, ratio) for n_in, n_out, ratio in zip(sizes_in, sizes_out, ratios)]
-    if need[0].mean() * need[1].mean() > 0.5:
-        return None
-    dev = torch.device(device)
-    masks = tuple(torch.from_numpy(n).to(dev) for n in need)
-    if dev.type == "cuda":
-        # the upload is ordered on THIS thread's stream only; the cached tensors are handed to every worker thread (each on
-        # its own stream) from now on, so they must be complete before the cache publishes them
-        torch.cuda.current_stream(dev).synchronize()
+    masks = None
+    if need[0].mean() * need[1].mean() <= 0.5:
+        dev = torch.device(device)
+        masks = tuple(torch.from_numpy(n).to(dev) for n in need)
+        if dev.type == "cuda":
+            # the upload is ordered on THIS thread's stream only; the cached tensors are handed to every worker thread (each on
+            # its own stream) from now on, so they must be complete before the cache publishes them
+            torch.cuda.current_stream(dev).synchronize()
+    with _NEED_MASKS_LOCK:
+        if len(_NEED_MASKS) < _NEED_MASKS_MAX:
+            _NEED_MASKS.setdefault(key, masks)
+            return _NEED_MASKS[key]
+    if masks is not None and torch.device(device).type == "cuda":
+        for m in masks:     # uncached: the caller's stream is the only user, tell the allocator so
+            m.record_stream(torch.cuda.current_stream(torch.device(device)))
     return masks
 
 
+def release_cached_masks():
+    """Called by runtime.release_all() after a device synchronisation."""
+    with _NEED_MASKS_LOCK:
+        _NEED_MASKS.clear()
+
+
 def smooth_and_resample(image, isotropic_voxel_size_mm=None, shrink_factor=None, smoothing_sigma=None,
-                        interpolator=sitkLinear):
+                        interpolator=sitkLinear, _share_input=False):
     """One pyramid level (reference: registration/utils.py:195-267): optional Gaussian blur with sigma in mm,
     then linear resampling onto a corner-aligned coarser grid.
+
+    The result never shares storage with `image` (sitk.Resample returns a new image).  `_share_input=True` is the pyramid
+    builder's private contract: it only READS its levels, so an unsmoothed shrink-factor-1 level may be the input's own
+    tensor under a new header instead of a 268 MB copy.
 
     The blur is only evaluated where the resample will read it (pp_discrete_gaussian_rows_f32): onto an 8x coarser
     grid that is a quarter of the z planes and a sixteenth of the rows, and every value produced is the dense filter's."""
     image = as_image(image)
+    as_image_tensor = image.tensor           # (the caller's storage: a blur below replaces `image` by a fresh tensor)
     original_spacing = image.GetSpacing()
     original_size = image.GetSize()
 
@@ -273,12 +309,14 @@ def smooth_and_resample(image, isotropic_voxel_size_mm=None, shrink_factor=None,
             image = image.like(out)      # valid exactly where the resample below reads it
 
     if new_size is None:
+        # (no resampling asked for: the reference returns its -- possibly smoothed -- input image object itself)
         return image
     if (list(new_size) == list(original_size) and interpolator in (sitkLinear, sitkNearestNeighbor)
             and np.allclose(new_spacing, original_spacing, rtol=1e-12, atol=0.0)):
         # shrink factor 1 (the finest pyramid level): the output grid IS the input grid -- ((n - 1) s) / (n - 1) can differ from
         # s in the last bit, a shift of < 1e-9 voxel -- and resampling onto it returns the samples themselves
-        return Image(image.tensor, new_spacing, image.GetOrigin(), image.GetDirection())
+        shared = image.tensor if (_share_input or image.tensor is not as_image_tensor) else image.tensor.clone()
+        return Image(shared, new_spacing, image.GetOrigin(), image.GetDirection())
     ref = Image(torch.empty((new_size[2], new_size[1], new_size[0]), dtype=torch.float32, device="meta"), new_spacing,
                 image.GetOrigin(), image.GetDirection())
     out = resample_image(image, ref, None, interpolator, 0.0)

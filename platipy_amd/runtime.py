@@ -39,7 +39,15 @@ def context(device=None):
 
 
 def release_all():
+    """Destroy every context (and its workspace) and drop the device-side caches of the Python layer."""
+    import torch
+
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()          # nothing queued may still read what is about to be freed
     with _LOCK:
         for c in _CTX.values():
             c.close()
         _CTX.clear()
+    from .registration.utils import release_cached_masks
+
+    release_cached_masks()

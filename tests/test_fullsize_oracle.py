@@ -435,3 +435,30 @@ def test_config4_eight_atlases_through_the_cardiac_entry_point(ctx, guided):
     assert stats["prob_max_abs_vs_oracle"] <= 5e-6, stats
     assert stats["mask_voxels_differing_vs_oracle"] == 0 and stats["voxels_outside_crop"] == 0, stats
     assert stats["dice_vs_template_label"] > (0.9 if guided else 0.95), stats
+
+
+def test_hundred_chains_on_four_streams_equal_the_sequential_run(ctx):
+    """the stream-parallel path under repetition, as a test instead of a hunt (round 3's mailbox and
+    row-mask races showed up once in ~15 affine registrations).  25 runs of 4 atlas chains (affine + demons + propagation +
+    fusion, the pipeline's defaults) at 256x256x128 on 4 HIP streams = 100 chains; every run's fused mask equals the ONE
+    sequential run's bit for bit and its probabilities to the fp32 summation order."""
+    from platipy_amd.projects.multiatlas import run_segmentation
+
+    shape = (128, 256, 256)
+    ids, atlases, target, label, st = _atlas_job(ctx, shape, 4)
+    seq, seq_p = run_segmentation(target, st, atlases=atlases, streams_per_gpu=1)
+    want_m, want_p = seq["HEART"].tensor.clone(), seq_p["HEART"].tensor.clone()
+    worst, bad = 0.0, []
+    t0 = time.perf_counter()
+    for run in range(25):
+        par, par_p = run_segmentation(target, st, atlases=atlases, streams_per_gpu=4)
+        if not torch.equal(par["HEART"].tensor, want_m):
+            bad.append(run)
+        worst = max(worst, float((par_p["HEART"].tensor - want_p).abs().max()))
+    torch.cuda.synchronize()
+    stats = {"runs": 25, "chains": 100, "size": [shape[2], shape[1], shape[0]], "runs_with_a_different_mask": bad,
+             "prob_max_abs_vs_sequential": worst, "seconds": time.perf_counter() - t0, "dice_vs_template_label": _dice(want_m, label)}
+    record_stats("stream_stress_100_chains_256x256x128", stats)
+    print("stream stress:", stats)
+    assert not bad, stats
+    assert worst <= 2e-6, stats

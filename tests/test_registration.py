@@ -362,6 +362,64 @@ def test_apply_transform_general_composites(host_api):
     np.testing.assert_allclose(d2[:, in2], want2[:, in2], rtol=0, atol=2e-4)
 
 
+def test_composite_of_fields_on_a_flipped_reference_grid(host_api):
+    """a composite whose displacement-field members share the REFERENCE grid takes the same route on an
+    oblique / flipped grid as one whose members have grids of their own (pp_compose_field_f32 refuses direction cosines; the
+    general resampler does not) -- the result must not depend on which branch _total_field picks.  Two fields on a grid
+    whose x axis runs backwards, against the map built with scipy in index space."""
+    from scipy.ndimage import map_coordinates
+
+    pa = host_api
+    shape, spacing, origin = (12, 18, 26), (1.1, 0.9, 1.7), (40.0, -3.0, 1.0)
+    direction = (-1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
+    Dm = np.array(direction).reshape(3, 3)
+    f1 = random_dvf(shape, spacing, seed=72, max_mm=2.0)
+    ref = pa.image_from_array(np.zeros(shape, np.float32), spacing, origin, direction)
+    F1 = pa.DisplacementFieldTransform(pa.image_from_array(f1, spacing, origin, direction, is_vector=True))
+    assert F1.field.same_grid(ref)
+
+    def field_at(q):     # physical points [3, ...] -> the field there (physical vectors), linear, zero outside
+        rel = np.einsum("cr,c...->r...", Dm, q - np.array(origin).reshape(3, 1, 1, 1))     # Dir^T (q - origin)
+        idx = [rel[a] / spacing[a] for a in range(3)]
+        return np.stack([map_coordinates(f1[c].astype(np.float64), [idx[2], idx[1], idx[0]], order=1, mode="constant", cval=0.0) for c in range(3)]), idx
+
+    zz, yy, xx = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing="ij")
+    idx0 = np.stack([spacing[0] * xx, spacing[1] * yy, spacing[2] * zz])
+    p = np.array(origin).reshape(3, 1, 1, 1) + np.einsum("rc,c...->r...", Dm, idx0)
+    d1, _ = field_at(p)
+    q = p + d1
+    d2, idx = field_at(q)
+    want = q + d2 - p
+    inside = np.ones(shape, bool)
+    for a in range(3):
+        inside &= (idx[a] >= 0) & (idx[a] <= shape[2 - a] - 1)
+    assert inside.mean() > 0.5
+    got = pa.registration.utils.transform_to_displacement_field(pa.CompositeTransform([F1, F1]), ref).numpy()
+    np.testing.assert_allclose(got[:, inside], want[:, inside], rtol=0, atol=2e-4)
+    # a single field is the field itself, on any grid
+    one = pa.registration.utils.transform_to_displacement_field(F1, ref).numpy()
+    np.testing.assert_allclose(one, f1, rtol=0, atol=1e-6)
+
+
+def test_public_smooth_and_resample_never_aliases_its_input(host_api):
+    """an unsmoothed shrink-factor-1 level is the input's samples; the public function still returns new
+    storage (sitk.Resample does), only the pyramid builder's private _share_input=True may hand the tensor through -- and a
+    registration leaves both of its inputs untouched."""
+    pa = host_api
+    shape, spacing = (10, 16, 20), (1.0, 1.0, 1.0)
+    a = pa.image_from_array(phantom(shape, seed=3), spacing)
+    out = pa.registration.smooth_and_resample(a, shrink_factor=1, smoothing_sigma=0)
+    assert out.tensor.data_ptr() != a.tensor.data_ptr()
+    np.testing.assert_array_equal(out.numpy(), a.numpy())
+    shared = pa.registration.smooth_and_resample(a, shrink_factor=1, smoothing_sigma=0, _share_input=True)
+    assert shared.tensor.data_ptr() == a.tensor.data_ptr()
+    b = pa.image_from_array(phantom(shape, seed=4), spacing)
+    a0, b0 = a.numpy().copy(), b.numpy().copy()
+    pa.registration.fast_symmetric_forces_demons_registration(a, b, resolution_staging=[2, 1], iteration_staging=[3, 3])
+    np.testing.assert_array_equal(a.numpy(), a0)
+    np.testing.assert_array_equal(b.numpy(), b0)
+
+
 def test_verbose_registration_prints_one_line_per_iteration(host_api, capsys):
     """verbose=True (reference deformable.py:260-264, registration/utils.py:36-41): the observer prints
     "{elapsed:3} = {metric:10.5f}" after every iteration of every level, metrics falling within a level."""
