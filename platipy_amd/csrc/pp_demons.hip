@@ -290,7 +290,14 @@ struct fused_geom {
   static constexpr int KU = (NU + NTH - 1) / NTH;   // of which one thread owns at most KU
   static constexpr int MW = UW + 2;               // image tile (1 more voxel each side for gradients)
   static constexpr int MH = UH + 2;
-  static constexpr int MWP = MW;
+  // Row pitch of the packed image tile (float2).  OPT == 2 (the 512-thread kernels): padded to UW + 32, so that the ESM pass's
+  // ds_read_b64 of a wave -- 64 consecutive update voxels, which wrap from one 68-voxel row into the next -- still touches 64
+  // distinct banks after the wrap (2 (MWP - UW) = 64 dwords: the same bank phase); unpadded, every wrapped wave-read hit two
+  // banks twice (+39 % cycles on kernel A's most frequent LDS read, MI355X_MICROARCH.md's LDS table).
+#ifndef PP_A_MWP_PAD
+#define PP_A_MWP_PAD 1
+#endif
+  static constexpr int MWP = (PP_A_MWP_PAD != 0 && OPT == 2) ? UW + 32 : MW;
   static constexpr int NB = MW * MH - UW * UH;    // border ring elements
   static constexpr int XI = UH * (TX / 4);        // x-pass work items per component
   // LDS carve (floats): region 1 holds the two image tiles during the force phase and is reused for

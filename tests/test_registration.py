@@ -51,16 +51,16 @@ def test_smooth_and_resample_sparse_blur_is_the_dense_blur(host_api, monkeypatch
     for kw in [dict(shrink_factor=4, smoothing_sigma=4), dict(shrink_factor=8, smoothing_sigma=8), dict(shrink_factor=[4, 4, 3], smoothing_sigma=2),
                dict(isotropic_voxel_size_mm=7.5, smoothing_sigma=5.0), dict(shrink_factor=4, smoothing_sigma=3, interpolator=pa.sitkNearestNeighbor)]:
         monkeypatch.setattr(utils, "_rows_read_by_resample", spy)
-        utils._need_masks.cache_clear()          # (the masks are cached per level geometry)
+        utils.release_cached_masks()          # (the masks are cached per level geometry)
         used.clear()
         sparse = pa.registration.smooth_and_resample(img, **kw).numpy()
         assert used and min(used) < 0.75                                         # rows really were skipped
         monkeypatch.setattr(utils, "_rows_read_by_resample", lambda n_in, n_out, ratio: np.ones(n_in, np.uint8))
-        utils._need_masks.cache_clear()
+        utils.release_cached_masks()
         dense = pa.registration.smooth_and_resample(img, **kw).numpy()
         assert np.isfinite(sparse).all()
         np.testing.assert_array_equal(sparse, dense)
-    utils._need_masks.cache_clear()
+    utils.release_cached_masks()
 
 
 def test_apply_transform_dtype_round_trip(host_api):
