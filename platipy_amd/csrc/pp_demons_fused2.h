@@ -22,6 +22,9 @@
 
 // Register budget: 4 waves per SIMD = two 512-thread blocks per CU (<= 128 VGPRs); without the bound the scheduler
 // spends up to ~170 registers on load latency it cannot use with one block per CU.
+#ifndef PP_A_XASM
+#define PP_A_XASM 1
+#endif
 #ifndef PP_B_XDPP
 #define PP_B_XDPP 1
 #endif
@@ -212,6 +215,20 @@ __device__ __forceinline__ void pp_strip_remap_lds(float* strip, int cstride, un
   }
 }
 
+// 16 bytes from a 16-byte-aligned LDS address as ONE ds_read_b128.  (Left to the compiler, the x pass's two float4 loads are
+// re-cut by the SLP vectoriser into the operand pairs of its v_pk_fma_f32 -- ds_read2_b32 / ds_read_b64 at odd dword offsets
+// and a 16-byte lane stride: 2- and 4-way bank conflicts, most of kernel A's 34 % LDS conflict cycles.)  The wait is in the
+// statement because the compiler does not count loads it cannot see.
+__device__ __forceinline__ void pp_lds_read2x128(const float* p, float4& a, float4& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && PP_A_XASM
+  const unsigned addr = (unsigned)(size_t)p;   // (LDS pointers are 32-bit offsets in the low half of a flat address)
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(addr) : "memory");
+#else
+  a = *reinterpret_cast<const float4*>(p);
+  b = *reinterpret_cast<const float4*>(p + 4);
+#endif
+}
+
 // x pass with per-thread precomputed LDS offsets (float indices; src < 0: no item).
 template <int R, int NXI, int NITEMS>
 __device__ __forceinline__ void fused2_xpass(const float* __restrict__ us, float* __restrict__ xs, const pp_taps_small& wx,
@@ -221,10 +238,17 @@ __device__ __forceinline__ void fused2_xpass(const float* __restrict__ us, float
     if ((i + 1) * 512 > NITEMS && xsrc[i] < 0) continue;   // only the last round can be partial
     const float* src = us + xsrc[i];
     float in[4 + 2 * R];
+    if constexpr ((4 + 2 * R) / 4 == 2) {   // radii 2 and 3: two whole 16-byte groups
+      float4 v0, v1;
+      pp_lds_read2x128(src, v0, v1);
+      in[0] = v0.x; in[1] = v0.y; in[2] = v0.z; in[3] = v0.w;
+      in[4] = v1.x; in[5] = v1.y; in[6] = v1.z; in[7] = v1.w;
+    } else {
 #pragma unroll
-    for (int q = 0; q < (4 + 2 * R) / 4; ++q) {
-      const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
-      in[4 * q + 0] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
+      for (int q = 0; q < (4 + 2 * R) / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+        in[4 * q + 0] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
+      }
     }
     if constexpr ((4 + 2 * R) % 4 == 2) {
       const float2 v = *reinterpret_cast<const float2*>(src + (4 + 2 * R) / 4 * 4);
