@@ -1189,6 +1189,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
   float v[3][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
 
   float2 dsum[SUM ? 3 : 1];
+  const bool dzero = (nprev == 0);   // (wave-uniform; see the adds in the plane step)
   const unsigned o_xy1 = (x + 1 < d.nx) ? o_xy + 4u : o_xy;
   auto load_dsum = [&](int zo, auto always_tag) {
     if constexpr (MASK) {
@@ -1283,6 +1284,14 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     float us[3][2];
     fused2_ring<R, P>(rg, v, a.wz, us);
     constexpr bool UNC = MASK || ST;   // memory instructions issued unconditionally
+    if constexpr (SUM) {
+      // First iteration of an Execute (nprev == 0): the field is zero by definition and its buffer has NOT been cleared (an
+      // 805 MB memset at 512 x 512 x 256) -- whatever the loads above returned is replaced by the zeros it stands for.
+      if (dzero) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dsum[c] = make_float2(0.0f, 0.0f);
+      }
+    }
     if constexpr (UNC) {
       // all three adds before the first store: the adds wait for the D loads of the previous step, and a wait placed between
       // two stores also waits for the first store's acknowledgement (vmcnt retires in issue order).  One store form (even
