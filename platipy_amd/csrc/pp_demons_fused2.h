@@ -25,9 +25,6 @@
 #ifndef PP_A_XASM
 #define PP_A_XASM 1
 #endif
-#ifndef PP_B_XDPP
-#define PP_B_XDPP 1
-#endif
 #ifndef PP_B_XSHFL
 #define PP_B_XSHFL 1
 #endif
@@ -399,24 +396,7 @@ struct strip_lanes {
   static_assert(G::RP == 4 && G::NSL == 1, "one halo strip either side, one strip per thread");
   static_assert(RPW >= 1 && (G::UH + RPW - 1) / RPW <= G::NTH / 64, "the tile's rows fit the block's waves");
 };
-// Value of the previous / next lane of the wavefront (DPP wave_shr:1 / wave_shl:1, a VALU move: no LDS crossbar trip).
-// Lane 0 / lane 63 keep their own value.
-__device__ __forceinline__ float pp_lane_prev(float v) {
-#if PP_B_XDPP
-  const int i = __builtin_bit_cast(int, v);
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x138, 0xf, 0xf, false));
-#else
-  return __shfl_up(v, 1);
-#endif
-}
-__device__ __forceinline__ float pp_lane_next(float v) {
-#if PP_B_XDPP
-  const int i = __builtin_bit_cast(int, v);
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x130, 0xf, 0xf, false));
-#else
-  return __shfl_down(v, 1);
-#endif
-}
+// (pp_lane_prev / pp_lane_next -- the DPP whole-wave shifts -- live in pp_internal.h: pp_fir.hip's fused Gaussian uses them too)
 __device__ __forceinline__ float pp_pick4(float ax, float ay, float az, float aw, unsigned i) {   // (selects on scalars: no vector indexing)
   const float lo = (i & 1u) ? ay : ax, hi = (i & 1u) ? aw : az;
   return (i & 2u) ? hi : lo;

@@ -607,6 +607,156 @@ int pp_conv_axis(pp_ctx* ctx, int axis, const float* in, const float* add, float
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// DiscreteGaussian of a scalar volume with small radii (<= 4 on every axis) as ONE kernel (round 4): z, y, x in one sweep.
+//
+// The three-launch form moves 24 bytes per voxel (each pass reads and writes the volume); this one reads it once and writes
+// it once.  A 64 x 16 tile (plus an R-voxel rim in x and y, fetched as 16-byte strips) marches along z:
+//   z pass   a thread owns one strip of four x voxels of the rimmed tile and keeps its last 2R + 1 planes in registers;
+//            the z-filtered strip goes to an LDS tile (two buffers: one barrier per plane);
+//   y pass   a thread owns one strip of one OUTPUT row: 2R + 1 ds_read_b128 down the tile;
+//   x pass   in registers: the 18 strips of a row sit in adjacent lanes (three rows per wavefront), the R voxels either side
+//            come from the neighbouring lanes by DPP whole-wave shifts; the sixteen interior strips store 16 bytes.
+// Arithmetic: each pass is the chain acc = fmaf(w[k], v[k], acc) from the lowest index up, in fp32, on fp32 intermediates --
+// k_fir_march / k_fir_x_shfl operation for operation, taps beyond an axis's own radius being zero (they add +0) -- so the
+// output is bit-identical to the three passes (tests/test_kernels.py).  Rim voxels outside the volume repeat the clamped
+// INPUT voxel; the z pass acts on each (x, y) column alone, so that is the z-filtered edge value the staged y pass would
+// have clamped to, and likewise for x after y (ZeroFluxNeumann on every intermediate).
+template <int R>
+struct gauss3_taps {
+  float wz[2 * R + 1], wy[2 * R + 1], wx[2 * R + 1];
+};
+template <int R>
+__global__ void __launch_bounds__(512) k_gauss3_zyx(const float* __restrict__ in, float* __restrict__ out, pp_dims d, gauss3_taps<R> taps,
+                                                     int zchunk, int gx, int gy, int per_xcd) {
+  constexpr int TX = 64, TY = 16, W = 2 * R + 1;
+  constexpr int SPR = TX / 4 + 2;            // strips per row of the rimmed tile (one rim strip either side: R <= 4)
+  constexpr int UW = 4 * SPR, UH = TY + 2 * R;
+  constexpr int NS = SPR * UH;               // strips per plane (<= 432)
+  constexpr int RPW = 64 / SPR;              // rows per wavefront in the y / x pass (3)
+  static_assert(NS <= 512 && (TY + RPW - 1) / RPW <= 8, "one strip per thread, the output rows fit the block's waves");
+  __shared__ __attribute__((aligned(16))) float tile[2][UH * UW];
+  // XCD-aware tile order as the fused demons kernels: block b runs on XCD b % 8 and takes tile rank (b % 8) * per_xcd + b / 8
+  const unsigned b = blockIdx.x, rank = (b & 7u) * (unsigned)per_xcd + (b >> 3);
+  const unsigned gz = (unsigned)((d.nz + zchunk - 1) / zchunk);
+  if (rank >= (unsigned)gx * gy * gz) return;
+  const int tx0 = (int)(rank % gx) * TX, ty0 = (int)((rank / gx) % gy) * TY, z0 = (int)(rank / ((unsigned)gx * gy)) * zchunk;
+  const int z1 = z0 + zchunk < d.nz ? z0 + zchunk : d.nz;
+  const int t = threadIdx.x;
+  const size_t sz = (size_t)d.nx * d.ny;
+
+  // z pass ownership: strip t of the rimmed tile
+  const bool zs_live = t < NS;
+  const int zs = zs_live ? t : 0;
+  const int uy = zs / SPR, sx = zs - uy * SPR;
+  const int xs = tx0 - 4 + 4 * sx, yc = pp_clampi(ty0 - R + uy, 0, d.ny - 1);
+  const int xl = pp_clampi(xs, 0, d.nx - 4);
+  unsigned jm = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) jm |= (unsigned)(pp_clampi(xs + i, 0, d.nx - 1) - xl) << (2 * i);
+  const size_t g_in = (size_t)yc * d.nx + xl;
+  auto load = [&](int q, float (&v)[4]) {
+    q = q < 0 ? 0 : (q > d.nz - 1 ? d.nz - 1 : q);
+    const float4 r = *reinterpret_cast<const float4*>(in + (size_t)q * sz + g_in);
+    if (jm == 0xE4u) {
+      v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    } else {   // strips that leave the volume in x: every position takes its clamped voxel
+      const float e[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned s_ = (jm >> (2 * i)) & 3u;
+        v[i] = s_ == 0 ? e[0] : (s_ == 1 ? e[1] : (s_ == 2 ? e[2] : e[3]));
+      }
+    }
+  };
+  // y / x pass ownership: strip sxo of output row oy, rows dealt RPW per wavefront
+  const int lane = t & 63, riw = lane / SPR, sxo = lane - riw * SPR;
+  const int oy = (t >> 6) * RPW + riw;
+  const bool ys_live = riw < RPW && oy < TY;
+  const int xo = tx0 + 4 * (sxo - 1), yo = ty0 + oy;
+  const bool st_live = ys_live && sxo >= 1 && sxo <= SPR - 2 && xo < d.nx && yo < d.ny;   // (nx % 4 == 0: whole strips)
+  const size_t g_out = (size_t)yo * d.nx + xo;
+
+  float win[W][4];
+#pragma unroll
+  for (int k = 0; k < W; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) win[k][i] = 0.0f;
+  if (zs_live) {
+#pragma unroll
+    for (int k = 1; k < W; ++k) load(z0 - R + k - 1, win[k]);   // slots 1 .. W-1: planes z0-R .. z0+R-1
+  }
+  for (int z = z0; z < z1; ++z) {
+    float* const tb = tile[(z - z0) & 1];
+    if (zs_live) {
+#pragma unroll
+      for (int k = 0; k < W - 1; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) win[k][i] = win[k + 1][i];
+      load(z + R, win[W - 1]);
+      float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int k = 0; k < W; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = fmaf(taps.wz[k], win[k][i], a[i]);
+      *reinterpret_cast<float4*>(tb + uy * UW + 4 * sx) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+    __syncthreads();
+    // (the other buffer is written in the next step, behind this barrier: every read of it finished before the barrier of
+    // the step after)
+    float own[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (ys_live) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        const float4 r = *reinterpret_cast<const float4*>(tb + (oy + k) * UW + 4 * sxo);
+        own[0] = fmaf(taps.wy[k], r.x, own[0]);
+        own[1] = fmaf(taps.wy[k], r.y, own[1]);
+        own[2] = fmaf(taps.wy[k], r.z, own[2]);
+        own[3] = fmaf(taps.wy[k], r.w, own[3]);
+      }
+    }
+    // x pass: [prev lane's strip | own | next lane's strip], every lane of the wavefront takes part in the shifts
+    float c[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      c[i] = pp_lane_prev(own[i]);
+      c[4 + i] = own[i];
+      c[8 + i] = pp_lane_next(own[i]);
+    }
+    if (st_live) {
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < W; ++k) acc = fmaf(taps.wx[k], c[4 + j - R + k], acc);
+        o[j] = acc;
+      }
+      *reinterpret_cast<float4*>(out + (size_t)z * sz + g_out) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+template <int R>
+int launch_gauss3(pp_ctx* ctx, const float* in, float* out, const pp_dims& d, const pp_taps taps[3]) {
+  gauss3_taps<R> g;
+  for (int k = 0; k < 2 * R + 1; ++k) {   // an axis's taps centred in the bucket, zeros beyond its own radius
+    const int o = k - R;
+    g.wz[k] = (o < -taps[2].r || o > taps[2].r) ? 0.0f : taps[2].w[o + taps[2].r];
+    g.wy[k] = (o < -taps[1].r || o > taps[1].r) ? 0.0f : taps[1].w[o + taps[1].r];
+    g.wx[k] = (o < -taps[0].r || o > taps[0].r) ? 0.0f : taps[0].w[o + taps[0].r];
+  }
+  const int gx = (d.nx + 63) / 64, gy = (d.ny + 15) / 16;
+  // z-chunks: enough tiles for ~4 blocks on each of the 256 CUs, chunks no shorter than 8 planes (2R planes are re-read per chunk)
+  int zchunk = d.nz;
+  while (zchunk > 8 && (long)gx * gy * ((d.nz + zchunk - 1) / zchunk) < 1024) zchunk = (zchunk + 1) / 2;
+  const int gz = (d.nz + zchunk - 1) / zchunk;
+  const int per_xcd = (int)(((long)gx * gy * gz + 7) / 8);
+  hipLaunchKernelGGL((k_gauss3_zyx<R>), dim3(8u * (unsigned)per_xcd), dim3(512), 0, ctx->stream, in, out, d, g, zchunk, gx, gy, per_xcd);
+  PP_LAUNCH_CHECK(ctx, "k_gauss3_zyx");
+  return PP_OK;
+}
+
 // dst = G_order[2] G_order[1] G_order[0] (src [+ add]); tmp1/tmp2 are ncomp-plane scratch.
 // dst may alias src (and add): the last pass reads only tmp2.
 int pp_smooth3_staged(pp_ctx* ctx, const float* src, const float* add, float* dst, float* tmp1, float* tmp2,
@@ -638,6 +788,20 @@ int pp_discrete_gaussian_f32(pp_ctx* ctx, const float* in, float* out, const int
     if (rc) return rc;
   }
   const size_t N = pp_nvox(size);
+  // small radii on a volume with whole 16-byte strips per row: one kernel, z, y, x in one sweep (k_gauss3_zyx; in != out there)
+  int rmax = taps[0].r > taps[1].r ? taps[0].r : taps[1].r;
+  if (taps[2].r > rmax) rmax = taps[2].r;
+  bool fused = rmax <= 4 && d.nx % 4 == 0 && d.nx >= 8 && in != out && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  if (const char* e = getenv("PP_GAUSS3")) fused = fused && atoi(e) != 0;   // (0: the three separable launches, for A/B runs)
+  if (fused) {
+    pp_prof_scope ps(ctx, "k_gauss3_zyx");
+    switch (rmax < 1 ? 1 : rmax) {
+      case 1: return launch_gauss3<1>(ctx, in, out, d, taps);
+      case 2: return launch_gauss3<2>(ctx, in, out, d, taps);
+      case 3: return launch_gauss3<3>(ctx, in, out, d, taps);
+      default: return launch_gauss3<4>(ctx, in, out, d, taps);
+    }
+  }
   int rc = pp_reserve(ctx, 2 * pp_align_up(N * sizeof(float), 256));
   if (rc) return rc;
   pp_carver cv{ctx->ws, 0};

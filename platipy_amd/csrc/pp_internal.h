@@ -207,6 +207,28 @@ struct pp_taps_small {
 
 __device__ __forceinline__ int pp_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Value of the previous / next lane of the wavefront (DPP wave_shr:1 / wave_shl:1, a VALU move: no LDS crossbar trip).
+// Lane 0 / lane 63 keep their own value.  Every lane of the wavefront must execute the call.
+#ifndef PP_B_XDPP
+#define PP_B_XDPP 1
+#endif
+__device__ __forceinline__ float pp_lane_prev(float v) {
+#if PP_B_XDPP
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x138, 0xf, 0xf, false));
+#else
+  return __shfl_up(v, 1);
+#endif
+}
+__device__ __forceinline__ float pp_lane_next(float v) {
+#if PP_B_XDPP
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x130, 0xf, 0xf, false));
+#else
+  return __shfl_down(v, 1);
+#endif
+}
+
 // The value, opaque to the optimiser at this point (an empty asm with the value as a read-write VGPR operand): what is
 // derived from it afterwards is computed where it is used instead of being hoisted out of the enclosing loop.  For
 // rarely-taken paths whose hoisted per-lane predicates (two scalar registers each) would otherwise be held -- and

@@ -780,3 +780,23 @@ def test_recursive_gaussian_single_sweep_equals_two_sweeps(backend, monkeypatch)
     assert diff.max() <= 2e-6 and (diff > 0).mean() < 1e-3, (diff.max(), (diff > 0).mean())
     want = O.recursive_gaussian_vec(O.Vol(f.astype(np.float64), spacing, origin), sigma).arr
     np.testing.assert_allclose(out[""], want, rtol=0, atol=3e-6)
+
+
+@pytest.mark.parametrize("shape", [(9, 21, 72), (20, 37, 136), (5, 16, 8), (33, 18, 64)])
+def test_fused_discrete_gaussian_equals_the_three_passes(backend, shape, monkeypatch):
+    """Round 4: DiscreteGaussian with radii <= 4 on rows of whole 16-byte strips runs as ONE kernel (k_gauss3_zyx: z pass in a
+    register window, y pass through an LDS tile, x pass by DPP lane shifts) instead of three launches over the volume.  Same
+    fmaf chains in the same order on fp32 intermediates: bit-identical to the separable passes (PP_GAUSS3=0), for equal and
+    unequal radii per axis, tiles that overhang the volume, z-chunks, and volumes narrower than the rim."""
+    spacing = (1.0, 1.3, 2.0)
+    img = (phantom(shape, seed=11) + 300.0 * np.random.default_rng(5).standard_normal(shape)).astype(np.float32)
+    size = (shape[2], shape[1], shape[0])
+    for var in ((1.0, 1.0, 1.0), (4.0, 4.0, 4.0), (0.3, 2.5, 9.0), (2.25, 0.8, 30.0)):
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("PP_GAUSS3", mode)
+            o = backend.empty(shape)
+            backend.ctx.discrete_gaussian(backend.dev(img), o, size, spacing, var, 0.01, 32, True)
+            out[mode] = backend.host(o).copy()
+        np.testing.assert_array_equal(out["0"], out["1"])
+        assert np.abs(out["1"] - img).max() > 1.0

@@ -34,7 +34,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_sha16  # noqa: E402  (the capture is tied to the kernel sources it was taken of)
 
-raw = md.replace("gpurun_out/r2/", "profiles/round2_").replace("gpurun_out/r3final/", "profiles/round3_")
+raw = md.replace("gpurun_out/r2/", "profiles/round2_").replace("gpurun_out/r3final/", "profiles/round3_").replace("gpurun_out/r4final/", "profiles/round4_")
 out = {"commit": commit, "kernel_source_sha16": kernel_source_sha16(), "size": [nx, ny, nz], "raw": raw, "calibration": cal,
        "fetch_factor": ff, "write_factor": fw, "hbm_bytes_per_launch": {}, "fetch_bytes_per_launch": {}, "write_bytes_per_launch": {},
        "tcc_hit_rate": {}}
