@@ -79,7 +79,8 @@ __device__ __forceinline__ float pp_esm_axis(float fm, float fp, float mc, float
   const bool um = !lo && (mm != SENT);
   // (mp - mm) h, (mp - mc) / sp, (mc - mm) / sp or 0, as one difference: an unusable side falls back to the centre value
   const float hi_v = up ? mp : mc, lo_v = um ? mm : mc;
-  const float wg = (hi_v - lo_v) * ((up && um) ? h : inv_sp);
+  const float su = up ? h : inv_sp;                 // (up && um) ? h : inv_sp as two selects on fresh compare masks (see pp_esm_voxel)
+  const float wg = (hi_v - lo_v) * (um ? su : inv_sp);
   const float fg = (lo || hi) ? 0.0f : (fp - fm) * h;
   return fg + wg;
 }
@@ -99,7 +100,15 @@ __device__ __forceinline__ pp_esm_out pp_esm_voxel(const pp_esm_consts& K, float
   const float speed = fc - mc;
   const float g2 = gx * gx + gy * gy + gz * gz;
   const float denom = g2 + speed * speed * K.inv_norm;
-  const bool live = mapped && !(fabsf(speed) < K.intensity_thr) && !(denom < K.denom_thr);
+  // live = mapped && !(|speed| < intensity_thr) && !(denom < denom_thr), formed so that the mask the four selects below read
+  // comes from ONE vector compare: a voxel that fails one of the first two tests carries -inf in place of its denominator
+  // (-inf < denom_thr holds for any threshold, so the voxel is not live).  Written as three conditions joined by &&, the
+  // compiler combined the compare masks on the scalar unit into VCC, and a v_cndmask reading a VCC that the SCALAR unit wrote
+  // last costs ~22 cycles against ~3.5 behind a vector compare (tools/probes/valu_rate.hip, kinds 15 / 18 / 22): ~35 such
+  // selects per wavefront and plane in kernel A (profiles/round4_vcc_selects.md).
+  float gate = (fabsf(speed) < K.intensity_thr) ? -__builtin_inff() : denom;
+  if constexpr (!MAPPED) gate = (mc != FLT_MAX) ? gate : -__builtin_inff();
+  const bool live = !(gate < K.denom_thr);
   const float factor = live ? 2.0f * speed * __builtin_amdgcn_rcpf(denom) : 0.0f;   // v_rcp_f32: 1 ulp
   pp_esm_out o;
   o.ux = live ? factor * gx : 0.0f;

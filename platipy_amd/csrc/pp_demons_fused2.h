@@ -875,7 +875,8 @@ __device__ __forceinline__ float pp_esm_axis_data(float fm, float fp, float mc, 
   const float h = 0.5f * inv_sp;
   const bool up = (mp != FLT_MAX), um = (mm != FLT_MAX);
   const float hi_v = up ? mp : mc, lo_v = um ? mm : mc;
-  const float wg = (hi_v - lo_v) * ((up && um) ? h : inv_sp);
+  const float su = up ? h : inv_sp;                 // (up && um) ? h : inv_sp as two selects on fresh compare masks (see pp_esm_voxel)
+  const float wg = (hi_v - lo_v) * (um ? su : inv_sp);
   const float fg = (fp - fm) * hf;
   return fg + wg;
 }

@@ -14,6 +14,8 @@ Deviations, all deliberate and visible:
     one direction, so this is the same computation -- and the field is rotated back to physical (LPS)
     components at the end.  (ITK's behaviour for this case could not be checked: parity unpinned.)
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -104,7 +106,8 @@ class HipDemonsFilter:
     # ANOTHER filter is about to run on the same context (its Execute resolves this one's first).
     def _resolve(self):
         ctx, self._pending = self._pending, None
-        if ctx is not None and getattr(ctx, "_demons_owner", None) is self:
+        owner_ref = getattr(ctx, "_demons_owner", None) if ctx is not None else None
+        if owner_ref is not None and owner_ref() is self:
             ctx._demons_owner = None
             history = ctx.demons_history()
             self._stats = _IterationView(len(history), *history[-1]) if history else None
@@ -148,7 +151,11 @@ class HipDemonsFilter:
         p.max_kernel_width = self._max_kernel_width
         p.variant = self._variant
         field = torch.empty((3,) + f.shape, dtype=torch.float32, device=ft.device)
-        owner = getattr(ctx, "_demons_owner", None)
+        # (the context remembers the filter whose measurements it still holds through a WEAK reference: once that filter is
+        # gone nobody can ask for them, and reading them back -- a stream synchronisation in front of this Execute, 0.9 ms of
+        # host stall at the start of every registration after the first -- would be for nothing)
+        owner_ref = getattr(ctx, "_demons_owner", None)
+        owner = owner_ref() if owner_ref is not None else None
         if owner is not None and owner is not self:
             owner._resolve()
         self._pending = None
@@ -168,7 +175,7 @@ class HipDemonsFilter:
                 for fn in self._commands:
                     fn()
         self._stats = final
-        ctx._demons_owner = self if lazy else None
+        ctx._demons_owner = weakref.ref(self) if lazy else None
         self._pending = ctx if lazy else None
         out = Image(field, f.spacing, f.origin, f.direction, True)
         return to_sitk(out) if wants_sitk else out

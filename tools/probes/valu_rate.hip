@@ -158,38 +158,49 @@ void run(const char* name, int n_per_iter, int cus, double ghz, float* out) {
   }
 }
 
-int main() {
+static float* g_out;
+static int g_cus;
+static double g_ghz;
+template <int KIND>
+void one(const char* name, int n_per_iter, int want) {
+  if (want >= 0 && want != KIND) return;
+  run<KIND>(name, n_per_iter, g_cus, g_ghz, g_out);
+  fflush(stdout);
+}
+
+// valu_rate [kind]: every kind, or one of them (run each new kind in its own process under `timeout`: a probe that hangs -- one
+// of the old kinds 8 / 9 / 14 did, and one of round 4's first mask-source kinds -- then costs seconds, not the GPU visit)
+int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
+  const int want = argc > 1 ? atoi(argv[1]) : -1;
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
-  const int cus = prop.multiProcessorCount;
-  const double ghz = prop.clockRate * 1e-6;
-  printf("device %s, %d CUs, clockRate %.3f GHz\n", prop.name, cus, ghz);
-  float* out;
-  CK(hipMalloc(&out, 4096));
-  run<0>("v_fma_f32", 16, cus, ghz, out);
-  run<1>("v_pk_fma_f32", 16, cus, ghz, out);
-  run<4>("v_mul_f32", 16, cus, ghz, out);
-  run<5>("v_pk_mul_f32", 16, cus, ghz, out);
-  run<10>("v_pk_add_f32", 16, cus, ghz, out);
-  run<2>("v_cndmask_b32 (vcc, undefined)", 16, cus, ghz, out);
-  run<6>("v_cmp + v_cndmask (sgpr)", 16, cus, ghz, out);
-  run<15>("v_cndmask_b32 (static vcc)", 16, cus, ghz, out);
-  run<17>("v_cmp vcc + s_nop 1 + cndmask", 16, cus, ghz, out);
-  run<18>("v_cmp vcc + cndmask (no nop)", 16, cus, ghz, out);
-  run<21>("s_not mask + cndmask (SALU-fresh)", 16, cus, ghz, out);
-  run<22>("cndmask, mask v_cmp'd once", 16, cus, ghz, out);
-  run<23>("v_cmp, 7 fma, cndmask", 16, cus, ghz, out);
-  run<24>("v_cmp + 7 cndmask on it", 16, cus, ghz, out);
-  run<26>("v_cndmask_b32 (exec)", 16, cus, ghz, out);
-  run<25>("v_fma_f32 with an SGPR operand", 16, cus, ghz, out);
-  run<16>("v_fma_f32 + s_nop 0", 16, cus, ghz, out);
-  run<20>("v_fma_f32 + s_nop 1", 16, cus, ghz, out);
-  run<3>("v_mov_b32_dpp wave_shr:1", 16, cus, ghz, out);
-  run<7>("v_rcp_f32", 16, cus, ghz, out);
-  run<11>("v_max_f32", 16, cus, ghz, out);
-  run<12>("v_floor_f32", 16, cus, ghz, out);
-  run<13>("v_add_u32", 16, cus, ghz, out);
-  // (kinds 8, 9 and 14 -- dependent chain, VALU + SALU pairs, 24-bit multiply -- are not run: one of them does not finish
-  // within minutes on MI355X and the round's GPU budget has better uses)
+  g_cus = prop.multiProcessorCount;
+  g_ghz = prop.clockRate * 1e-6;
+  if (want < 0) printf("device %s, %d CUs, clockRate %.3f GHz\n", prop.name, g_cus, g_ghz);
+  CK(hipMalloc(&g_out, 4096));
+  one<0>("v_fma_f32", 16, want);
+  one<1>("v_pk_fma_f32", 16, want);
+  one<4>("v_mul_f32", 16, want);
+  one<5>("v_pk_mul_f32", 16, want);
+  one<10>("v_pk_add_f32", 16, want);
+  one<2>("v_cndmask_b32 (vcc, undefined)", 16, want);
+  one<6>("v_cmp + v_cndmask (sgpr)", 16, want);
+  one<15>("v_cndmask_b32 (static vcc)", 16, want);
+  one<17>("v_cmp vcc + s_nop 1 + cndmask", 16, want);
+  one<18>("v_cmp vcc + cndmask (no nop)", 16, want);
+  one<21>("s_not mask + cndmask (SALU-fresh)", 16, want);
+  one<22>("cndmask, mask v_cmp'd once", 16, want);
+  one<23>("v_cmp, 7 fma, cndmask", 16, want);
+  one<24>("v_cmp + 7 cndmask on it", 16, want);
+  one<26>("v_cndmask_b32 (exec)", 16, want);
+  one<25>("v_fma_f32 with an SGPR operand", 16, want);
+  one<16>("v_fma_f32 + s_nop 0", 16, want);
+  one<20>("v_fma_f32 + s_nop 1", 16, want);
+  one<3>("v_mov_b32_dpp wave_shr:1", 16, want);
+  one<7>("v_rcp_f32", 16, want);
+  one<11>("v_max_f32", 16, want);
+  one<12>("v_floor_f32", 16, want);
+  one<13>("v_add_u32", 16, want);
   return 0;
 }
