@@ -622,6 +622,13 @@ int pp_conv_axis(pp_ctx* ctx, int axis, const float* in, const float* add, float
 // output is bit-identical to the three passes (tests/test_kernels.py).  Rim voxels outside the volume repeat the clamped
 // INPUT voxel; the z pass acts on each (x, y) column alone, so that is the z-filtered edge value the staged y pass would
 // have clamped to, and likewise for x after y (ZeroFluxNeumann on every intermediate).
+// Resource over the first 2^31 bytes only: a lane whose per-lane offset is FIR_OOB (= 2^31) is outside it and the hardware
+// drops its store -- the lane mask of a store without a branch around it (same device as the fused demons kernels' PP_OOB).
+constexpr unsigned FIR_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fir_rsrc_first_2g(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)FIR_OOB, 0x00020000);
+}
+
 template <int R>
 struct gauss3_taps {
   float wz[2 * R + 1], wy[2 * R + 1], wx[2 * R + 1];
@@ -655,9 +662,11 @@ __global__ void __launch_bounds__(512) k_gauss3_zyx(const float* __restrict__ in
 #pragma unroll
   for (int i = 0; i < 4; ++i) jm |= (unsigned)(pp_clampi(xs + i, 0, d.nx - 1) - xl) << (2 * i);
   const size_t g_in = (size_t)yc * d.nx + xl;
-  auto load = [&](int q, float (&v)[4]) {
+  auto fetch = [&](int q) -> float4 {   // the raw strip of plane q (clamped in z): every lane loads, lanes without a strip re-read strip 0
     q = q < 0 ? 0 : (q > d.nz - 1 ? d.nz - 1 : q);
-    const float4 r = *reinterpret_cast<const float4*>(in + (size_t)q * sz + g_in);
+    return *reinterpret_cast<const float4*>(in + (size_t)q * sz + g_in);
+  };
+  auto place = [&](const float4& r, float (&v)[4]) {
     if (jm == 0xE4u) {
       v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
     } else {   // strips that leave the volume in x: every position takes its clamped voxel
@@ -675,25 +684,49 @@ __global__ void __launch_bounds__(512) k_gauss3_zyx(const float* __restrict__ in
   const bool ys_live = riw < RPW && oy < TY;
   const int xo = tx0 + 4 * (sxo - 1), yo = ty0 + oy;
   const bool st_live = ys_live && sxo >= 1 && sxo <= SPR - 2 && xo < d.nx && yo < d.ny;   // (nx % 4 == 0: whole strips)
-  const size_t g_out = (size_t)yo * d.nx + xo;
+  // the store's lane mask travels in its offset (FIR_OOB: dropped by the hardware), so that every wave issues it on every
+  // step: with the store inside `if (st_live)` the wait for the plane requested a step ahead is emitted as vmcnt(0) and also
+  // sits out the store's acknowledgement (the demons kernels' MASK instances, pp_demons_fused2.h)
+  const __amdgpu_buffer_rsrc_t r_out = fir_rsrc_first_2g(out);
+  const unsigned g_out4 = st_live ? (unsigned)(((size_t)yo * d.nx + xo) * 4u) : FIR_OOB;
+  const unsigned sz4 = (unsigned)(sz * 4u);
 
   float win[W][4];
 #pragma unroll
   for (int k = 0; k < W; ++k)
 #pragma unroll
     for (int i = 0; i < 4; ++i) win[k][i] = 0.0f;
-  if (zs_live) {
+  {
+    float4 raw[W - 1];
 #pragma unroll
-    for (int k = 1; k < W; ++k) load(z0 - R + k - 1, win[k]);   // slots 1 .. W-1: planes z0-R .. z0+R-1
+    for (int k = 1; k < W; ++k) raw[k - 1] = fetch(z0 - R + k - 1);   // all in flight together
+#pragma unroll
+    for (int k = 1; k < W; ++k) place(raw[k - 1], win[k]);            // slots 1 .. W-1: planes z0-R .. z0+R-1
+  }
+  float4 ahead = fetch(z0 + R);   // the plane the first step appends; every step requests the next one before it computes
+  {
+    // A store that stores nothing (every lane out of range), issued behind that load: the loop body is [wait for `ahead`,
+    // request the next plane, ..., store], so on the way round exactly one store is younger than the load waited for -- with
+    // the same picture on the way in, the compiler's wait is vmcnt(1) at both and never drains the output store.
+    typedef unsigned pp_u4 __attribute__((vector_size(16)));
+    const pp_u4 nothing = {0u, 0u, 0u, 0u};
+    __builtin_amdgcn_raw_buffer_store_b128(nothing, r_out, FIR_OOB, 0u, 0);
   }
   for (int z = z0; z < z1; ++z) {
     float* const tb = tile[(z - z0) & 1];
-    if (zs_live) {
+    {
 #pragma unroll
       for (int k = 0; k < W - 1; ++k)
 #pragma unroll
         for (int i = 0; i < 4; ++i) win[k][i] = win[k + 1][i];
-      load(z + R, win[W - 1]);
+      float4 cur = ahead;
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+v"(cur.x), "+v"(cur.y), "+v"(cur.z), "+v"(cur.w));   // (the wait for the strip sits HERE, in straight-line code with an exact count -- not inside place()'s lane-divergent branches)
+#endif
+      ahead = fetch(z + 1 + R);   // (no branch around the load either)
+      place(cur, win[W - 1]);
+    }
+    if (zs_live) {
       float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int k = 0; k < W; ++k)
@@ -723,7 +756,7 @@ __global__ void __launch_bounds__(512) k_gauss3_zyx(const float* __restrict__ in
       c[4 + i] = own[i];
       c[8 + i] = pp_lane_next(own[i]);
     }
-    if (st_live) {
+    {
       float o[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -732,7 +765,11 @@ __global__ void __launch_bounds__(512) k_gauss3_zyx(const float* __restrict__ in
         for (int k = 0; k < W; ++k) acc = fmaf(taps.wx[k], c[4 + j - R + k], acc);
         o[j] = acc;
       }
-      *reinterpret_cast<float4*>(out + (size_t)z * sz + g_out) = make_float4(o[0], o[1], o[2], o[3]);
+      typedef unsigned pp_u4 __attribute__((vector_size(16)));
+      pp_u4 w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = __builtin_bit_cast(unsigned, o[j]);
+      __builtin_amdgcn_raw_buffer_store_b128(w, r_out, g_out4, (unsigned)z * sz4, 0);
     }
   }
 }
@@ -791,7 +828,8 @@ int pp_discrete_gaussian_f32(pp_ctx* ctx, const float* in, float* out, const int
   // small radii on a volume with whole 16-byte strips per row: one kernel, z, y, x in one sweep (k_gauss3_zyx; in != out there)
   int rmax = taps[0].r > taps[1].r ? taps[0].r : taps[1].r;
   if (taps[2].r > rmax) rmax = taps[2].r;
-  bool fused = rmax <= 4 && d.nx % 4 == 0 && d.nx >= 8 && in != out && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  bool fused = rmax <= 4 && d.nx % 4 == 0 && d.nx >= 8 && in != out && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
+               N * sizeof(float) < ((size_t)1 << 31);   // (the output goes through a 2^31-byte buffer resource)
   if (const char* e = getenv("PP_GAUSS3")) fused = fused && atoi(e) != 0;   // (0: the three separable launches, for A/B runs)
   if (fused) {
     pp_prof_scope ps(ctx, "k_gauss3_zyx");

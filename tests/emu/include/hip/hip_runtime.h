@@ -185,6 +185,11 @@ static inline void __builtin_amdgcn_raw_buffer_store_b64(hipemu_u2 v, __amdgpu_b
   if (hipemu_buf_in_range(r, voff, 8)) memcpy(r.base + (size_t)voff + soff, &v, 8);
 }
 
+typedef unsigned hipemu_u4 __attribute__((vector_size(16)));
+static inline void __builtin_amdgcn_raw_buffer_store_b128(hipemu_u4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int) {
+  if (hipemu_buf_in_range(r, voff, 16)) memcpy(r.base + (size_t)voff + soff, &v, 16);
+}
+
 // Wavefront shuffle (64 lanes).  Every live lane of the WAVEFRONT must reach the call: the value is exchanged through a
 // per-block table between two wavefront rendezvous.
 namespace hipemu { extern thread_local double t_shfl[1024]; }
