@@ -157,12 +157,12 @@ int pp_mail_take(pp_ctx* ctx, int writer, int n, unsigned long long seq, double*
 int pp_ticket(pp_ctx* ctx, unsigned** out) {
   if (!ctx->ticket) {
     void* p = nullptr;
-    if (hipMalloc(&p, 1024) != hipSuccess || !p) {
+    if (hipMalloc(&p, 2048) != hipSuccess || !p) {   // 16 counters, 128 bytes apart
       (void)hipGetLastError();
       return pp_fail(ctx, PP_ERR_ALLOC, "ticket counter allocation failed");
     }
     ctx->ticket = static_cast<unsigned*>(p);
-    PP_HIP(ctx, hipMemsetAsync(ctx->ticket, 0, 1024, ctx->stream));
+    PP_HIP(ctx, hipMemsetAsync(ctx->ticket, 0, 2048, ctx->stream));
   }
   *out = ctx->ticket;
   return PP_OK;

@@ -389,9 +389,9 @@ __global__ void __launch_bounds__(NT) k_sum14_final(const double* __restrict__ p
 // latency (the sample lattice is 16 K .. 1 M points).  The host speculates the next few levels of the search
 // tree and evaluates all of their learning rates at once: blockIdx.y = candidate.  The last block of a candidate to
 // finish (device ticket per candidate) folds that candidate's per-block partial sums with a fixed tree, so a candidate's value does not depend on
-// which other candidates ride in the launch.  (ctx->ticket holds 256 counters; a chunk uses the one at chunk * TICKET_STRIDE.)
+// which other candidates ride in the launch.  (ctx->ticket holds 16 counters 128 bytes apart; a chunk uses the one at chunk * TICKET_STRIDE.)
 constexpr int PP_MAX_CAND = 16;
-constexpr unsigned TICKET_STRIDE = 32;   // counters of a launch's chunks sit 128 bytes apart (ctx->ticket holds 256 of them)
+constexpr unsigned TICKET_STRIDE = 32;   // counters sit 128 bytes apart (ctx->ticket holds 16 of them)
 struct mval_args {
   double Af[9], bf[3];
   double Am[PP_MAX_CAND][9], bm[PP_MAX_CAND][3];
@@ -600,6 +600,241 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
     }
   }
   if (threadIdx.x == 0) atomicExch(ticket + blockIdx.y * TICKET_STRIDE, 0u);   // (where the increments go, not a cached plain store)
+}
+
+// ---- line-search evaluations, second generation: a candidate is a LANE ---------------------------------------
+// k_metric_values walks a thread over its samples and, per sample, over the candidates: on the sparse lattices of the
+// pipelines (every 8th voxel of the full-resolution moving image along x) the 64 lanes of a gather then address 16-64
+// different cache lines, and the kernel runs at the vector cache's line-lookup rate (measured: 75 us for 16 candidates on
+// 524 K samples, ~64 clocks per gather instruction).  Here lane = 16 * slot + candidate: a wavefront holds FOUR
+// consecutive samples x 16 candidates, the candidates of a sample land within a voxel or two of each other and the four
+// samples in neighbouring 32-byte sectors, so a gather instruction touches a handful of lines; a thread keeps NV
+// accumulators instead of 16 * NV (no 64 KB reduction tile: the block is bound by registers, not LDS), and a candidate's
+// samples are spread over 16 x as many threads (shorter dependent chains on the small lattices).
+// Sum order of a candidate: a thread adds its samples e0 + slot, e0 + 16 + slot, ... in increasing order; the four slots
+// of a wavefront combine as (s0 + s1) + (s2 + s3), the four wavefronts as (w0 + w1) + (w2 + w3); the last block to finish folds the
+// blocks' rows with the fixed tree of k_metric_values.  The layout does not depend on the number of candidates, so a
+// candidate's value does not depend on its companions.
+// pp_trilinear_pairs with 32-bit offsets built from 24-bit multiplies (full rate; a 64-bit offset costs four quarter-rate
+// multiplies per row pair).  Caller guarantees ny * nz < 2^24, nx < 2^24, nx >= 2 and fewer than 2^31 voxels.  Same lerps.
+__device__ __forceinline__ float mv_trilinear_pairs32(const float* __restrict__ im, int nx, int ny, int nz, int bx, float fx, int by,
+                                                      float fy, int bz, float fz) {
+  int x0, x1, y0, y1, z0, z1;
+  float wx, wy, wz;
+  pp_axis_setup(bx, fx, nx, x0, x1, wx);
+  pp_axis_setup(by, fy, ny, y0, y1, wy);
+  pp_axis_setup(bz, fz, nz, z0, z1, wz);
+  const bool xlast = x0 > nx - 2;
+  const unsigned xs = (unsigned)(xlast ? nx - 2 : x0);
+  const unsigned r00 = __umul24(__umul24((unsigned)z0, (unsigned)ny) + (unsigned)y0, (unsigned)nx) + xs;
+  const unsigned dy = y1 > y0 ? (unsigned)nx : 0u, dz = z1 > z0 ? __umul24((unsigned)nx, (unsigned)ny) : 0u;
+  const pp_pair<float> p00 = *reinterpret_cast<const pp_pair<float>*>(im + r00);
+  const pp_pair<float> p10 = *reinterpret_cast<const pp_pair<float>*>(im + (r00 + dy));
+  const pp_pair<float> p01 = *reinterpret_cast<const pp_pair<float>*>(im + (r00 + dz));
+  const pp_pair<float> p11 = *reinterpret_cast<const pp_pair<float>*>(im + (r00 + dz + dy));
+  const float a000 = xlast ? p00.y : p00.x, a100 = p00.y;
+  const float a010 = xlast ? p10.y : p10.x, a110 = p10.y;
+  const float a001 = xlast ? p01.y : p01.x, a101 = p01.y;
+  const float a011 = xlast ? p11.y : p11.x, a111 = p11.y;
+  const float v00 = a000 + (a100 - a000) * wx;
+  const float v10 = a010 + (a110 - a010) * wx;
+  const float v01 = a001 + (a101 - a001) * wx;
+  const float v11 = a011 + (a111 - a011) * wx;
+  const float v0 = v00 + (v10 - v00) * wy;
+  const float v1 = v01 + (v11 - v01) * wy;
+  return v0 + (v1 - v0) * wz;
+}
+
+constexpr int MV_CL = 16;              // lanes per sample
+constexpr int MV_SLOTS = NT / MV_CL;   // samples a block handles side by side
+template <int MODE>
+__global__ void __launch_bounds__(NT) k_metric_values_lanes(const float* __restrict__ F, pp_dims df, const float* __restrict__ M, pp_dims dm,
+                                                            const uint8_t* __restrict__ fmask, const uint8_t* __restrict__ mmask,
+                                                            mval_args a, int ncand, int spt /* samples per thread */,
+                                                            double* partials /* [grid.x][16 * NV] */, unsigned* __restrict__ ticket,
+                                                            void* mailbox, unsigned long long seq, const float* __restrict__ fsamp) {
+  constexpr int NV = MODE == 0 ? 2 : 6;
+  constexpr int ROW = MV_CL * NV;
+  constexpr int CPW = MODE == 0 ? 16 : 8;   // candidates per mailbox writer (64 entries each)
+  constexpr int NPARTS = NT / ROW;          // the last block folds the rows in NPARTS interleaved parts
+  __shared__ double red[(NT / 64 > NPARTS ? NT / 64 : NPARTS) * ROW];
+  __shared__ int is_last;
+  const int c = (int)threadIdx.x % MV_CL, slot = (int)threadIdx.x / MV_CL;
+  const bool live = c < ncand;
+  double A[9], b[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) A[k] = a.Am[live ? c : 0][k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) b[k] = a.bm[live ? c : 0][k];
+  double acc[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+  const size_t nvirt = (size_t)a.vsize[0] * a.vsize[1] * a.vsize[2];
+  const size_t nsamp = (nvirt + a.stride - 1) / a.stride;
+  const size_t e0 = (size_t)blockIdx.x * ((size_t)MV_SLOTS * spt) + slot;
+  // Lattice coordinates of this thread's first sample by division, of the following ones by adding the decomposed step
+  // (the samples of a thread are MV_SLOTS * stride raster positions apart): no division inside the loop.
+  unsigned px, py, pz, sx_, sy_, sz_;
+  {
+    const size_t lin0 = (e0 < nsamp ? e0 : nsamp - 1) * (size_t)a.stride, step = (size_t)MV_SLOTS * a.stride;
+    const size_t vx = (size_t)a.vsize[0], vy = (size_t)a.vsize[1];
+    if (nvirt < ((size_t)1 << 31) && step < ((size_t)1 << 31)) {   // (uniform; 32-bit divisions)
+      const unsigned l32 = (unsigned)lin0, s32 = (unsigned)step, vx32 = (unsigned)vx, vy32 = (unsigned)vy;
+      unsigned q = l32 / vx32;
+      px = l32 - q * vx32; py = q % vy32; pz = q / vy32;
+      q = s32 / vx32;
+      sx_ = s32 - q * vx32; sy_ = q % vy32; sz_ = q / vy32;
+    } else {
+      px = (unsigned)(lin0 % vx); py = (unsigned)((lin0 / vx) % vy); pz = (unsigned)(lin0 / (vx * vy));
+      sx_ = (unsigned)(step % vx); sy_ = (unsigned)((step / vx) % vy); sz_ = (unsigned)(step / (vx * vy));
+    }
+  }
+  const bool idx32 = dm.nx >= 2 && dm.nx < (1 << 24) && (size_t)dm.ny * dm.nz < ((size_t)1 << 24) &&
+                     (size_t)dm.nx * dm.ny * dm.nz < ((size_t)1 << 31);   // (uniform)
+  // Straight-line over groups of four samples: every sample forms a valid (clamped) address and gathers unconditionally,
+  // "inside / masked / beyond the lattice" only selects what is accumulated (adding 0.0 leaves the sums bit-identical) --
+  // so the sixteen gathers of a group are in flight together.
+  for (int i0 = 0; i0 < spt; i0 += 4) {
+    if (e0 + (size_t)i0 * MV_SLOTS - slot >= nsamp) break;   // (block-uniform: the whole group lies beyond the lattice)
+    double fd[4], md[4];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t eq = e0 + (size_t)(i0 + j) * MV_SLOTS;
+      ok[j] = live && (i0 + j < spt) && eq < nsamp;
+      const size_t e = eq < nsamp ? eq : nsamp - 1;
+      const double v[3] = {(double)px, (double)py, (double)pz};
+      {   // next sample of this thread (beyond the lattice the position is never used: ok[j] is false there)
+        px += sx_;
+        const bool cx = px >= (unsigned)a.vsize[0];
+        px -= cx ? (unsigned)a.vsize[0] : 0u;
+        py += sy_ + (cx ? 1u : 0u);
+        const bool cy = py >= (unsigned)a.vsize[1];
+        py -= cy ? (unsigned)a.vsize[1] : 0u;
+        pz += sz_ + (cy ? 1u : 0u);
+      }
+      if (fsamp) {   // (uniform) the fixed side of this sample was evaluated once for the level
+        const float fv = fsamp[e];
+        ok[j] = ok[j] && __builtin_bit_cast(unsigned, fv) != PP_FSAMP_INVALID;
+        fd[j] = fv;
+      } else {
+        double cf[3];
+        for (int r = 0; r < 3; ++r) cf[r] = a.Af[r * 3 + 0] * v[0] + a.Af[r * 3 + 1] * v[1] + a.Af[r * 3 + 2] * v[2] + a.bf[r];
+        int bf_[3] = {0, 0, 0};
+        float ff[3] = {0.0f, 0.0f, 0.0f};
+        bool okf = msq_locate(cf, df, bf_, ff);
+        if (okf && fmask) {
+          const int qx = (int)floor(cf[0] + 0.5), qy = (int)floor(cf[1] + 0.5), qz = (int)floor(cf[2] + 0.5);
+          okf = fmask[((size_t)qz * df.ny + qy) * df.nx + qx] != 0;
+        }
+        fd[j] = okf ? (double)msq_trilinear_pairs(F, df.nx, df.ny, df.nz, bf_[0], ff[0], bf_[1], ff[1], bf_[2], ff[2]) : 0.0;
+        ok[j] = ok[j] && okf;
+      }
+      double cm[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) cm[r] = A[r * 3 + 0] * v[0] + A[r * 3 + 1] * v[1] + A[r * 3 + 2] * v[2] + b[r];
+      const bool in = (cm[0] >= -0.5) & (cm[0] < dm.nx - 0.5) & (cm[1] >= -0.5) & (cm[1] < dm.ny - 0.5) & (cm[2] >= -0.5) &
+                      (cm[2] < dm.nz - 0.5);
+      ok[j] = ok[j] & in;
+      int bm_[3];
+      float fm[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double cc = in ? cm[r] : 0.0;
+        const double fl = floor(cc);
+        bm_[r] = (int)fl;
+        fm[r] = (float)(cc - fl);
+      }
+      if (mmask) {   // (uniform)
+        const int qx = in ? (int)floor(cm[0] + 0.5) : 0, qy = in ? (int)floor(cm[1] + 0.5) : 0, qz = in ? (int)floor(cm[2] + 0.5) : 0;
+        ok[j] = ok[j] & (mmask[((size_t)qz * dm.ny + qy) * dm.nx + qx] != 0);
+      }
+      md[j] = idx32      ? (double)mv_trilinear_pairs32(M, dm.nx, dm.ny, dm.nz, bm_[0], fm[0], bm_[1], fm[1], bm_[2], fm[2])
+              : dm.nx >= 2 ? (double)pp_trilinear_pairs(M, dm.nx, dm.ny, dm.nz, bm_[0], fm[0], bm_[1], fm[1], bm_[2], fm[2])
+                           : (double)msq_trilinear_pairs(M, dm.nx, dm.ny, dm.nz, bm_[0], fm[0], bm_[1], fm[1], bm_[2], fm[2]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (MODE == 0) {
+        const double diff = fd[j] - md[j];
+        acc[0] += ok[j] ? diff * diff : 0.0;
+        acc[1] += ok[j] ? 1.0 : 0.0;
+      } else {
+        acc[0] += ok[j] ? 1.0 : 0.0;
+        acc[1] += ok[j] ? fd[j] : 0.0;
+        acc[2] += ok[j] ? md[j] : 0.0;
+        acc[3] += ok[j] ? fd[j] * fd[j] : 0.0;
+        acc[4] += ok[j] ? md[j] * md[j] : 0.0;
+        acc[5] += ok[j] ? fd[j] * md[j] : 0.0;
+      }
+    }
+  }
+  // the four slots of a wavefront, then the four wavefronts
+  const int wave = (int)threadIdx.x / 64, lane = (int)threadIdx.x % 64;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double t = acc[k];
+    t += __shfl_xor(t, 16);
+    t += __shfl_xor(t, 32);
+    if (lane < MV_CL) red[wave * ROW + lane * NV + k] = t;
+  }
+  __syncthreads();
+  double* mine = partials + (size_t)blockIdx.x * ROW;
+  if ((int)threadIdx.x < ROW) {
+    const double t = (red[0 * ROW + threadIdx.x] + red[1 * ROW + threadIdx.x]) + (red[2 * ROW + threadIdx.x] + red[3 * ROW + threadIdx.x]);
+    // Rows cross XCDs inside one launch: 8-byte agent-scope atomics on both sides (write-through store, L1-bypassing load) are
+    // a complete hand-off on gfx950 -- no release / acquire fence, which would write back and invalidate the XCD's L2 once per
+    // BLOCK (~3.5 us each, serialised per XCD: what made a probe slower the more blocks it had).  The store only has to have
+    // left the wavefront before the block takes its ticket.
+    __hip_atomic_store(mine + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  }
+  __syncthreads();
+  // Two-level ticket: block b counts on counter b % G (blocks are dealt to the XCDs round-robin, so a counter's increments
+  // come from one XCD and the 1024 returning atomics of a launch do not queue on one word, ~11 ns each); the last block of
+  // a group counts on the top counter, the last of those folds.  Counters sit 128 bytes apart.
+  if (threadIdx.x == 0) {
+    const unsigned G = gridDim.x < 8u ? gridDim.x : 8u, g = blockIdx.x % G;
+    const unsigned members = (gridDim.x - g + G - 1u) / G;
+    int last = 0;
+    if (__hip_atomic_fetch_add(ticket + (1u + g) * TICKET_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
+      __hip_atomic_store(ticket + (1u + g) * TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1u;
+    }
+    is_last = last;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  {
+    const int col = (int)threadIdx.x % ROW, part = (int)threadIdx.x / ROW;
+    double p = 0.0;
+    // (sixteen rows requested before the first is added: one dependent L2-miss load per row made the fold the longest part of a
+    // probe -- ~0.24 us per row and part, 31 us of a 1024-block launch.  Same order of additions.)
+    if (part < NPARTS)
+      for (unsigned i = (unsigned)part; i < gridDim.x; i += NPARTS * 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const unsigned r = i + (unsigned)u * NPARTS;
+          v[u] = __hip_atomic_load(partials + (size_t)(r < gridDim.x ? r : i) * ROW + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v[u] = r < gridDim.x ? v[u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) p += v[u];
+      }
+    __syncthreads();   // (red still holds the block's own sums)
+    if (part < NPARTS) red[part * ROW + col] = p;
+    __syncthreads();
+    if ((int)threadIdx.x < ncand * NV) {
+      double tot = 0.0;
+      for (int q = 0; q < NPARTS; ++q) tot += red[q * ROW + threadIdx.x];
+      const int cand = (int)threadIdx.x / NV, f = (int)threadIdx.x % NV;
+      pp_mail_post(pp_mail_slot(mailbox, cand / CPW) + (cand % CPW) * NV + f, tot, seq);
+    }
+  }
+  if (threadIdx.x == 0) atomicExch(ticket, 0u);
 }
 
 
@@ -1082,6 +1317,48 @@ int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, con
   // Candidates per thread: 16 on big lattices (HBM/L2-bound: the candidates of a sample share cache lines; the straight-line
   // form of the kernel keeps several candidates' gathers in flight), 4 for batches of up to four and on small lattices
   // (latency-bound: spread the candidates over blocks).
+  const char* lanes_env = getenv("PP_METRIC_LANES");   // (0: the candidate-loop kernels, for A/B runs and the equality test)
+  if (!lanes_env || atoi(lanes_env) != 0) {
+    // Blocks: the small lattices are bound by the latency of one probe (a block's dependent gather rounds, then one ticket
+    // atomic per block, ~12 ns each, serialised), the large ones by throughput.  The cap depends on the lattice only.
+    unsigned nb_cap = nsamp < 20000 ? 128u : 1024u;   // (tools/r4/run16.sh: 128 x 128 x 64 lattice 24.2 / 15.4 / 11.3 / 11.9 / 13.7 ms per level at 256 .. 4096)
+    if (const char* e = getenv("PP_METRIC_BLOCKS")) nb_cap = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : nb_cap;
+    size_t spt = (nsamp + (size_t)MV_SLOTS * nb_cap - 1) / ((size_t)MV_SLOTS * nb_cap);
+    spt = (spt + 3) / 4 * 4;
+    PP_REQUIRE(ctx, spt < ((size_t)1 << 30), "metric values: sampling lattice too large");
+    const unsigned nb = (unsigned)((nsamp + (size_t)MV_SLOTS * spt - 1) / ((size_t)MV_SLOTS * spt));
+    const int nv = metric == 0 ? 2 : 6, cpw = metric == 0 ? 16 : 8;
+    int rc = pp_reserve(ctx, pp_align_up((size_t)nb * MV_CL * nv * sizeof(double), 256));
+    if (rc) return rc;
+    unsigned* ticket = nullptr;
+    rc = pp_ticket(ctx, &ticket);
+    if (rc) return rc;
+    double* partials = reinterpret_cast<double*>(ctx->ws);
+    char* mail = nullptr;
+    unsigned long long seq = 0;
+    rc = pp_mailbox(ctx, &mail, &seq);
+    if (rc) return rc;
+    const float* fsamp = nullptr;
+    rc = pp_fixed_samples(ctx, fixed, fsize, Af, bf, vsize, stride, fixed_mask, &fsamp);
+    if (rc) return rc;
+    if (metric == 0)
+      hipLaunchKernelGGL((k_metric_values_lanes<0>), dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a,
+                         ncand, (int)spt, partials, ticket, mail, seq, fsamp);
+    else
+      hipLaunchKernelGGL((k_metric_values_lanes<1>), dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a,
+                         ncand, (int)spt, partials, ticket, mail, seq, fsamp);
+    PP_LAUNCH_CHECK(ctx, "k_metric_values_lanes");
+    memset(result, 0, (size_t)ncand * 6 * sizeof(double));
+    for (int w = 0; w * cpw < ncand; ++w) {
+      const int k = ncand - w * cpw < cpw ? ncand - w * cpw : cpw;
+      double vals[PP_MAIL_ENTRIES];
+      rc = pp_mail_take(ctx, w, k * nv, seq, vals);
+      if (rc) return rc;
+      for (int j = 0; j < k; ++j)
+        for (int f = 0; f < nv; ++f) result[((size_t)w * cpw + j) * 6 + f] = vals[j * nv + f];
+    }
+    return PP_OK;
+  }
   constexpr int CH0 = 16, CH0S = 4, CH1 = 4;
   const bool small = metric == 0 && nsamp < 150000;
   const int ch = metric == 0 ? (small || ncand <= 4 ? CH0S : CH0) : CH1, nv = metric == 0 ? 2 : 6;

@@ -136,6 +136,8 @@ template <class T>
 static inline void __hip_atomic_store(T* p, T v, int /*order*/, int /*scope*/) {
   __atomic_store(p, &v, __ATOMIC_SEQ_CST);
 }
+template <class T>
+static inline T __hip_atomic_fetch_add(T* p, T v, int /*order*/, int /*scope*/) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 static inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
