@@ -616,39 +616,51 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
 // blocks' rows with the fixed tree of k_metric_values.  The layout does not depend on the number of candidates, so a
 // candidate's value does not depend on its companions.
 // pp_trilinear_pairs with 32-bit offsets built from 24-bit multiplies (full rate; a 64-bit offset costs four quarter-rate
-// multiplies per row pair).  Caller guarantees ny * nz < 2^24, nx < 2^24, nx >= 2 and fewer than 2^31 voxels.  Same lerps.
-__device__ __forceinline__ float mv_trilinear_pairs32(const float* __restrict__ im, int nx, int ny, int nz, int bx, float fx, int by,
-                                                      float fy, int bz, float fz) {
-  int x0, x1, y0, y1, z0, z1;
+// multiplies per row pair), split into "request the four row pairs" and "interpolate" so that a caller can have the pairs of
+// several samples in flight before it touches the first.  Caller guarantees ny * nz < 2^24, nx < 2^24, nx >= 2 and fewer
+// than 2^31 voxels.  Same lerps as pp_trilinear_pairs.
+struct mv_pairs {
+  pp_pair<float> p00, p10, p01, p11;
   float wx, wy, wz;
-  pp_axis_setup(bx, fx, nx, x0, x1, wx);
-  pp_axis_setup(by, fy, ny, y0, y1, wy);
-  pp_axis_setup(bz, fz, nz, z0, z1, wz);
-  const bool xlast = x0 > nx - 2;
-  const unsigned xs = (unsigned)(xlast ? nx - 2 : x0);
+  bool xlast;
+};
+__device__ __forceinline__ void mv_pairs32_issue(const float* __restrict__ im, int nx, int ny, int nz, int bx, float fx, int by, float fy,
+                                                 int bz, float fz, mv_pairs& g) {
+  int x0, x1, y0, y1, z0, z1;
+  pp_axis_setup(bx, fx, nx, x0, x1, g.wx);
+  pp_axis_setup(by, fy, ny, y0, y1, g.wy);
+  pp_axis_setup(bz, fz, nz, z0, z1, g.wz);
+  g.xlast = x0 > nx - 2;
+  const unsigned xs = (unsigned)(g.xlast ? nx - 2 : x0);
   const unsigned r00 = __umul24(__umul24((unsigned)z0, (unsigned)ny) + (unsigned)y0, (unsigned)nx) + xs;
   const unsigned dy = y1 > y0 ? (unsigned)nx : 0u, dz = z1 > z0 ? __umul24((unsigned)nx, (unsigned)ny) : 0u;
-  const pp_pair<float> p00 = *reinterpret_cast<const pp_pair<float>*>(im + r00);
-  const pp_pair<float> p10 = *reinterpret_cast<const pp_pair<float>*>(im + (r00 + dy));
-  const pp_pair<float> p01 = *reinterpret_cast<const pp_pair<float>*>(im + (r00 + dz));
-  const pp_pair<float> p11 = *reinterpret_cast<const pp_pair<float>*>(im + (r00 + dz + dy));
-  const float a000 = xlast ? p00.y : p00.x, a100 = p00.y;
-  const float a010 = xlast ? p10.y : p10.x, a110 = p10.y;
-  const float a001 = xlast ? p01.y : p01.x, a101 = p01.y;
-  const float a011 = xlast ? p11.y : p11.x, a111 = p11.y;
-  const float v00 = a000 + (a100 - a000) * wx;
-  const float v10 = a010 + (a110 - a010) * wx;
-  const float v01 = a001 + (a101 - a001) * wx;
-  const float v11 = a011 + (a111 - a011) * wx;
-  const float v0 = v00 + (v10 - v00) * wy;
-  const float v1 = v01 + (v11 - v01) * wy;
-  return v0 + (v1 - v0) * wz;
+  g.p00 = *reinterpret_cast<const pp_pair<float>*>(im + r00);
+  g.p10 = *reinterpret_cast<const pp_pair<float>*>(im + (r00 + dy));
+  g.p01 = *reinterpret_cast<const pp_pair<float>*>(im + (r00 + dz));
+  g.p11 = *reinterpret_cast<const pp_pair<float>*>(im + (r00 + dz + dy));
 }
+__device__ __forceinline__ float mv_pairs32_finish(const mv_pairs& g) {
+  const float a000 = g.xlast ? g.p00.y : g.p00.x, a100 = g.p00.y;
+  const float a010 = g.xlast ? g.p10.y : g.p10.x, a110 = g.p10.y;
+  const float a001 = g.xlast ? g.p01.y : g.p01.x, a101 = g.p01.y;
+  const float a011 = g.xlast ? g.p11.y : g.p11.x, a111 = g.p11.y;
+  const float v00 = a000 + (a100 - a000) * g.wx;
+  const float v10 = a010 + (a110 - a010) * g.wx;
+  const float v01 = a001 + (a101 - a001) * g.wx;
+  const float v11 = a011 + (a111 - a011) * g.wx;
+  const float v0 = v00 + (v10 - v00) * g.wy;
+  const float v1 = v01 + (v11 - v01) * g.wy;
+  return v0 + (v1 - v0) * g.wz;
+}
+template <bool B> struct mv_flag { static constexpr bool value = B; };
 
 constexpr int MV_CL = 16;              // lanes per sample
 constexpr int MV_SLOTS = NT / MV_CL;   // samples a block handles side by side
 template <int MODE>
-__global__ void __launch_bounds__(NT) k_metric_values_lanes(const float* __restrict__ F, pp_dims df, const float* __restrict__ M, pp_dims dm,
+#ifndef PP_MV_WAVES
+#define PP_MV_WAVES 1
+#endif
+__global__ void __launch_bounds__(NT, PP_MV_WAVES) k_metric_values_lanes(const float* __restrict__ F, pp_dims df, const float* __restrict__ M, pp_dims dm,
                                                             const uint8_t* __restrict__ fmask, const uint8_t* __restrict__ mmask,
                                                             mval_args a, int ncand, int spt /* samples per thread */,
                                                             double* partials /* [grid.x][16 * NV] */, unsigned* __restrict__ ticket,
@@ -691,82 +703,128 @@ __global__ void __launch_bounds__(NT) k_metric_values_lanes(const float* __restr
   }
   const bool idx32 = dm.nx >= 2 && dm.nx < (1 << 24) && (size_t)dm.ny * dm.nz < ((size_t)1 << 24) &&
                      (size_t)dm.nx * dm.ny * dm.nz < ((size_t)1 << 31);   // (uniform)
-  // Straight-line over groups of four samples: every sample forms a valid (clamped) address and gathers unconditionally,
-  // "inside / masked / beyond the lattice" only selects what is accumulated (adding 0.0 leaves the sums bit-identical) --
-  // so the sixteen gathers of a group are in flight together.
-  for (int i0 = 0; i0 < spt; i0 += 4) {
-    if (e0 + (size_t)i0 * MV_SLOTS - slot >= nsamp) break;   // (block-uniform: the whole group lies beyond the lattice)
-    double fd[4], md[4];
-    bool ok[4];
+  // Groups of four samples.  Every sample forms a valid (clamped) address and gathers unconditionally; "inside / masked /
+  // beyond the lattice" only selects what is accumulated (adding 0.0 leaves the sums bit-identical).  FAST (fixed samples
+  // cached for the level, 32-bit offsets -- what the optimiser runs): the body has no branch at all, the sixteen row pairs of
+  // a group are requested before the first is interpolated.  (With the three uniform decisions INSIDE the body the compiler
+  // waited for each sample's pairs before it requested the next: 32 dependent round trips per thread, 45 us of a 57 us probe.)
+  // Lanes without a candidate skip the walk -- a launch costs what its candidates cost -- and join the reduction with zeros.
+  auto walk = [&](auto fast_tag, auto mask_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value, MASKED = decltype(mask_tag)::value;
+    for (int i0 = 0; i0 < spt; i0 += 4) {
+      if (e0 + (size_t)i0 * MV_SLOTS - slot >= nsamp) break;   // (block-uniform: the whole group lies beyond the lattice)
+      double fd[4], md[4];
+      bool ok[4];
+      mv_pairs g[4];
+      float fv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      unsigned mk[4] = {1u, 1u, 1u, 1u};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const size_t eq = e0 + (size_t)(i0 + j) * MV_SLOTS;
-      ok[j] = live && (i0 + j < spt) && eq < nsamp;
-      const size_t e = eq < nsamp ? eq : nsamp - 1;
-      const double v[3] = {(double)px, (double)py, (double)pz};
-      {   // next sample of this thread (beyond the lattice the position is never used: ok[j] is false there)
-        px += sx_;
-        const bool cx = px >= (unsigned)a.vsize[0];
-        px -= cx ? (unsigned)a.vsize[0] : 0u;
-        py += sy_ + (cx ? 1u : 0u);
-        const bool cy = py >= (unsigned)a.vsize[1];
-        py -= cy ? (unsigned)a.vsize[1] : 0u;
-        pz += sz_ + (cy ? 1u : 0u);
-      }
-      if (fsamp) {   // (uniform) the fixed side of this sample was evaluated once for the level
-        const float fv = fsamp[e];
-        ok[j] = ok[j] && __builtin_bit_cast(unsigned, fv) != PP_FSAMP_INVALID;
-        fd[j] = fv;
-      } else {
-        double cf[3];
-        for (int r = 0; r < 3; ++r) cf[r] = a.Af[r * 3 + 0] * v[0] + a.Af[r * 3 + 1] * v[1] + a.Af[r * 3 + 2] * v[2] + a.bf[r];
-        int bf_[3] = {0, 0, 0};
-        float ff[3] = {0.0f, 0.0f, 0.0f};
-        bool okf = msq_locate(cf, df, bf_, ff);
-        if (okf && fmask) {
-          const int qx = (int)floor(cf[0] + 0.5), qy = (int)floor(cf[1] + 0.5), qz = (int)floor(cf[2] + 0.5);
-          okf = fmask[((size_t)qz * df.ny + qy) * df.nx + qx] != 0;
+      for (int j = 0; j < 4; ++j) {
+        const size_t eq = e0 + (size_t)(i0 + j) * MV_SLOTS;
+        ok[j] = (i0 + j < spt) && eq < nsamp;
+        const size_t e = eq < nsamp ? eq : nsamp - 1;
+        const double v[3] = {(double)px, (double)py, (double)pz};
+        {   // next sample of this thread (beyond the lattice the position is never used: ok[j] is false there)
+          px += sx_;
+          const bool cx = px >= (unsigned)a.vsize[0];
+          px -= cx ? (unsigned)a.vsize[0] : 0u;
+          py += sy_ + (cx ? 1u : 0u);
+          const bool cy = py >= (unsigned)a.vsize[1];
+          py -= cy ? (unsigned)a.vsize[1] : 0u;
+          pz += sz_ + (cy ? 1u : 0u);
         }
-        fd[j] = okf ? (double)msq_trilinear_pairs(F, df.nx, df.ny, df.nz, bf_[0], ff[0], bf_[1], ff[1], bf_[2], ff[2]) : 0.0;
-        ok[j] = ok[j] && okf;
-      }
-      double cm[3];
+        if (FAST) {            // the fixed side of this sample was evaluated once for the level (looked at with the pairs, below)
+          fv[j] = fsamp[e];
+        } else if (fsamp) {
+          const float f1 = fsamp[e];
+          ok[j] = ok[j] && __builtin_bit_cast(unsigned, f1) != PP_FSAMP_INVALID;
+          fd[j] = f1;
+        } else {
+          double cf[3];
+          for (int r = 0; r < 3; ++r) cf[r] = a.Af[r * 3 + 0] * v[0] + a.Af[r * 3 + 1] * v[1] + a.Af[r * 3 + 2] * v[2] + a.bf[r];
+          int bf_[3] = {0, 0, 0};
+          float ff[3] = {0.0f, 0.0f, 0.0f};
+          bool okf = msq_locate(cf, df, bf_, ff);
+          if (okf && fmask) {
+            const int qx = (int)floor(cf[0] + 0.5), qy = (int)floor(cf[1] + 0.5), qz = (int)floor(cf[2] + 0.5);
+            okf = fmask[((size_t)qz * df.ny + qy) * df.nx + qx] != 0;
+          }
+          fd[j] = okf ? (double)msq_trilinear_pairs(F, df.nx, df.ny, df.nz, bf_[0], ff[0], bf_[1], ff[1], bf_[2], ff[2]) : 0.0;
+          ok[j] = ok[j] && okf;
+        }
+        double cm[3];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) cm[r] = A[r * 3 + 0] * v[0] + A[r * 3 + 1] * v[1] + A[r * 3 + 2] * v[2] + b[r];
-      const bool in = (cm[0] >= -0.5) & (cm[0] < dm.nx - 0.5) & (cm[1] >= -0.5) & (cm[1] < dm.ny - 0.5) & (cm[2] >= -0.5) &
-                      (cm[2] < dm.nz - 0.5);
-      ok[j] = ok[j] & in;
-      int bm_[3];
-      float fm[3];
+        for (int r = 0; r < 3; ++r) cm[r] = A[r * 3 + 0] * v[0] + A[r * 3 + 1] * v[1] + A[r * 3 + 2] * v[2] + b[r];
+        const bool in = (cm[0] >= -0.5) & (cm[0] < dm.nx - 0.5) & (cm[1] >= -0.5) & (cm[1] < dm.ny - 0.5) & (cm[2] >= -0.5) &
+                        (cm[2] < dm.nz - 0.5);
+        ok[j] = ok[j] & in;
+        int bm_[3];
+        float fm[3];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const double cc = in ? cm[r] : 0.0;
-        const double fl = floor(cc);
-        bm_[r] = (int)fl;
-        fm[r] = (float)(cc - fl);
+        for (int r = 0; r < 3; ++r) {
+          const double cc = in ? cm[r] : 0.0;
+          const double fl = floor(cc);
+          bm_[r] = (int)fl;
+          fm[r] = (float)(cc - fl);
+        }
+        if (MASKED) {
+          const int qx = in ? (int)floor(cm[0] + 0.5) : 0, qy = in ? (int)floor(cm[1] + 0.5) : 0, qz = in ? (int)floor(cm[2] + 0.5) : 0;
+          mk[j] = mmask[((size_t)qz * dm.ny + qy) * dm.nx + qx];
+          if (!FAST) ok[j] = ok[j] & (mk[j] != 0);
+        }
+        if (FAST)
+          mv_pairs32_issue(M, dm.nx, dm.ny, dm.nz, bm_[0], fm[0], bm_[1], fm[1], bm_[2], fm[2], g[j]);
+        else
+          md[j] = dm.nx >= 2 ? (double)pp_trilinear_pairs(M, dm.nx, dm.ny, dm.nz, bm_[0], fm[0], bm_[1], fm[1], bm_[2], fm[2])
+                             : (double)msq_trilinear_pairs(M, dm.nx, dm.ny, dm.nz, bm_[0], fm[0], bm_[1], fm[1], bm_[2], fm[2]);
       }
-      if (mmask) {   // (uniform)
-        const int qx = in ? (int)floor(cm[0] + 0.5) : 0, qy = in ? (int)floor(cm[1] + 0.5) : 0, qz = in ? (int)floor(cm[2] + 0.5) : 0;
-        ok[j] = ok[j] & (mmask[((size_t)qz * dm.ny + qy) * dm.nx + qx] != 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (FAST) {
+        // Pin "all sixteen requests, then the interpolations": instruction selection is free to emit a sample's (pure)
+        // interpolation arithmetic right under its own loads -- one sample in flight per thread -- and a scheduling barrier alone
+        // does not order arithmetic.  The empty statements consume and re-define the loaded registers, so every
+        // interpolation depends on a statement that follows every load.
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j += 2)
+          asm volatile("" : "+v"(g[j].p00.x), "+v"(g[j].p00.y), "+v"(g[j].p10.x), "+v"(g[j].p10.y), "+v"(g[j].p01.x), "+v"(g[j].p01.y),
+                            "+v"(g[j].p11.x), "+v"(g[j].p11.y), "+v"(g[j + 1].p00.x), "+v"(g[j + 1].p00.y), "+v"(g[j + 1].p10.x),
+                            "+v"(g[j + 1].p10.y), "+v"(g[j + 1].p01.x), "+v"(g[j + 1].p01.y), "+v"(g[j + 1].p11.x), "+v"(g[j + 1].p11.y),
+                            "+v"(fv[j]), "+v"(fv[j + 1]), "+v"(mk[j]), "+v"(mk[j + 1]));
       }
-      md[j] = idx32      ? (double)mv_trilinear_pairs32(M, dm.nx, dm.ny, dm.nz, bm_[0], fm[0], bm_[1], fm[1], bm_[2], fm[2])
-              : dm.nx >= 2 ? (double)pp_trilinear_pairs(M, dm.nx, dm.ny, dm.nz, bm_[0], fm[0], bm_[1], fm[1], bm_[2], fm[2])
-                           : (double)msq_trilinear_pairs(M, dm.nx, dm.ny, dm.nz, bm_[0], fm[0], bm_[1], fm[1], bm_[2], fm[2]);
+#endif
+      if (FAST) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ok[j] = ok[j] && __builtin_bit_cast(unsigned, fv[j]) != PP_FSAMP_INVALID && mk[j] != 0;
+          fd[j] = fv[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (FAST) md[j] = (double)mv_pairs32_finish(g[j]);
+        if (MODE == 0) {
+          const double diff = fd[j] - md[j];
+          acc[0] += ok[j] ? diff * diff : 0.0;
+          acc[1] += ok[j] ? 1.0 : 0.0;
+        } else {
+          acc[0] += ok[j] ? 1.0 : 0.0;
+          acc[1] += ok[j] ? fd[j] : 0.0;
+          acc[2] += ok[j] ? md[j] : 0.0;
+          acc[3] += ok[j] ? fd[j] * fd[j] : 0.0;
+          acc[4] += ok[j] ? md[j] * md[j] : 0.0;
+          acc[5] += ok[j] ? fd[j] * md[j] : 0.0;
+        }
+      }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (MODE == 0) {
-        const double diff = fd[j] - md[j];
-        acc[0] += ok[j] ? diff * diff : 0.0;
-        acc[1] += ok[j] ? 1.0 : 0.0;
-      } else {
-        acc[0] += ok[j] ? 1.0 : 0.0;
-        acc[1] += ok[j] ? fd[j] : 0.0;
-        acc[2] += ok[j] ? md[j] : 0.0;
-        acc[3] += ok[j] ? fd[j] * fd[j] : 0.0;
-        acc[4] += ok[j] ? md[j] * md[j] : 0.0;
-        acc[5] += ok[j] ? fd[j] * md[j] : 0.0;
-      }
+  };
+  if (live) {
+    if (fsamp && idx32) {
+      if (mmask) walk(mv_flag<true>{}, mv_flag<true>{});
+      else walk(mv_flag<true>{}, mv_flag<false>{});
+    } else {
+      if (mmask) walk(mv_flag<false>{}, mv_flag<true>{});
+      else walk(mv_flag<false>{}, mv_flag<false>{});
     }
   }
   // the four slots of a wavefront, then the four wavefronts

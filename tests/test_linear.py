@@ -82,6 +82,36 @@ def test_metric_values_batch_matches_single_evaluations(backend):
     assert alone[0, 0] == both[3, 0] and alone[0, 1] == both[3, 1]
 
 
+def test_lane_probe_kernel_equals_the_loop_kernel(backend, monkeypatch):
+    """The line-search probes' second generation (a candidate per lane, pairs of four samples in flight) sums the same
+    per-sample terms as the candidate-loop kernels in another order: every count equal, every sum to 1e-12, for 1..16
+    candidates, both metrics, with and without a moving mask, and twice the same bits."""
+    rng = np.random.default_rng(1)
+    F = (100 * rng.standard_normal((20, 24, 28))).astype(np.float32)
+    M = (100 * rng.standard_normal((22, 25, 26))).astype(np.float32)
+    mm = (rng.random((22, 25, 26)) > 0.2).astype(np.uint8)
+    dF, dM, dmm = backend.dev(F), backend.dev(M), backend.dev(mm)
+    fs, ms_ = (28, 24, 20), (26, 25, 22)
+    Af, bf = np.eye(3) * 2.0, np.array([0.5, 0.5, 0.5])
+    Am0 = np.array([[1.9137, 0.1071, 0.0031], [-0.0813, 2.0519, 0.0207], [0.0109, 0.0043, 2.1011]])
+    bm0 = np.array([0.7123, -0.4057, 0.9131])
+    Ams = [Am0 + 0.01 * rng.standard_normal((3, 3)) for _ in range(16)]
+    bms = [bm0 + 0.5 * rng.standard_normal(3) for _ in range(16)]
+    vsize, stride = (13, 11, 9), 2
+    for metric in (0, 1):
+        for mask in (None, dmm):
+            for n in (1, 3, 4, 7, 16):
+                monkeypatch.setenv("PP_METRIC_LANES", "0")
+                loop = backend.ctx.metric_values_affine(metric, dF, fs, dM, ms_, Af.ravel(), bf, Ams[:n], bms[:n], vsize, stride, moving_mask=mask)
+                monkeypatch.setenv("PP_METRIC_LANES", "1")
+                lanes = backend.ctx.metric_values_affine(metric, dF, fs, dM, ms_, Af.ravel(), bf, Ams[:n], bms[:n], vsize, stride, moving_mask=mask)
+                again = backend.ctx.metric_values_affine(metric, dF, fs, dM, ms_, Af.ravel(), bf, Ams[:n], bms[:n], vsize, stride, moving_mask=mask)
+                count = 1 if metric == 0 else 0
+                assert np.array_equal(lanes[:, count], loop[:, count]) and lanes[:, count].max() > 100
+                np.testing.assert_allclose(lanes, loop, rtol=1e-12, atol=0)
+                assert np.array_equal(lanes, again)
+
+
 def test_speculative_golden_section_is_the_sequential_search():
     """Batched probing of the search tree takes the same probes in the same order and returns the same learning
     rate as itk's sequential golden-section search (depth 1), for well- and ill-behaved objectives."""

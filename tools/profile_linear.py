@@ -13,6 +13,8 @@ from platipy_amd import _lib  # noqa: E402
 from platipy_amd.projects.multiatlas import MUTLIATLAS_SETTINGS_DEFAULTS, QUICK_REG_SETTINGS  # noqa: E402
 from platipy_amd.registration import linear  # noqa: E402
 
+if len(sys.argv) > 1:      # another build of the library (A/B measurements)
+    _lib._DLL = _lib.load(os.path.abspath(sys.argv[1]))
 ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
 fixed, moving, _ = synth_pair(ctx, (256, 512, 512), (1.0, 1.0, 1.0), 1234, torch.device("cuda", 0), warp_seed=2000)
 fi, mi = pa.Image(fixed, (1.0, 1.0, 1.0)), pa.Image(moving, (1.0, 1.0, 1.0))
