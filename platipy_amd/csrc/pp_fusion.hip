@@ -896,6 +896,225 @@ __global__ void __launch_bounds__(NT, PP_MV_WAVES) k_metric_values_lanes(const f
 }
 
 
+// ---- metric value + gradient, second generation: one launch ---------------------------------------------------
+// k_metric_affine + k_sum14_final with the lessons of the probe kernel: a thread's samples go four (two for the 42
+// correlation sums) at a time with every corner request issued before the first is used, the block folds through wavefront shuffles
+// instead of forty barrier rounds, and the last block to finish (two-level ticket, fence-free rows) folds the rows and
+// posts the sums itself: no second launch.  Per-sample terms and accumulators are those of k_metric_affine; a thread adds
+// its samples in increasing order, lanes combine by mg_wave_sum16's fixed tree, wavefronts as (w0 + w1) + (w2 + w3),
+// block rows by the fixed interleaved fold of the probe kernel.
+// Sum of sixteen per-lane doubles over the 64 lanes of a wavefront by "transpose and add": at xor distance 32 a lane keeps
+// eight of its values and hands the other eight to its partner, at 16 four, at 8 two, at 4 one -- then two plain butterfly
+// steps.  17 exchanges instead of 16 x 6; lanes 4 q .. 4 q + 3 end up holding the total of value q.  A fixed tree.
+__device__ __forceinline__ double mg_wave_sum16(double* v, int lane) {
+#pragma unroll
+  for (int half = 8, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
+    const bool up = (lane & bit) != 0;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+      const double keep = up ? v[i + half] : v[i], send = up ? v[i] : v[i + half];
+      v[i] = keep + __shfl_xor(send, bit);
+    }
+  }
+  double t = v[0];
+  t += __shfl_xor(t, 2);
+  t += __shfl_xor(t, 1);
+  return t;
+}
+
+struct mg_corners {
+  float a000, a100, a010, a110, a001, a101, a011, a111;
+  float wx, wy, wz;
+};
+template <int MODE>
+__global__ void __launch_bounds__(NT) k_metric_grad(const float* __restrict__ F, pp_dims df, const float* __restrict__ M, pp_dims dm,
+                                                    const uint8_t* __restrict__ fmask, const uint8_t* __restrict__ mmask, msq_args a,
+                                                    double* partials /* [grid][NACC] */, unsigned* __restrict__ ticket, void* mailbox,
+                                                    unsigned long long seq, const float* __restrict__ fsamp) {
+  constexpr int NACC = MODE == 0 ? 14 : 42;
+  constexpr int G = MODE == 0 ? 4 : 2;          // samples in flight per thread
+  constexpr int NPARTS = NT / NACC;
+  __shared__ double red[(NT / 64 > NPARTS ? NT / 64 : NPARTS) * NACC];
+  __shared__ int is_last;
+  double acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+  const size_t nvirt = (size_t)a.vsize[0] * a.vsize[1] * a.vsize[2];
+  const size_t nsamp = (nvirt + a.stride - 1) / a.stride;
+  const size_t tid = (size_t)blockIdx.x * NT + threadIdx.x, nthr = (size_t)gridDim.x * NT;
+  const bool small = nvirt < ((size_t)1 << 31);
+  const size_t sy = dm.nx, sz = (size_t)dm.nx * dm.ny;
+  for (size_t e0 = tid; e0 < nsamp; e0 += nthr * G) {
+    mg_corners g[G];
+    double v[G][3];
+    float fval[G];
+    bool ok[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const size_t eq = e0 + (size_t)j * nthr;
+      ok[j] = eq < nsamp;
+      const size_t e = ok[j] ? eq : nsamp - 1;
+      const size_t lin = e * (size_t)a.stride;
+      if (small) {   // (uniform; 32-bit divisions)
+        const unsigned l32 = (unsigned)lin, vx = (unsigned)a.vsize[0], vy = (unsigned)a.vsize[1];
+        const unsigned q = l32 / vx;
+        v[j][0] = (double)(l32 - q * vx);
+        v[j][1] = (double)(q % vy);
+        v[j][2] = (double)(q / vy);
+      } else {
+        v[j][0] = (double)(lin % a.vsize[0]);
+        v[j][1] = (double)((lin / a.vsize[0]) % a.vsize[1]);
+        v[j][2] = (double)(lin / ((size_t)a.vsize[0] * a.vsize[1]));
+      }
+      double cf[3], cm[3];
+      for (int r = 0; r < 3; ++r) {
+        cf[r] = a.Af[r * 3 + 0] * v[j][0] + a.Af[r * 3 + 1] * v[j][1] + a.Af[r * 3 + 2] * v[j][2] + a.bf[r];
+        cm[r] = a.Am[r * 3 + 0] * v[j][0] + a.Am[r * 3 + 1] * v[j][1] + a.Am[r * 3 + 2] * v[j][2] + a.bm[r];
+      }
+      int bf_[3] = {0, 0, 0}, bm_[3] = {0, 0, 0};
+      float ff[3] = {0.0f, 0.0f, 0.0f}, fm[3] = {0.0f, 0.0f, 0.0f};
+      fval[j] = 0.0f;
+      if (fsamp) {   // (uniform) the fixed side of this sample was evaluated once for the level (same arithmetic)
+        fval[j] = fsamp[e];
+        ok[j] = ok[j] && __builtin_bit_cast(unsigned, fval[j]) != PP_FSAMP_INVALID;
+      } else {
+        bool okf = msq_locate(cf, df, bf_, ff);
+        if (okf && fmask) {
+          const int qx = (int)floor(cf[0] + 0.5), qy = (int)floor(cf[1] + 0.5), qz = (int)floor(cf[2] + 0.5);
+          okf = fmask[((size_t)qz * df.ny + qy) * df.nx + qx] != 0;
+        }
+        if (okf) fval[j] = pp_trilinear(F, df.nx, df.ny, df.nz, bf_[0], ff[0], bf_[1], ff[1], bf_[2], ff[2]);
+        ok[j] = ok[j] && okf;
+      }
+      const bool in = msq_locate(cm, dm, bm_, fm);   // (outside: base 0, fraction 0 -- a valid address, nothing accumulated)
+      ok[j] = ok[j] && in;
+      if (mmask) {   // (uniform)
+        const int qx = in ? (int)floor(cm[0] + 0.5) : 0, qy = in ? (int)floor(cm[1] + 0.5) : 0, qz = in ? (int)floor(cm[2] + 0.5) : 0;
+        ok[j] = ok[j] && mmask[((size_t)qz * dm.ny + qy) * dm.nx + qx] != 0;
+      }
+      int x0, x1, y0, y1, z0, z1;
+      pp_axis_setup(bm_[0], fm[0], dm.nx, x0, x1, g[j].wx);
+      pp_axis_setup(bm_[1], fm[1], dm.ny, y0, y1, g[j].wy);
+      pp_axis_setup(bm_[2], fm[2], dm.nz, z0, z1, g[j].wz);
+      g[j].a000 = M[z0 * sz + y0 * sy + x0]; g[j].a100 = M[z0 * sz + y0 * sy + x1];
+      g[j].a010 = M[z0 * sz + y1 * sy + x0]; g[j].a110 = M[z0 * sz + y1 * sy + x1];
+      g[j].a001 = M[z1 * sz + y0 * sy + x0]; g[j].a101 = M[z1 * sz + y0 * sy + x1];
+      g[j].a011 = M[z1 * sz + y1 * sy + x0]; g[j].a111 = M[z1 * sz + y1 * sy + x1];
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // every corner request before the first interpolation (see k_metric_values_lanes)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < G; j += 2)
+      asm volatile("" : "+v"(g[j].a000), "+v"(g[j].a100), "+v"(g[j].a010), "+v"(g[j].a110), "+v"(g[j].a001), "+v"(g[j].a101),
+                        "+v"(g[j].a011), "+v"(g[j].a111), "+v"(g[j + 1].a000), "+v"(g[j + 1].a100), "+v"(g[j + 1].a010),
+                        "+v"(g[j + 1].a110), "+v"(g[j + 1].a001), "+v"(g[j + 1].a101), "+v"(g[j + 1].a011), "+v"(g[j + 1].a111));
+#endif
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const mg_corners& c = g[j];
+      const float v00 = c.a000 + (c.a100 - c.a000) * c.wx, v10 = c.a010 + (c.a110 - c.a010) * c.wx;
+      const float v01 = c.a001 + (c.a101 - c.a001) * c.wx, v11 = c.a011 + (c.a111 - c.a011) * c.wx;
+      const float v0 = v00 + (v10 - v00) * c.wy, v1 = v01 + (v11 - v01) * c.wy;
+      const float m = v0 + (v1 - v0) * c.wz;
+      const float gx0 = (c.a100 - c.a000) + ((c.a110 - c.a010) - (c.a100 - c.a000)) * c.wy;
+      const float gx1 = (c.a101 - c.a001) + ((c.a111 - c.a011) - (c.a101 - c.a001)) * c.wy;
+      const float gx = gx0 + (gx1 - gx0) * c.wz;
+      const float gy = (v10 - v00) + ((v11 - v01) - (v10 - v00)) * c.wz;
+      const float gz = v1 - v0;
+      const double w = ok[j] ? 1.0 : 0.0;   // (a rejected sample adds exact zeros)
+      if (MODE == 0) {
+        const double diff = ok[j] ? (double)fval[j] - (double)m : 0.0;
+        acc[0] += diff * diff;
+        acc[1] += w;
+        const double sc = -2.0 * diff;
+        const double gg[3] = {sc * gx, sc * gy, sc * gz};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          acc[2 + r * 3 + 0] += gg[r] * v[j][0];
+          acc[2 + r * 3 + 1] += gg[r] * v[j][1];
+          acc[2 + r * 3 + 2] += gg[r] * v[j][2];
+          acc[11 + r] += gg[r];
+        }
+      } else {
+        const double fd = ok[j] ? (double)fval[j] : 0.0, md = ok[j] ? (double)m : 0.0;
+        acc[0] += w;
+        acc[1] += fd;
+        acc[2] += md;
+        acc[3] += fd * fd;
+        acc[4] += md * md;
+        acc[5] += fd * md;
+        const double gg[3] = {w * gx, w * gy, w * gz};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const double t = gg[r] * (q < 3 ? v[j][q < 3 ? q : 0] : 1.0);
+            const int slot = q < 3 ? r * 3 + q : 9 + r;
+            acc[6 + slot] += t;
+            acc[18 + slot] += fd * t;
+            acc[30 + slot] += md * t;
+          }
+      }
+    }
+  }
+  const int wave = (int)threadIdx.x / 64, lane = (int)threadIdx.x % 64;
+#pragma unroll
+  for (int k0 = 0; k0 < NACC; k0 += 16) {
+    double v16[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v16[i] = k0 + i < NACC ? acc[k0 + i] : 0.0;
+    const double t = mg_wave_sum16(v16, lane);
+    if ((lane & 3) == 0 && k0 + (lane >> 2) < NACC) red[wave * NACC + k0 + (lane >> 2)] = t;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < NACC) {
+    const double t = (red[0 * NACC + threadIdx.x] + red[1 * NACC + threadIdx.x]) + (red[2 * NACC + threadIdx.x] + red[3 * NACC + threadIdx.x]);
+    __hip_atomic_store(partials + (size_t)blockIdx.x * NACC + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned GR = gridDim.x < 8u ? gridDim.x : 8u, gi = blockIdx.x % GR;
+    const unsigned members = (gridDim.x - gi + GR - 1u) / GR;
+    int last = 0;
+    if (__hip_atomic_fetch_add(ticket + (1u + gi) * TICKET_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
+      __hip_atomic_store(ticket + (1u + gi) * TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GR - 1u;
+    }
+    is_last = last;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  {
+    const int col = (int)threadIdx.x % NACC, part = (int)threadIdx.x / NACC;
+    double p = 0.0;
+    if (part < NPARTS)
+      for (unsigned i = (unsigned)part; i < gridDim.x; i += NPARTS * 16) {
+        double t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const unsigned r = i + (unsigned)u * NPARTS;
+          t[u] = __hip_atomic_load(partials + (size_t)(r < gridDim.x ? r : i) * NACC + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          t[u] = r < gridDim.x ? t[u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) p += t[u];
+      }
+    __syncthreads();
+    if (part < NPARTS) red[part * NACC + col] = p;
+    __syncthreads();
+    if ((int)threadIdx.x < NACC) {
+      double tot = 0.0;
+      for (int q = 0; q < NPARTS; ++q) tot += red[q * NACC + threadIdx.x];
+      pp_mail_post(pp_mail_slot(mailbox, 0) + threadIdx.x, tot, seq);
+    }
+  }
+  if (threadIdx.x == 0) atomicExch(ticket, 0u);
+}
+
 // ---- mutual-information metrics (linear.py:145-148: mattes_mi, joint_hist_mi) -------------------------------
 // Two passes over the same sample lattice as the metrics above.  Pass 1 builds the joint intensity histogram of the
 // sample pairs: per block in LDS, in 64-bit fixed point (2^-32 units) so that the sum is associative and the result
@@ -1315,6 +1534,24 @@ static int metric_affine(pp_ctx* ctx, int mode, const float* fixed, const int fs
   const float* fsamp = nullptr;
   rc = pp_fixed_samples(ctx, fixed, fsize, Af, bf, vsize, stride, fixed_mask, &fsamp);
   if (rc) return rc;
+  const char* one_env = getenv("PP_METRIC_GRAD_ONE_LAUNCH");   // (0: k_metric_affine + k_sum14_final, for A/B runs and the equality test)
+  if (!one_env || atoi(one_env) != 0) {
+    unsigned* ticket = nullptr;
+    rc = pp_ticket(ctx, &ticket);
+    if (rc) return rc;
+    char* mail1 = nullptr;
+    unsigned long long seq1 = 0;
+    rc = pp_mailbox(ctx, &mail1, &seq1);
+    if (rc) return rc;
+    if (mode == 0)
+      hipLaunchKernelGGL((k_metric_grad<0>), dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, partials,
+                         ticket, mail1, seq1, fsamp);
+    else
+      hipLaunchKernelGGL((k_metric_grad<1>), dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, partials,
+                         ticket, mail1, seq1, fsamp);
+    PP_LAUNCH_CHECK(ctx, "k_metric_grad");
+    return pp_mail_take(ctx, 0, nacc, seq1, result);
+  }
   if (mode == 0)
     hipLaunchKernelGGL((k_metric_affine<0>), dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, partials,
                        fsamp);
