@@ -411,18 +411,30 @@ struct fused_args {
   int per_xcd;      // ceil(gx * gy * gz / 8)
   int streaming;    // generation 2: non-temporal output stores (volumes far beyond the infinity cache)
   int masked;       // generation 2: the MASK kernels (even rows, a whole field under 2^31 bytes; pp_demons_fused2.h)
+  // generation 2, mixed tile shapes (SH == 2): region 0 = gx x gy tiles of 64 x 16 from x = 0, region 1 = gx2 x gy2 tiles of
+  // 32 x 32 from x = x2_off (the columns a 64-wide tile would overhang by half or more); gx2 == 0: one shape only
+  int gx2, gy2, x2_off;
   pp_taps_small wx, wy, wz;
 };
 
-// Tile of this block (see the grid note above); false for the few surplus blocks of the last XCD run.
-__device__ __forceinline__ bool fused_tile(const fused_args& a, int TX, int TY, int& tx0, int& ty0, int& z0, unsigned& rank) {
+// Tile of this block (see the grid note above); false for the few surplus blocks of the last XCD run.  `region`: which
+// of the two tile regions of a mixed launch the caller's tile shape belongs to (0 when there is one shape).
+__device__ __forceinline__ unsigned fused_rank(const fused_args& a) {
   const unsigned b = blockIdx.x;
-  const unsigned j = b >> 3;
-  rank = (b & 7u) * (unsigned)a.per_xcd + j;
-  const unsigned T = (unsigned)a.gx * a.gy * a.gz;
-  if (rank >= T) return false;
-  const unsigned tx = rank % a.gx, ty = (rank / a.gx) % a.gy, tz = rank / ((unsigned)a.gx * a.gy);
-  tx0 = (int)tx * TX;
+  return (b & 7u) * (unsigned)a.per_xcd + (b >> 3);
+}
+__device__ __forceinline__ int fused_region(const fused_args& a) {   // (surplus blocks report region 0 and fail fused_tile there)
+  const unsigned n1 = (unsigned)a.gx * a.gy * a.gz, n2 = (unsigned)a.gx2 * a.gy2 * a.gz, rank = fused_rank(a);
+  return rank >= n1 && rank < n1 + n2 ? 1 : 0;
+}
+__device__ __forceinline__ bool fused_tile(const fused_args& a, int TX, int TY, int& tx0, int& ty0, int& z0, unsigned& rank, int region = 0) {
+  rank = fused_rank(a);
+  const unsigned n1 = (unsigned)a.gx * a.gy * a.gz, n2 = (unsigned)a.gx2 * a.gy2 * a.gz;
+  if (rank >= n1 + n2) return false;
+  if ((region != 0) != (rank >= n1)) return false;
+  const unsigned r = region ? rank - n1 : rank, gx = region ? (unsigned)a.gx2 : (unsigned)a.gx, gy = region ? (unsigned)a.gy2 : (unsigned)a.gy;
+  const unsigned tx = r % gx, ty = (r / gx) % gy, tz = r / (gx * gy);
+  tx0 = (region ? a.x2_off : 0) + (int)tx * TX;
   ty0 = (int)ty * TY;
   z0 = (int)tz * a.zchunk;
   return true;
@@ -821,7 +833,7 @@ void small_taps(const pp_taps& t, int R, pp_taps_small* s) {
 
 // z-chunk length: long chunks amortise the 2R (+3 image) halo planes, but the launch should fill the
 // chip a whole number of times.  `slots` = resident blocks of the slower kernel (256 CUs x blocks/CU).
-int fused_zchunk(const pp_dims& d, int slots, int TX, int TY, double* cost_out = nullptr, char kernel = 0) {
+int fused_zchunk(const pp_dims& d, int slots, int TX, int TY, double* cost_out = nullptr, char kernel = 0, int tiles_override = 0) {
   const char* e = kernel == 'A' ? getenv("PP_FUSED_ZCHUNK_A") : (kernel == 'B' ? getenv("PP_FUSED_ZCHUNK_B") : nullptr);
   if (!e) e = getenv("PP_FUSED_ZCHUNK");
   if (e) {
@@ -831,7 +843,7 @@ int fused_zchunk(const pp_dims& d, int slots, int TX, int TY, double* cost_out =
       return v < d.nz ? v : d.nz;
     }
   }
-  const int tiles = ((d.nx + TX - 1) / TX) * ((d.ny + TY - 1) / TY);
+  const int tiles = tiles_override > 0 ? tiles_override : ((d.nx + TX - 1) / TX) * ((d.ny + TY - 1) / TY);
   // Small grids (the coarse pyramid levels) cannot fill the chip either way and are bound by the latency of one
   // block's march instead, ~2.5 us per plane: short chunks (down to 2 planes + halo) cut that chain.
   int best = d.nz < 32 ? d.nz : 32;
@@ -963,33 +975,37 @@ int launch_warp(pp_ctx* ctx, int sh, const float* D, const float* Us, const floa
 
 template <int R>
 int occ_force2(int sh) {   // (cached: the answer depends on the kernel binary only, and the query costs ~10 us per call)
-  static int cache[2] = {0, 0};
-  if (cache[sh ? 1 : 0]) return cache[sh ? 1 : 0];
+  static int cache[3] = {0, 0, 0};
+  sh = sh < 0 ? 0 : (sh > 2 ? 2 : sh);
+  if (cache[sh]) return cache[sh];
   int a = 0;
 #ifdef PP_MINI
   const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(0, true, true, PP_MINI_MASK), 512, 0);
 #else
-  const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(1, true, false, true), 512, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(0, true, false, true), 512, 0);
+  const hipError_t e = sh == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(2, true, false, true), 512, 0)
+                       : sh  ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(1, true, false, true), 512, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_A2_KERNEL(0, true, false, true), 512, 0);
 #endif
   if (e != hipSuccess) a = 2;
   (void)hipGetLastError();
-  return cache[sh ? 1 : 0] = (a < 1 ? 1 : a);
+  return cache[sh] = (a < 1 ? 1 : a);
 }
 template <int R>
 int occ_warp2(int sh) {   // (cached: the answer depends on the kernel binary only, and the query costs ~10 us per call)
-  static int cache[2] = {0, 0};
-  if (cache[sh ? 1 : 0]) return cache[sh ? 1 : 0];
+  static int cache[3] = {0, 0, 0};
+  sh = sh < 0 ? 0 : (sh > 2 ? 2 : sh);
+  if (cache[sh]) return cache[sh];
   int a = 0;
 #ifdef PP_MINI
   const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(0, true, true, PP_MINI_MASK), 512, 0);
 #else
-  const hipError_t e = sh ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(1, true, false, true), 512, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(0, true, false, true), 512, 0);
+  const hipError_t e = sh == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(2, true, false, true), 512, 0)
+                       : sh  ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(1, true, false, true), 512, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, PP_B2_KERNEL(0, true, false, true), 512, 0);
 #endif
   if (e != hipSuccess) a = 2;
   (void)hipGetLastError();
-  return cache[sh ? 1 : 0] = (a < 1 ? 1 : a);
+  return cache[sh] = (a < 1 ? 1 : a);
 }
 template <int R>
 int launch_force2(pp_ctx* ctx, int sh, bool sum, const float* F, const float* Mw_in, const float* D, float* Us, const fused_args& fu,
@@ -1003,14 +1019,14 @@ int launch_force2(pp_ctx* ctx, int sh, bool sum, const float* F, const float* Mw
   PP_GO(0, true, true, PP_MINI_MASK);
 #else
   if (!sum) {   // (PP_FUSED_SUM=0, a measurement path: cached stores only)
-    if (sh) PP_GO(1, false, false, false); else PP_GO(0, false, false, false);
+    if (sh == 2) PP_GO(2, false, false, false); else if (sh) PP_GO(1, false, false, false); else PP_GO(0, false, false, false);
   } else if (fu.masked) {
-    if (fu.streaming) { if (sh) PP_GO(1, true, true, true); else PP_GO(0, true, true, true); }
-    else { if (sh) PP_GO(1, true, false, true); else PP_GO(0, true, false, true); }
+    if (fu.streaming) { if (sh == 2) PP_GO(2, true, true, true); else if (sh) PP_GO(1, true, true, true); else PP_GO(0, true, true, true); }
+    else { if (sh == 2) PP_GO(2, true, false, true); else if (sh) PP_GO(1, true, false, true); else PP_GO(0, true, false, true); }
   } else if (fu.streaming) {
-    if (sh) PP_GO(1, true, true, false); else PP_GO(0, true, true, false);
+    if (sh == 2) PP_GO(2, true, true, false); else if (sh) PP_GO(1, true, true, false); else PP_GO(0, true, true, false);
   } else {
-    if (sh) PP_GO(1, true, false, false); else PP_GO(0, true, false, false);
+    if (sh == 2) PP_GO(2, true, false, false); else if (sh) PP_GO(1, true, false, false); else PP_GO(0, true, false, false);
   }
 #endif
 #undef PP_GO
@@ -1027,28 +1043,51 @@ int launch_warp2(pp_ctx* ctx, int sh, bool sum, const float* D, const float* Us,
   PP_GO(0, true, true, PP_MINI_MASK);
 #else
   if (!sum) {
-    if (sh) PP_GO(1, false, false, false); else PP_GO(0, false, false, false);
+    if (sh == 2) PP_GO(2, false, false, false); else if (sh) PP_GO(1, false, false, false); else PP_GO(0, false, false, false);
   } else if (fd.masked) {
-    if (fd.streaming) { if (sh) PP_GO(1, true, true, true); else PP_GO(0, true, true, true); }
-    else { if (sh) PP_GO(1, true, false, true); else PP_GO(0, true, false, true); }
+    if (fd.streaming) { if (sh == 2) PP_GO(2, true, true, true); else if (sh) PP_GO(1, true, true, true); else PP_GO(0, true, true, true); }
+    else { if (sh == 2) PP_GO(2, true, false, true); else if (sh) PP_GO(1, true, false, true); else PP_GO(0, true, false, true); }
   } else if (fd.streaming) {
-    if (sh) PP_GO(1, true, true, false); else PP_GO(0, true, true, false);
+    if (sh == 2) PP_GO(2, true, true, false); else if (sh) PP_GO(1, true, true, false); else PP_GO(0, true, true, false);
   } else {
-    if (sh) PP_GO(1, true, false, false); else PP_GO(0, true, false, false);
+    if (sh == 2) PP_GO(2, true, false, false); else if (sh) PP_GO(1, true, false, false); else PP_GO(0, true, false, false);
   }
 #endif
 #undef PP_GO
   return PP_OK;
 }
 
+// Mixed tile shapes (generation 2, SH == 2): 64 x 16 tiles wherever a whole 64-wide tile fits and ONE column of 32 x 32 tiles
+// over the rest, when that rest is at most 32 columns -- a 64-wide tile there would compute on >= 50 % overhang, and all
+// 32 x 32 tiles run a 15-20 % longer plane step.  Measured against the launcher's single shape (tools/r4/run24.sh, bit-identical
+// fields): 340 x 340 x 170 0.453 -> 0.414 ms per iteration, 405 x 405 x 200 0.745 -> 0.706, 341 x 341 x 171 (odd rows: the
+// branchy instances) 0.466 -> 0.454, 288 x 288 x 160 0.273 -> 0.269; 85 x 85 x 43 0.033 -> 0.036 -- so only from 8 M voxels up
+// (PP_FUSED_MIX=1 forces it where the shape allows, =0 switches it off).
+bool fused_mix_ok(const pp_dims& d) {
+  const int rest = d.nx % tile_shape<0>::TX;
+  const bool shape_ok = d.nx >= tile_shape<0>::TX && rest != 0 && rest <= tile_shape<1>::TX;
+  if (const char* e = getenv("PP_FUSED_MIX")) return shape_ok && atoi(e) != 0;
+  return shape_ok && (size_t)d.nx * d.ny * d.nz >= ((size_t)8 << 20);
+}
+
 void fused_grid(fused_args* f, const pp_dims& d, int occupancy, int sh, char kernel) {
-  const int TX = sh ? tile_shape<1>::TX : tile_shape<0>::TX, TY = sh ? tile_shape<1>::TY : tile_shape<0>::TY;
+  const int TX = sh == 1 ? tile_shape<1>::TX : tile_shape<0>::TX, TY = sh == 1 ? tile_shape<1>::TY : tile_shape<0>::TY;
   f->d = d;
-  f->zchunk = fused_zchunk(d, 256 * occupancy, TX, TY, nullptr, kernel);
-  f->gx = (d.nx + TX - 1) / TX;
-  f->gy = (d.ny + TY - 1) / TY;
+  f->gx2 = f->gy2 = f->x2_off = 0;
+  if (sh == 2) {
+    f->gx = d.nx / tile_shape<0>::TX;
+    f->gy = (d.ny + tile_shape<0>::TY - 1) / tile_shape<0>::TY;
+    f->gx2 = 1;
+    f->gy2 = (d.ny + tile_shape<1>::TY - 1) / tile_shape<1>::TY;
+    f->x2_off = f->gx * tile_shape<0>::TX;
+    f->zchunk = fused_zchunk(d, 256 * occupancy, TX, TY, nullptr, kernel, f->gx * f->gy + f->gx2 * f->gy2);
+  } else {
+    f->zchunk = fused_zchunk(d, 256 * occupancy, TX, TY, nullptr, kernel);
+    f->gx = (d.nx + TX - 1) / TX;
+    f->gy = (d.ny + TY - 1) / TY;
+  }
   f->gz = (d.nz + f->zchunk - 1) / f->zchunk;
-  f->per_xcd = (int)(((size_t)f->gx * f->gy * f->gz + 7) / 8);
+  f->per_xcd = (int)((((size_t)f->gx * f->gy + (size_t)f->gx2 * f->gy2) * f->gz + 7) / 8);
   // an iteration touches 13 volumes' worth of floats (F, M, two warped images, D, D', S: 3 each); stream the outputs once
   // that is several times the 256 MB infinity cache.  Measured (tools/kbench/run12.sh): 79 MB volumes +1.5 % slower with
   // nt stores, 113 MB -1.5 %, 180 MB -2 %, 268 MB -2.7 %.
@@ -1244,7 +1283,14 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
 #undef PP_OCC_A20
 #undef PP_OCC_A21
     sh_a = fused_shape(d, 256 * occ_a0, 256 * occ_a1);
-    fused_grid(&fu, d, sh_a ? occ_a1 : occ_a0, sh_a, 'A');
+#define PP_OCC_A22(RR) occ_force2<RR>(2)
+    if (fused_mix_ok(d) && !getenv("PP_FUSED_TILE")) {
+      sh_a = 2;
+      fused_grid(&fu, d, PP_BY_RADIUS_A2(ra, PP_OCC_A22), 2, 'A');
+    } else {
+      fused_grid(&fu, d, sh_a ? occ_a1 : occ_a0, sh_a, 'A');
+    }
+#undef PP_OCC_A22
   } else {
 #define PP_OCC_A0(RR, OO) occ_force_sh<RR, OO>(0)
 #define PP_OCC_A1(RR, OO) occ_force_sh<RR, OO>(1)
@@ -1262,7 +1308,14 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
 #undef PP_OCC_B20
 #undef PP_OCC_B21
     sh_b = fused_shape(d, 256 * occ_b0, 256 * occ_b1);
-    fused_grid(&fd, d, sh_b ? occ_b1 : occ_b0, sh_b, 'B');
+#define PP_OCC_B22(RR) occ_warp2<RR>(2)
+    if (fused_mix_ok(d) && !getenv("PP_FUSED_TILE")) {
+      sh_b = 2;
+      fused_grid(&fd, d, PP_BY_RADIUS_B2(rb, PP_OCC_B22), 2, 'B');
+    } else {
+      fused_grid(&fd, d, sh_b ? occ_b1 : occ_b0, sh_b, 'B');
+    }
+#undef PP_OCC_B22
   } else {
 #define PP_OCC_B0(RR, OO) occ_warp_sh<RR, OO>(0)
 #define PP_OCC_B1(RR, OO) occ_warp_sh<RR, OO>(1)
@@ -1279,7 +1332,7 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   small_taps(td[0], rb, &fd.wx);
   small_taps(td[1], rb, &fd.wy);
   small_taps(td[2], rb, &fd.wz);
-  const size_t nblk = (size_t)fu.gx * fu.gy * fu.gz;
+  const size_t nblk = ((size_t)fu.gx * fu.gy + (size_t)fu.gx2 * fu.gy2) * fu.gz;
   const size_t need = 2 * pp_align_up(N * 4, 256) + 2 * pp_align_up(3 * N * 4, 256) + 2 * pp_align_up(3 * nblk * 8, 256) + 256;
   rc = pp_reserve(ctx, need);
   if (rc) return rc;

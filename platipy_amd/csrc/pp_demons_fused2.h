@@ -570,21 +570,29 @@ __device__ __forceinline__ void fused2_plane_loop3(F& step, int nsteps, int s_lo
 // path (vmcnt(0) right behind the warp's gathers, between the field stores, at the top of a step), and each wave sat out the
 // acknowledgement of its own stores and the HBM latency of the loads it had just issued.  The host picks MASK when rows are
 // even (8-byte buffer stores need 8-byte alignment) and a whole field spans < 2^31 bytes.
+// LDS floats of kernel B for one tile shape
+template <int R, int SH, bool SUM>
+struct fused2_warp_lds {
+  using G = strip_geom<R, SH, 0>;
+  static constexpr bool XS = (PP_B_XSHFL != 0) && SUM;
+  static constexpr int N = XS ? 2 * G::SZ_X : G::SZ_X + G::SZ_U;
+};
+// The kernel's body for ONE tile shape (SH 0 / 1); `smem` = the block's LDS (fused2_warp_lds<R, SH, SUM>::N floats), `region`:
+// fused_tile.  The __global__ wrapper below owns the LDS and, in a mixed launch, picks the shape per block.
 template <int R, int SH, bool UNROLL, bool SUM, bool NT, bool MASK>
-__global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(const float* __restrict__ D, const float* __restrict__ Us,
-                                                                            const float* __restrict__ M, float* __restrict__ Dn,
-                                                                            float* __restrict__ Mw, fused_args a, pp_warp_scale sc,
-                                                                            const int* __restrict__ halt) {
+__device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, const float* __restrict__ Us, const float* __restrict__ M,
+                                                 float* __restrict__ Dn, float* __restrict__ Mw, const fused_args& a,
+                                                 const pp_warp_scale& sc, const int* __restrict__ halt, float* const smem,
+                                                 const int region) {
   using G = strip_geom<R, SH, 0>;
   constexpr int NTH = G::NTH, TX = G::TX, TY = G::TY, W = 2 * R + 1;
   constexpr bool XS = (PP_B_XSHFL != 0) && SUM;   // x pass in registers (wavefront shuffles), y-pass buffer double-buffered
-  __shared__ __attribute__((aligned(16))) float smem[XS ? 2 * G::SZ_X : G::SZ_X + G::SZ_U];
   float* const s_x = smem;
   float* const s_u = smem + G::SZ_X;   // (XS: the second y-pass buffer)
   if (halt && *halt) return;
   int tx0, ty0, z0;
   unsigned rank;
-  if (!fused_tile(a, TX, TY, tx0, ty0, z0, rank)) return;
+  if (!fused_tile(a, TX, TY, tx0, ty0, z0, rank, region)) return;
 
   const pp_dims d = a.d;
   const int t = threadIdx.x;
@@ -867,6 +875,25 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
 #endif
 }
 
+// SH 0 / 1: every tile of that shape.  SH 2: tiles of both shapes in one launch (fused_args: gx2 > 0) -- 64 x 16 wherever a
+// whole 64-wide tile fits, 32 x 32 over the remaining columns -- with the LDS of the larger carve.
+template <int R, int SH, bool UNROLL, bool SUM, bool NT, bool MASK>
+__global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(const float* __restrict__ D, const float* __restrict__ Us,
+                                                                            const float* __restrict__ M, float* __restrict__ Dn,
+                                                                            float* __restrict__ Mw, fused_args a, pp_warp_scale sc,
+                                                                            const int* __restrict__ halt) {
+  if constexpr (SH == 2) {
+    constexpr int N0 = fused2_warp_lds<R, 0, SUM>::N, N1 = fused2_warp_lds<R, 1, SUM>::N;
+    __shared__ __attribute__((aligned(16))) float smem[N0 > N1 ? N0 : N1];
+    if (fused_region(a) == 0) fused2_warp_body<R, 0, UNROLL, SUM, NT, MASK>(D, Us, M, Dn, Mw, a, sc, halt, smem, 0);
+    else fused2_warp_body<R, 1, UNROLL, SUM, NT, MASK>(D, Us, M, Dn, Mw, a, sc, halt, smem, 1);
+  } else {
+    __shared__ __attribute__((aligned(16))) float smem[fused2_warp_lds<R, SH, SUM>::N];
+    fused2_warp_body<R, SH, UNROLL, SUM, NT, MASK>(D, Us, M, Dn, Mw, a, sc, halt, smem, 0);
+  }
+}
+
+
 // pp_esm_axis with the border rules carried by DATA instead of per-lane flags (the hoisted flag masks cost kernel A ~36
 // scalar-register reloads per plane): a neighbour slot outside the volume holds the sentinel in its warped-image half, so
 // "usable" needs no first/last-index test, and the fixed-image difference is scaled by hf = 0 on the first/last index
@@ -893,34 +920,25 @@ __device__ __forceinline__ float pp_esm_axis_plain(float fm, float fp, float mm,
 // ---- kernel A, generation 2: ESM update + 3-D Gaussian of the update -----------------------------------
 // SUM: the stored volume is D + G_u * update (D read at the thread's own output voxels), what kernel B<SUM> smooths.
 // MASK: as in kernel B -- every memory instruction of a plane step issued on every step, lane masks in the offsets.
+// LDS floats of kernel A for one tile shape: the packed image tile, the smoothing input, the x-pass tile
+template <int R, int SH>
+struct fused2_force_lds {
+  using G = fused_geom<R, 2, SH>;
+  static constexpr int SZ_IMG2 = (2 * G::MH * G::MWP + 3) / 4 * 4;   // packed (moving, fixed) tile, floats
+  static constexpr int SZ_U = G::SZ_U;
+  static constexpr int SZ_XT = 3 * G::UH * fused2_xtile<SH>::XP;     // x-pass tile (>= G::SZ_X: the row pitch may be padded)
+};
+// The kernel's body for ONE tile shape; the three LDS objects come from the __global__ wrapper below (as for kernel B).
 template <int R, int SH, bool UNROLL, bool SUM, bool NT, bool MASK>
-__global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(const float* __restrict__ F, const float* __restrict__ Mw,
-                                                                         const float* __restrict__ D, float* __restrict__ Us,
-                                                                         fused_args a, pp_esm_consts K,
-                                                                         double* __restrict__ partials, pp_dev_stats* __restrict__ st,
-                                                                         const double* __restrict__ prev, int nprev, double max_rms) {
+__device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, const float* __restrict__ Mw, const float* __restrict__ D,
+                                                  float* __restrict__ Us, const fused_args& a, const pp_esm_consts& K,
+                                                  double* __restrict__ partials, pp_dev_stats* __restrict__ st,
+                                                  const double* __restrict__ prev, int nprev, double max_rms, float2* const s_mf,
+                                                  float* const s_u, float* const s_x, const int region) {
   using G = fused_geom<R, 2, SH>;
   constexpr int NTH = G::NTH, TX = G::TX, TY = G::TY, W = 2 * R + 1;
   constexpr int NXI = (3 * G::XI + NTH - 1) / NTH;
-  constexpr int SZ_IMG2 = (2 * G::MH * G::MWP + 3) / 4 * 4;   // packed (moving, fixed) tile, floats
-  constexpr int SZ_XT = 3 * G::UH * fused2_xtile<SH>::XP;     // x-pass tile (>= G::SZ_X: the row pitch may be padded)
-#if PP_A_SPLIT_LDS
-  // three objects instead of one carved array: the compiler may then move the image-tile reads of one ESM round above the
-  // update stores of the previous one (as slices of one array it must keep them in order, and each wave pays the LDS round
-  // trip once per round)
-  __shared__ __attribute__((aligned(16))) float2 s_mf_[SZ_IMG2 / 2];
-  __shared__ __attribute__((aligned(16))) float s_u_[G::SZ_U];
-  __shared__ __attribute__((aligned(16))) float s_x_[SZ_XT];
-  float2* const s_mf = s_mf_;
-  float* const s_u = s_u_;
-  float* const s_x = s_x_;
-  float* const smem = s_u_;   // (the reduction scratch of the prologue: 3 * 8 doubles)
-#else
-  __shared__ __attribute__((aligned(16))) float smem[SZ_IMG2 + G::SZ_U + SZ_XT];
-  float2* const s_mf = reinterpret_cast<float2*>(smem);
-  float* const s_u = smem + SZ_IMG2;
-  float* const s_x = smem + SZ_IMG2 + G::SZ_U;
-#endif
+  float* const smem = s_u;   // (the reduction scratch of the prologue: 3 * 8 doubles)
   if (st->halt) return;   // (written by an earlier launch)
   // End of the PREVIOUS iteration, folded into this launch instead of a one-block kernel of its own (k_demons_finalize:
   // 5 us plus a launch gap per iteration, a fifth of an iteration on the coarse pyramid levels): every block adds the
@@ -959,7 +977,7 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
   }
   int tx0, ty0, z0;
   unsigned rank;
-  if (!fused_tile(a, TX, TY, tx0, ty0, z0, rank)) return;
+  if (!fused_tile(a, TX, TY, tx0, ty0, z0, rank, region)) return;
 
   const pp_dims d = a.d;
   const int t = threadIdx.x;
@@ -1351,5 +1369,31 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     partials[3 * (size_t)rank + 0] = r_ssd;
     partials[3 * (size_t)rank + 1] = r_ssc;
     partials[3 * (size_t)rank + 2] = r_n;
+  }
+}
+
+// SH 0 / 1 / 2 as for kernel B.  (Three LDS objects, not one carved array: the compiler may then move the image-tile reads of
+// one ESM round above the update stores of the previous one -- as slices of one array it must keep them in order, and each
+// wave pays the LDS round trip once per round.)
+template <int R, int SH, bool UNROLL, bool SUM, bool NT, bool MASK>
+__global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(const float* __restrict__ F, const float* __restrict__ Mw,
+                                                                         const float* __restrict__ D, float* __restrict__ Us,
+                                                                         fused_args a, pp_esm_consts K,
+                                                                         double* __restrict__ partials, pp_dev_stats* __restrict__ st,
+                                                                         const double* __restrict__ prev, int nprev, double max_rms) {
+  if constexpr (SH == 2) {
+    using L0 = fused2_force_lds<R, 0>;
+    using L1 = fused2_force_lds<R, 1>;
+    __shared__ __attribute__((aligned(16))) float2 s_mf_[(L0::SZ_IMG2 > L1::SZ_IMG2 ? L0::SZ_IMG2 : L1::SZ_IMG2) / 2];
+    __shared__ __attribute__((aligned(16))) float s_u_[L0::SZ_U > L1::SZ_U ? L0::SZ_U : L1::SZ_U];
+    __shared__ __attribute__((aligned(16))) float s_x_[L0::SZ_XT > L1::SZ_XT ? L0::SZ_XT : L1::SZ_XT];
+    if (fused_region(a) == 0) fused2_force_body<R, 0, UNROLL, SUM, NT, MASK>(F, Mw, D, Us, a, K, partials, st, prev, nprev, max_rms, s_mf_, s_u_, s_x_, 0);
+    else fused2_force_body<R, 1, UNROLL, SUM, NT, MASK>(F, Mw, D, Us, a, K, partials, st, prev, nprev, max_rms, s_mf_, s_u_, s_x_, 1);
+  } else {
+    using L = fused2_force_lds<R, SH>;
+    __shared__ __attribute__((aligned(16))) float2 s_mf_[L::SZ_IMG2 / 2];
+    __shared__ __attribute__((aligned(16))) float s_u_[L::SZ_U];
+    __shared__ __attribute__((aligned(16))) float s_x_[L::SZ_XT];
+    fused2_force_body<R, SH, UNROLL, SUM, NT, MASK>(F, Mw, D, Us, a, K, partials, st, prev, nprev, max_rms, s_mf_, s_u_, s_x_, 0);
   }
 }

@@ -332,24 +332,36 @@ def test_demons_execute(backend, grid, variant):
     assert np.abs(want).max() > 0.2  # the registration did something
 
 
-@pytest.mark.parametrize("grid", GRIDS + [HIRES])
+MIXED = [((8, 37, 85), (1.5, 1.5, 1.5), (0.0, 0.0, 0.0)),      # 85 = 64 + 21: one column of 64 x 16 tiles, one of 32 x 32 (odd rows)
+         ((7, 35, 160), (1.0, 1.2, 0.9), (5.0, 0.0, -3.0))]    # 160 = 2 x 64 + 32: two columns + a full 32-wide one (even rows: MASK)
+
+
+@pytest.mark.parametrize("grid", GRIDS + [HIRES] + MIXED)
 def test_fused_demons_tile_shapes_agree(backend, grid, monkeypatch):
     """The 32 x 32 tile variant of the fused kernels (chosen for grids that 64 x 16 tiles fit badly) computes every
-    output voxel with the same operations in the same order: bit-identical fields, equal statistics."""
+    output voxel with the same operations in the same order: bit-identical fields, equal statistics.  So does the MIXED
+    launch (64 x 16 tiles where a whole one fits, one column of 32 x 32 tiles over the rest), which the launcher picks by
+    itself for row lengths 64 k + 1 .. 64 k + 32 of volumes from 8 M voxels up when no shape is forced."""
     shape, spacing, origin = grid
     fix = phantom(shape, seed=40)
     dv = random_dvf(shape, spacing, seed=41, max_mm=2.5)
     mov = O.warp_image(O.Vol(fix, spacing, origin), dv.astype(np.float64), edge_value=-1000.0).arr.astype(np.float32)
     p = _demons_params(backend.ctx, 3, spacing, _lib.DEMONS_FUSED, max_rms=0.0)
     out = {}
-    for tile in ("0", "1"):
-        monkeypatch.setenv("PP_FUSED_TILE", tile)
+    for tile in ("0", "1", "mixed", "never mixed"):
+        monkeypatch.delenv("PP_FUSED_TILE", raising=False)
+        monkeypatch.delenv("PP_FUSED_MIX", raising=False)
+        if tile in ("0", "1"):
+            monkeypatch.setenv("PP_FUSED_TILE", tile)
+        else:       # (on its own the launcher mixes from 8 M voxels up)
+            monkeypatch.setenv("PP_FUSED_MIX", "1" if tile == "mixed" else "0")
         f = backend.empty((3,) + shape)
         st = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, f)
         out[tile] = (backend.host(f).copy(), st.metric, st.rms_change, st.elapsed_iterations)
-    np.testing.assert_array_equal(out["0"][0], out["1"][0])
-    np.testing.assert_allclose(out["0"][1:3], out["1"][1:3], rtol=1e-6)
-    assert out["0"][3] == out["1"][3] == 3
+    for other in ("1", "mixed", "never mixed"):
+        np.testing.assert_array_equal(out["0"][0].view(np.uint32), out[other][0].view(np.uint32))
+        np.testing.assert_allclose(out["0"][1:3], out[other][1:3], rtol=1e-6)
+        assert out["0"][3] == out[other][3] == 3
     assert np.abs(out["0"][0]).max() > 0.1
 
 
