@@ -255,6 +255,33 @@ __global__ void __launch_bounds__(NT) k_copy_if_odd(float* __restrict__ dst, con
   for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) dst[i] = alt[i];
 }
 
+// Dense rows of nx voxels -> rows of px (a multiple of four) with the last voxel repeated into the padding (never read as
+// data: every read clamps x to nx - 1; a finite value keeps the padding's arithmetic quiet).  One thread = one quad.
+__global__ void __launch_bounds__(NT) k_pad_rows(const float* __restrict__ src, float* __restrict__ dst, int nx, int px, size_t rows) {
+  const size_t qpr = (size_t)(px / 4), n = rows * qpr;
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+    const size_t r = i / qpr;
+    const int x = (int)(i - r * qpr) * 4;
+    const float* s = src + r * (size_t)nx;
+    float4 v;
+    v.x = s[x < nx ? x : nx - 1];
+    v.y = s[x + 1 < nx ? x + 1 : nx - 1];
+    v.z = s[x + 2 < nx ? x + 2 : nx - 1];
+    v.w = s[x + 3 < nx ? x + 3 : nx - 1];
+    *reinterpret_cast<float4*>(dst + r * (size_t)px + x) = v;
+  }
+}
+// The three components of the newest padded field (`even` after an even number of iterations, `odd` otherwise) -> dense rows.
+__global__ void __launch_bounds__(NT) k_unpad_field(float* __restrict__ dst, const float* __restrict__ even, const float* __restrict__ odd,
+                                                    int nx, int px, size_t rows, const pp_dev_stats* __restrict__ st) {
+  const float* __restrict__ src = (st->elapsed & 1) ? odd : even;
+  const size_t n = 3 * rows * (size_t)nx;
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+    const size_t r = i / (size_t)nx;   // (row index over the three components: they are rows * px apart, i.e. contiguous rows)
+    dst[i] = src[r * (size_t)px + (i - r * (size_t)nx)];
+  }
+}
+
 // k_demons_force4's precondition: whole 16-byte quads per row, 16-byte aligned volumes
 bool force_vec4(const pp_dims& d, const float* f, const float* m, const float* u) {
   const size_t N = (size_t)d.nx * d.ny * d.nz;
@@ -414,6 +441,10 @@ struct fused_args {
   // generation 2, mixed tile shapes (SH == 2): region 0 = gx x gy tiles of 64 x 16 from x = 0, region 1 = gx2 x gy2 tiles of
   // 32 x 32 from x = x2_off (the columns a 64-wide tile would overhang by half or more); gx2 == 0: one shape only
   int gx2, gy2, x2_off;
+  // generation 2: row pitch in voxels of EVERY volume the kernels touch (>= d.nx).  The fused Execute copies volumes whose
+  // rows are not whole 16-byte quads into padded rows once: strips are then 16-byte aligned and pairs 8-byte aligned for any
+  // row length, and the MASK instances (which need pairs) serve odd row lengths too.  Padding is written, never read as data.
+  int px;
   pp_taps_small wx, wy, wz;
 };
 
@@ -1070,7 +1101,7 @@ bool fused_mix_ok(const pp_dims& d) {
   return shape_ok && (size_t)d.nx * d.ny * d.nz >= ((size_t)8 << 20);
 }
 
-void fused_grid(fused_args* f, const pp_dims& d, int occupancy, int sh, char kernel) {
+void fused_grid(fused_args* f, const pp_dims& d, int occupancy, int sh, char kernel, int px = 0) {
   const int TX = sh == 1 ? tile_shape<1>::TX : tile_shape<0>::TX, TY = sh == 1 ? tile_shape<1>::TY : tile_shape<0>::TY;
   f->d = d;
   f->gx2 = f->gy2 = f->x2_off = 0;
@@ -1093,8 +1124,14 @@ void fused_grid(fused_args* f, const pp_dims& d, int occupancy, int sh, char ker
   // nt stores, 113 MB -1.5 %, 180 MB -2 %, 268 MB -2.7 %.
   f->streaming = (size_t)d.nx * d.ny * d.nz * sizeof(float) > ((size_t)100 << 20);
   if (const char* e = getenv("PP_FUSED_NT")) f->streaming = atoi(e) != 0;
-  f->masked = (d.nx % 2 == 0) && 3 * (size_t)d.nx * d.ny * d.nz * sizeof(float) < ((size_t)1 << 31);
-  if (const char* e = getenv("PP_FUSED_MASK")) f->masked = f->masked && atoi(e) != 0;   // (0: the branchy kernels, for A/B runs)
+  f->px = px > 0 ? px : d.nx;
+  // MASK instances: pairs must exist (even pitch), offsets must fit the buffer-resource trick -- and the volume must be large
+  // enough to be throughput-bound: on the small pyramid levels every lane loading on every step costs more than exact waits
+  // give (128 x 128 x 64 and 64 x 64 x 32: +7 %, profiles/round4_kbench_mask.txt; 512 x 512 x 256: -2.6 %; equal at 340 x 340 x 170).
+  f->masked = (f->px % 2 == 0) && 3 * (size_t)f->px * d.ny * d.nz * sizeof(float) < ((size_t)1 << 31) &&
+              (size_t)d.nx * d.ny * d.nz >= ((size_t)8 << 20);
+  if (const char* e = getenv("PP_FUSED_MASK"))   // (0: the branchy kernels; 1: MASK wherever the shape allows -- A/B runs, tests)
+    f->masked = atoi(e) != 0 && (f->px % 2 == 0) && 3 * (size_t)f->px * d.ny * d.nz * sizeof(float) < ((size_t)1 << 31);
 }
 
 int check_demons_args(pp_ctx* ctx, const pp_geom* g, const pp_demons_params* p) {
@@ -1275,6 +1312,15 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   const int opt_a = ra > 3 ? 2 : opt, opt_b = rb > 3 ? 2 : opt;   // radii 4 and 5 exist in the 512-thread layout only
   fused_args fu, fd;
   int sh_a = 0, sh_b = 0;
+  // Padded rows (fused_args::px) when both kernels are generation 2 in SUM mode and the rows are not whole 16-byte quads.
+  // Measured (tools/r4/run26.sh, bit-identical fields): 341 x 341 x 171 0.451 -> 0.420 ms per iteration, 405 x 405 x 200 0.704 ->
+  // 0.655; 171 x 171 x 85 0.073 -> 0.082 and 85 x 85 x 43 0.033 -> 0.037 (latency-bound levels: the MASK instances' unconditional
+  // loads and the two copies cost more than alignment gives) -- so from 8 M voxels up; PP_FUSED_PITCH=1 / 0 forces / forbids it.
+  bool pitched = gen_a == 2 && gen_b == 2 && sum_mode && p->iterations > 0 && d.nx % 4 != 0;
+  if (const char* e = getenv("PP_FUSED_PITCH")) pitched = pitched && atoi(e) != 0;
+  else pitched = pitched && N >= ((size_t)8 << 20);
+  const int px = pitched ? (d.nx + 3) / 4 * 4 : d.nx;
+  const size_t Np = (size_t)px * d.ny * d.nz;
   // tile shape per kernel: 32 x 32 where the z-chunk model says the 64 x 16 launch wastes >= 10 % (512-thread layouts only)
   if (gen_a == 2) {
 #define PP_OCC_A20(RR) occ_force2<RR>(0)
@@ -1286,9 +1332,9 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
 #define PP_OCC_A22(RR) occ_force2<RR>(2)
     if (fused_mix_ok(d) && !getenv("PP_FUSED_TILE")) {
       sh_a = 2;
-      fused_grid(&fu, d, PP_BY_RADIUS_A2(ra, PP_OCC_A22), 2, 'A');
+      fused_grid(&fu, d, PP_BY_RADIUS_A2(ra, PP_OCC_A22), 2, 'A', px);
     } else {
-      fused_grid(&fu, d, sh_a ? occ_a1 : occ_a0, sh_a, 'A');
+      fused_grid(&fu, d, sh_a ? occ_a1 : occ_a0, sh_a, 'A', px);
     }
 #undef PP_OCC_A22
   } else {
@@ -1311,9 +1357,9 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
 #define PP_OCC_B22(RR) occ_warp2<RR>(2)
     if (fused_mix_ok(d) && !getenv("PP_FUSED_TILE")) {
       sh_b = 2;
-      fused_grid(&fd, d, PP_BY_RADIUS_B2(rb, PP_OCC_B22), 2, 'B');
+      fused_grid(&fd, d, PP_BY_RADIUS_B2(rb, PP_OCC_B22), 2, 'B', px);
     } else {
-      fused_grid(&fd, d, sh_b ? occ_b1 : occ_b0, sh_b, 'B');
+      fused_grid(&fd, d, sh_b ? occ_b1 : occ_b0, sh_b, 'B', px);
     }
 #undef PP_OCC_B22
   } else {
@@ -1333,14 +1379,27 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   small_taps(td[1], rb, &fd.wy);
   small_taps(td[2], rb, &fd.wz);
   const size_t nblk = ((size_t)fu.gx * fu.gy + (size_t)fu.gx2 * fu.gy2) * fu.gz;
-  const size_t need = 2 * pp_align_up(N * 4, 256) + 2 * pp_align_up(3 * N * 4, 256) + 2 * pp_align_up(3 * nblk * 8, 256) + 256;
+  const size_t need = (pitched ? 4 : 2) * pp_align_up(Np * 4, 256) + (pitched ? 3 : 2) * pp_align_up(3 * Np * 4, 256) +
+                      2 * pp_align_up(3 * nblk * 8, 256) + 256;
   rc = pp_reserve(ctx, need);
   if (rc) return rc;
   pp_carver cv{ctx->ws, 0};
-  float* MwA = cv.take<float>(N);
-  float* MwB = cv.take<float>(N);
-  float* Us = cv.take<float>(3 * N);
-  float* D2 = cv.take<float>(3 * N);
+  float* MwA = cv.take<float>(Np);
+  float* MwB = cv.take<float>(Np);
+  float* Us = cv.take<float>(3 * Np);
+  float* D2 = cv.take<float>(3 * Np);
+  float* D1 = field;   // the other field buffer: the caller's (dense rows) or a padded one of this call's
+  if (pitched) {
+    D1 = cv.take<float>(3 * Np);
+    float* Fp = cv.take<float>(Np);
+    float* Mp = cv.take<float>(Np);
+    const size_t rows = (size_t)d.ny * d.nz;
+    hipLaunchKernelGGL(k_pad_rows, dim3(grid_for(rows * (px / 4), 16384)), dim3(NT), 0, ctx->stream, fixed, Fp, d.nx, px, rows);
+    hipLaunchKernelGGL(k_pad_rows, dim3(grid_for(rows * (px / 4), 16384)), dim3(NT), 0, ctx->stream, moving, Mp, d.nx, px, rows);
+    PP_LAUNCH_CHECK(ctx, "k_pad_rows");
+    fixed = Fp;
+    moving = Mp;
+  }
   double* partials = cv.take<double>(3 * nblk);
   double* partials2 = cv.take<double>(3 * nblk);   // generation-2 kernel A alternates: it folds the previous launch's sums itself
   pp_dev_stats* dst = cv.take<pp_dev_stats>(1);
@@ -1355,8 +1414,8 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     // D = 0 warps the moving image onto itself exactly, so iteration 0 reads it directly.
     const float* mw_in = it == 0 ? moving : ((it & 1) ? MwA : MwB);
     float* mw_out = (it & 1) ? MwB : MwA;
-    const float* Dcur = (it & 1) ? D2 : field;
-    float* Dnext = (it & 1) ? field : D2;
+    const float* Dcur = (it & 1) ? D2 : D1;
+    float* Dnext = (it & 1) ? D1 : D2;
     // a failed first launch must not be masked by the second one's status
     if (gen_a == 2) {
       double* const pcur = (it & 1) ? partials2 : partials;
@@ -1391,9 +1450,15 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   }
   // (a grid-stride copy: with an even iteration count -- the usual case -- every block returns at once, and a quarter of a
   // million blocks doing so took 22 us)
-  hipLaunchKernelGGL(k_copy_if_odd, dim3(grid_for(3 * N, 8192)), dim3(NT), 0, ctx->stream, field, (const float*)D2, 3 * N,
-                     (const pp_dev_stats*)dst);
-  PP_LAUNCH_CHECK(ctx, "k_copy_if_odd");
+  if (pitched) {   // the newest field (D1 after an even number of iterations, D2 after an odd one) back into dense rows
+    hipLaunchKernelGGL(k_unpad_field, dim3(grid_for(3 * N, 16384)), dim3(NT), 0, ctx->stream, field, (const float*)D1, (const float*)D2,
+                       d.nx, px, (size_t)d.ny * d.nz, (const pp_dev_stats*)dst);
+    PP_LAUNCH_CHECK(ctx, "k_unpad_field");
+  } else {
+    hipLaunchKernelGGL(k_copy_if_odd, dim3(grid_for(3 * N, 8192)), dim3(NT), 0, ctx->stream, field, (const float*)D2, 3 * N,
+                       (const pp_dev_stats*)dst);
+    PP_LAUNCH_CHECK(ctx, "k_copy_if_odd");
+  }
   if (stats) return read_stats(ctx, dst, stats);
   return PP_OK;
 }

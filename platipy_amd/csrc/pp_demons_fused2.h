@@ -184,7 +184,7 @@ struct pp_strip {
   int slot;        // float index of the strip in the LDS tile (< 0: this thread has no such strip)
   unsigned jm;     // element map; 0xE4 = identity
 };
-__device__ __forceinline__ pp_strip pp_strip_setup(int s, int ns, int spr, int uw, int x_first, int y_first, const pp_dims& d) {
+__device__ __forceinline__ pp_strip pp_strip_setup(int s, int ns, int spr, int uw, int x_first, int y_first, const pp_dims& d, int px) {
   pp_strip st;
   const int ss = s < ns ? s : 0;
   const int uy = ss / spr, sx = ss - uy * spr;
@@ -194,7 +194,7 @@ __device__ __forceinline__ pp_strip pp_strip_setup(int s, int ns, int spr, int u
   unsigned jm = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) jm |= (unsigned)(pp_clampi(xs + i, 0, d.nx - 1) - xl) << (2 * i);
-  st.goff = ((unsigned)yc * (unsigned)d.nx + (unsigned)xl) * 4u;
+  st.goff = ((unsigned)yc * (unsigned)px + (unsigned)xl) * 4u;   // (px: row pitch in voxels, >= d.nx)
   st.slot = s < ns ? uy * uw + 4 * sx : -1;
   st.jm = jm;
   return st;
@@ -597,7 +597,7 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
   const pp_dims d = a.d;
   const int t = threadIdx.x;
   const int cx = t % G::LX, cy = t / G::LX;
-  const unsigned sy = d.nx, sz = (unsigned)d.nx * d.ny;
+  const unsigned sy = (unsigned)a.px, sz = (unsigned)a.px * d.ny;   // rows are a.px voxels apart (>= d.nx: padded rows, see pp_demons.hip)
   const size_t N = (size_t)sz * d.nz;
 
   pp_strip st[G::NSL];
@@ -609,20 +609,20 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
     const int lane = t & 63, riw = lane / G::SPR, sx = lane - riw * G::SPR;
     const int uy = (t >> 6) * RPW + riw;
     const bool valid = riw < RPW && uy < G::UH;
-    st[0] = pp_strip_setup(valid ? uy * G::SPR + sx : G::NS, G::NS, G::SPR, G::UW, tx0 - G::RP, ty0 - R, d);
+    st[0] = pp_strip_setup(valid ? uy * G::SPR + sx : G::NS, G::NS, G::SPR, G::UW, tx0 - G::RP, ty0 - R, d, a.px);
     xs_out = valid && sx >= 1 && sx <= G::SPR - 2;
     xs_off = uy * TX + 4 * (sx - 1);
   } else {
 #pragma unroll
-    for (int i = 0; i < G::NSL; ++i) st[i] = pp_strip_setup(t + i * NTH, G::NS, G::SPR, G::UW, tx0 - G::RP, ty0 - R, d);
+    for (int i = 0; i < G::NSL; ++i) st[i] = pp_strip_setup(t + i * NTH, G::NS, G::SPR, G::UW, tx0 - G::RP, ty0 - R, d, a.px);
     fused2_xpass_strips_setup<G>(t, xsrc, xdst);
   }
   const int yb = cy * TX + 2 * cx;
   const int x = tx0 + 2 * cx, y = ty0 + cy;
   const bool out_ok = (y < d.ny) && (x < d.nx);
-  const bool pair_ok = (d.nx % 2) == 0;     // then x + 1 < nx whenever x < nx and the 8-B stores are aligned
+  const bool pair_ok = (a.px % 2) == 0;     // then the 8-B accesses are aligned and voxel x + 1 of a pair exists -- in the row or in its padding
   const unsigned o_xy = ((unsigned)y * sy + (unsigned)x) * 4u;
-  const pp_warp_dims wd{d.nx, d.ny, d.nz, (unsigned)d.nx * 4u, sz * 4u};
+  const pp_warp_dims wd{d.nx, d.ny, d.nz, sy * 4u, sz * 4u};
   const char* const rm = reinterpret_cast<const char*>(M);
   const pp_rsrc r_dn = MASK ? pp_make_rsrc_masked(Dn) : pp_make_rsrc(Dn), r_mw = MASK ? pp_make_rsrc_masked(Mw) : pp_make_rsrc(Mw);   // one resource per output array (PP_SOFF)
 
@@ -982,7 +982,7 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
   const pp_dims d = a.d;
   const int t = threadIdx.x;
   const int cx = t % G::LX, cy = t / G::LX;
-  const unsigned sy = d.nx, sz = (unsigned)d.nx * d.ny;
+  const unsigned sy = (unsigned)a.px, sz = (unsigned)a.px * d.ny;
   const size_t N = (size_t)sz * d.nz;
   const pp_rsrc r_f = pp_make_rsrc(F), r_mw = pp_make_rsrc(Mw);   // (PP_SOFF)
   const pp_rsrc r_d = pp_make_rsrc(D), r_us = MASK ? pp_make_rsrc_masked(Us) : pp_make_rsrc(Us);
@@ -1036,7 +1036,7 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
   const int yb = cy * fused2_xtile<SH>::XP + 2 * cx;
   const int x = tx0 + 2 * cx, y = ty0 + cy;
   const bool out_ok = (y < d.ny) && (x < d.nx);
-  const bool pair_ok = (d.nx % 2) == 0;
+  const bool pair_ok = (a.px % 2) == 0;
   const unsigned o_xy = ((unsigned)y * sy + (unsigned)x) * 4u;
 
   const int zs = z0 - R;

@@ -368,6 +368,31 @@ def test_fused_demons_tile_shapes_agree(backend, grid, monkeypatch):
 ODD = ((9, 21, 67), (1.3, 0.9, 0.8), (0.0, 0.0, 0.0))   # odd nx: the scalar-store path; radii 1, 2, 2
 
 
+@pytest.mark.parametrize("grid", [GRIDS[0], ODD, MIXED[0], ((6, 18, 70), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0))])
+def test_fused_demons_padded_rows_do_not_change_the_field(backend, grid, monkeypatch):
+    """Rows that are not whole 16-byte quads (nx % 4 != 0) are copied into padded rows for the generation-2 kernels (aligned
+    strips and pairs, the MASK instances for odd row lengths too): the field, the statistics and the iteration count are
+    those of the dense-row run, bit for bit, whatever the padding holds (the workspace is poisoned first)."""
+    shape, spacing, origin = grid
+    assert shape[2] % 4 != 0
+    fix = phantom(shape, seed=60)
+    dv = random_dvf(shape, spacing, seed=61, max_mm=2.5)
+    mov = O.warp_image(O.Vol(fix, spacing, origin), dv.astype(np.float64), edge_value=-1000.0).arr.astype(np.float32)
+    out = {}
+    for iters in (3, 4):      # the newest field ends in either buffer
+        p = _demons_params(backend.ctx, iters, spacing, _lib.DEMONS_FUSED, max_rms=0.0)
+        for pitch, mask in (("1", "1"), ("1", "0"), ("0", "0")):     # (padded rows make the MASK instances possible for odd rows)
+            monkeypatch.setenv("PP_FUSED_PITCH", pitch)
+            monkeypatch.setenv("PP_FUSED_MASK", mask)
+            f = backend.empty((3,) + shape)
+            st = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, f)
+            out[pitch + mask] = (backend.host(f).copy(), st.metric, st.rms_change, st.elapsed_iterations, st.n_pixels)
+        for leg in ("11", "10"):
+            np.testing.assert_array_equal(out[leg][0].view(np.uint32), out["00"][0].view(np.uint32))
+            assert out[leg][1:] == out["00"][1:] and out[leg][3] == iters
+        assert np.abs(out["00"][0]).max() > 0.1
+
+
 @pytest.mark.parametrize("tile", ["0", "1"])
 @pytest.mark.parametrize("grid", GRIDS + [HIRES, ODD])
 def test_fused_demons_generations_agree(backend, grid, tile, monkeypatch):
