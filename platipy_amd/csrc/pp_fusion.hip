@@ -803,7 +803,7 @@ __global__ void __launch_bounds__(NT, PP_MV_WAVES) k_metric_values_lanes(const f
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (FAST) md[j] = (double)mv_pairs32_finish(g[j]);
-        if (MODE == 0) {
+        if constexpr (MODE == 0) {
           const double diff = fd[j] - md[j];
           acc[0] += ok[j] ? diff * diff : 0.0;
           acc[1] += ok[j] ? 1.0 : 0.0;
@@ -1023,7 +1023,7 @@ __global__ void __launch_bounds__(NT) k_metric_grad(const float* __restrict__ F,
       const float gy = (v10 - v00) + ((v11 - v01) - (v10 - v00)) * c.wz;
       const float gz = v1 - v0;
       const double w = ok[j] ? 1.0 : 0.0;   // (a rejected sample adds exact zeros)
-      if (MODE == 0) {
+      if constexpr (MODE == 0) {
         const double diff = ok[j] ? (double)fval[j] - (double)m : 0.0;
         acc[0] += diff * diff;
         acc[1] += w;
