@@ -607,8 +607,8 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
 // pipelines (every 8th voxel of the full-resolution moving image along x) the 64 lanes of a gather then address 16-64
 // different cache lines, and the kernel runs at the vector cache's line-lookup rate (measured: 75 us for 16 candidates on
 // 524 K samples, ~64 clocks per gather instruction).  Here lane = 16 * slot + candidate: a wavefront holds FOUR
-// consecutive samples x 16 candidates, the candidates of a sample land within a voxel or two of each other and the four
-// samples in neighbouring 32-byte sectors, so a gather instruction touches a handful of lines; a thread keeps NV
+// consecutive samples x 16 candidates; the four samples sit in neighbouring 32-byte sectors and, once the search bracket has
+// shrunk, a sample's candidates within a voxel or two of each other, so a gather instruction touches a handful of lines; a thread keeps NV
 // accumulators instead of 16 * NV (no 64 KB reduction tile: the block is bound by registers, not LDS), and a candidate's
 // samples are spread over 16 x as many threads (shorter dependent chains on the small lattices).
 // Sum order of a candidate: a thread adds its samples e0 + slot, e0 + 16 + slot, ... in increasing order; the four slots
