@@ -95,6 +95,51 @@ def test_demons_execute_full_size_matches_the_oracle(ctx, pair, oracle_execute, 
     assert stats["field_abs_max"] > 0.2
 
 
+def test_demons_execute_at_a_pipeline_level_size_matches_the_oracle(ctx, monkeypatch):
+    """The pipelines' 1.5 mm level (341 x 341 x 171: odd rows, 64-wide tiles that do not fit) is where the launcher pads the rows
+    and mixes tile shapes on its own (>= 8 M voxels).  Four iterations there against the oracle with the small tests' tolerances,
+    and bit for bit against the dense-row, single-shape launch."""
+    from bench import synth_pair
+    from oracle import oracle as O
+
+    shape, spacing = (171, 341, 341), (1.5, 1.5, 1.5)
+    fixed, moving, geom = synth_pair(ctx, shape, spacing, 4321, torch.device("cuda", 0))
+    flt = O.DemonsFilter()
+    flt.SetSmoothUpdateField(True)
+    flt.SetSmoothDisplacementField(True)
+    flt.SetStandardDeviations([1.5 / s for s in spacing])
+    flt.SetNumberOfIterations(4)
+    flt.SetMaximumRMSError(0.0)
+    t0 = time.perf_counter()
+    want = flt.Execute(O.Vol(fixed.cpu().numpy(), spacing), O.Vol(moving.cpu().numpy(), spacing)).arr
+    oracle_s = time.perf_counter() - t0
+    p = ctx.default_demons_params()
+    p.iterations, p.smooth_update, p.smooth_displacement, p.max_rms_error = 4, 1, 1, 0.0
+    p.sigma_d_vox[:] = [1.5 / s for s in spacing]
+    p.variant = _lib.DEMONS_FUSED
+    out = {}
+    for leg in ("launcher", "dense rows, one shape"):
+        if leg != "launcher":
+            monkeypatch.setenv("PP_FUSED_PITCH", "0")
+            monkeypatch.setenv("PP_FUSED_MIX", "0")
+        field = torch.empty((3,) + shape, device="cuda")
+        st = ctx.demons_execute(fixed, moving, geom, p, field)
+        out[leg] = (field.cpu().numpy(), st)
+    got, st = out["launcher"]
+    stats = _err_stats(got, want)
+    stats.update({"metric_hip": st.metric, "metric_oracle": flt.stats.metric, "n_pixels_hip": int(st.n_pixels),
+                  "n_pixels_oracle": int(flt.stats.n_pixels), "oracle_seconds": oracle_s, "size": [341, 341, 171], "iterations": 4,
+                  "bit_identical_to_dense_single_shape": bool(np.array_equal(got.view(np.uint32), out["dense rows, one shape"][0].view(np.uint32)))})
+    record_stats("levelsize_demons_execute_341x341x171", stats)
+    print("341 x 341 x 171 Execute vs oracle:", stats)
+    assert stats["bit_identical_to_dense_single_shape"]
+    assert st.elapsed_iterations == 4 == flt.stats.elapsed_iterations and st.n_pixels == flt.stats.n_pixels
+    assert stats["max"] <= 2e-3 and stats["rms"] <= 5e-5, stats
+    np.testing.assert_allclose(st.metric, flt.stats.metric, rtol=1e-4)
+    np.testing.assert_allclose(st.rms_change, flt.stats.rms_change, rtol=1e-4)
+    assert float(np.abs(want).max()) > 0.2
+
+
 def test_config2_whole_registration_full_size_matches_the_oracle(ctx, pair):
     """BASELINE config 2 end to end at 512x512x256: pyramids (sigma 8 / 4 / 1 mm blur + shrink), three levels of ten
     iterations, field up-sampling, composition, per-level recursive Gaussian, final warp -- product vs oracle, tolerance
