@@ -99,6 +99,56 @@ __global__ void __launch_bounds__(NT) k_cc_rows(const uint8_t* __restrict__ mask
   }
 }
 
+// The same labelling with one WAVEFRONT per row pass (rows up to 512 voxels in one pass, longer ones with a carry): a lane
+// walks CC_E consecutive voxels, the run start in force at its span comes from a max-scan over the lanes by wavefront
+// shuffles -- no LDS, no block barrier, four rows per block at a time.  (A block per row kept 38 of 256 threads busy on the
+// pipelines' ~300-voxel rows and paid twelve block barriers per row.)
+__global__ void __launch_bounds__(NT) k_cc_rows_wave(const uint8_t* __restrict__ mask, int* __restrict__ L, pp_dims d, int fg_only) {
+  const size_t rows = (size_t)d.ny * d.nz;
+  const int lane = (int)threadIdx.x & 63, wib = (int)threadIdx.x >> 6;
+  constexpr int WPB = NT / 64, SPAN = 64 * CC_E;
+  for (size_t row0 = (size_t)blockIdx.x * WPB; row0 < rows; row0 += (size_t)gridDim.x * WPB) {
+    const size_t row = row0 + wib;
+    if (row >= rows) continue;   // (shuffles are per wavefront: one without a row takes part in nothing)
+    const uint8_t* m = mask + row * d.nx;
+    int carry = 0;
+    for (int x0 = 0; x0 < d.nx; x0 += SPAN) {
+      const int xb = x0 + lane * CC_E;
+      bool v[CC_E];
+      int last = -1;                       // last run start inside my span
+      const bool before = xb > 0 && xb <= d.nx ? m[xb - 1] != 0 : false;
+      bool prev = before;
+#pragma unroll
+      for (int e = 0; e < CC_E; ++e) {
+        const int x = xb + e;
+        v[e] = x < d.nx ? m[x] != 0 : false;
+        if (x < d.nx && (x == 0 || v[e] != prev)) last = x;
+        prev = v[e];
+      }
+      int s = last;                        // inclusive max-scan over the lanes
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(s, (unsigned)off);
+        if (lane >= off && t > s) s = t;
+      }
+      int cur = __shfl_up(s, 1u);          // run start in force when my span begins
+      if (lane == 0 || cur < 0) cur = carry;   // (lane 0's shuffle returns its own value; -1: no run start to the left in this pass)
+      prev = before;
+#pragma unroll
+      for (int e = 0; e < CC_E; ++e) {
+        const int x = xb + e;
+        if (x < d.nx) {
+          if (x == 0 || v[e] != prev) cur = x;
+          prev = v[e];
+          L[row * d.nx + x] = (fg_only && !v[e]) ? (int)(row * d.nx + x) : (int)(row * d.nx + cur);
+        }
+      }
+      const int tail = __shfl(s, 63);
+      carry = tail >= 0 ? tail : carry;
+    }
+  }
+}
+
 // Stage 2, across rows: two equal-valued runs in adjacent rows (y - 1 or z - 1) overlap somewhere, and the later
 // of their two starts lies inside the overlap -- one union there joins them, so only positions where either run
 // starts need to try.  That is a few unions per run instead of three per voxel, and finds are one or two hops.
@@ -233,7 +283,12 @@ unsigned grid_for(size_t work, unsigned cap = 16384u) {
 int cc_label(pp_ctx* ctx, const uint8_t* mask, int* L, const pp_dims& d, size_t n, int fg_only) {
   const dim3 g(grid_for(n)), b(NT);
   const size_t rows = (size_t)d.ny * d.nz;
-  hipLaunchKernelGGL(k_cc_rows, dim3((unsigned)(rows < 65535 ? rows : 65535)), b, 0, ctx->stream, mask, L, d, fg_only);
+  if (getenv("PP_CC_ROWS_BLOCK")) {   // (the block-per-row form, for A/B runs)
+    hipLaunchKernelGGL(k_cc_rows, dim3((unsigned)(rows < 65535 ? rows : 65535)), b, 0, ctx->stream, mask, L, d, fg_only);
+  } else {
+    const size_t nbr = (rows + NT / 64 - 1) / (NT / 64);
+    hipLaunchKernelGGL(k_cc_rows_wave, dim3((unsigned)(nbr < 16384 ? nbr : 16384)), b, 0, ctx->stream, mask, L, d, fg_only);
+  }
   PP_LAUNCH_CHECK(ctx, "k_cc_rows");
   hipLaunchKernelGGL(k_cc_merge, g, b, 0, ctx->stream, mask, L, d, fg_only);
   PP_LAUNCH_CHECK(ctx, "k_cc_merge");

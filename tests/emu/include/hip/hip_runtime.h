@@ -207,6 +207,19 @@ static inline float hipemu_shfl_from(float v, int delta) {   // value of lane (l
 }
 static inline float __shfl_up(float v, unsigned delta, int /*width*/ = 64) { return hipemu_shfl_from(v, -(int)delta); }
 static inline float __shfl_down(float v, unsigned delta, int /*width*/ = 64) { return hipemu_shfl_from(v, (int)delta); }
+// 32-bit integers travel through the same table as exact doubles
+static inline int hipemu_shfl_int(int v, int src_lane_or_delta, bool relative) {
+  const unsigned t = threadIdx.x;
+  ::hipemu::t_shfl[t] = (double)v;
+  ::hipemu::wave_barrier();
+  const int src = relative ? (int)(t & 63u) + src_lane_or_delta : (src_lane_or_delta & 63);
+  const unsigned idx = (t & ~63u) + (unsigned)src;
+  const int r = (src >= 0 && src < 64 && idx < blockDim.x) ? (int)::hipemu::t_shfl[idx] : v;
+  ::hipemu::wave_barrier();
+  return r;
+}
+static inline int __shfl_up(int v, unsigned delta, int /*width*/ = 64) { return hipemu_shfl_int(v, -(int)delta, true); }
+static inline int __shfl(int v, int src_lane, int /*width*/ = 64) { return hipemu_shfl_int(v, src_lane, false); }
 // DPP whole-wave shifts by one lane (the two controls csrc/ uses): 0x138 = wave_shr:1 (value of lane - 1), 0x130 = wave_shl:1.
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
   (void)old;
