@@ -158,7 +158,8 @@ __global__ void __launch_bounds__(NT) k_cc_merge(const uint8_t* __restrict__ mas
   for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
     const bool v = mask[i] != 0;
     if (fg_only && !v) continue;
-    const int x = (int)(i % d.nx), y = (int)((i / d.nx) % d.ny), z = (int)(i / sz);
+    const unsigned i32 = (unsigned)i, row = i32 / (unsigned)d.nx;   // (n < 2^31: 32-bit divisions)
+    const int x = (int)(i32 - row * (unsigned)d.nx), y = (int)(row % (unsigned)d.ny), z = (int)(row / (unsigned)d.ny);
     const bool start = x == 0 || (mask[i - 1] != 0) != v;
     if (y > 0 && (mask[i - sy] != 0) == v && (start || (mask[i - sy - 1] != 0) != v)) cc_unite(L, (int)i, (int)i - sy);
     if (z > 0 && (mask[i - sz] != 0) == v && (start || (mask[i - sz - 1] != 0) != v)) cc_unite(L, (int)i, (int)i - sz);
@@ -173,10 +174,10 @@ __global__ void __launch_bounds__(NT) k_cc_compress(int* __restrict__ L, size_t 
 __global__ void __launch_bounds__(NT) k_cc_flag_border(const uint8_t* __restrict__ mask, const int* __restrict__ L,
                                                        int* __restrict__ flag, pp_dims d) {
   const size_t n = (size_t)d.nx * d.ny * d.nz;
-  const int sz = d.nx * d.ny;
   for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
     if (mask[i]) continue;
-    const int x = (int)(i % d.nx), y = (int)((i / d.nx) % d.ny), z = (int)(i / sz);
+    const unsigned i32 = (unsigned)i, row = i32 / (unsigned)d.nx;
+    const int x = (int)(i32 - row * (unsigned)d.nx), y = (int)(row % (unsigned)d.ny), z = (int)(row / (unsigned)d.ny);
     if (x == 0 || y == 0 || z == 0 || x == d.nx - 1 || y == d.ny - 1 || z == d.nz - 1) flag[L[i]] = 1;
   }
 }
