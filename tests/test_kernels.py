@@ -582,8 +582,9 @@ def test_fillhole_largest_component(backend):
     from scipy import ndimage
 
     rng = np.random.default_rng(5)
-    # the last shape has rows longer than a 256-thread scan segment (run starts carried across segments)
-    for shape, seed in [((12, 20, 37), 1), ((9, 33, 64), 2), ((6, 7, 5), 3), ((4, 9, 600), 4)]:
+    # (4, 9, 600): rows longer than one scan pass (run starts carried across passes); (44, 128, 160): more voxels than
+    # 2048 blocks x 256, so that the size count's blocks walk several segments each (runs carried across segments)
+    for shape, seed in [((12, 20, 37), 1), ((9, 33, 64), 2), ((6, 7, 5), 3), ((4, 9, 600), 4), ((44, 128, 160), 5)]:
         base = smooth_noise(shape, 90 + seed, cells=4) > 0.15
         m = base.copy()
         holes = rng.random(shape) < 0.04
