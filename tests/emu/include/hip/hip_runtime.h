@@ -240,6 +240,18 @@ static inline double __shfl_xor(double v, int lane_mask, int /*width*/ = 64) {
   ::hipemu::wave_barrier();
   return r;
 }
+// Wavefront ballot: bit l = predicate of lane l of the caller's wavefront (lanes beyond the block: 0).
+static inline unsigned long long __ballot(int pred) {
+  const unsigned t = threadIdx.x;
+  ::hipemu::t_shfl[t] = pred ? 1.0 : 0.0;
+  ::hipemu::wave_barrier();
+  unsigned long long r = 0;
+  for (unsigned l = (t & ~63u); l < (t & ~63u) + 64u && l < blockDim.x; ++l)
+    if (::hipemu::t_shfl[l] != 0.0) r |= 1ull << (l & 63u);
+  ::hipemu::wave_barrier();
+  return r;
+}
+static inline int __ffsll(unsigned long long v) { return v ? __builtin_ctzll(v) + 1 : 0; }
 // Wavefront vote: non-zero if the predicate holds in any live lane of the caller's wavefront.
 static inline int __any(int pred) {
   const unsigned t = threadIdx.x;
