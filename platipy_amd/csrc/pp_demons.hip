@@ -445,6 +445,11 @@ struct fused_args {
   // rows are not whole 16-byte quads into padded rows once: strips are then 16-byte aligned and pairs 8-byte aligned for any
   // row length, and the MASK instances (which need pairs) serve odd row lengths too.  Padding is written, never read as data.
   int px;
+  // generation 2, PP_SOFTSYNC builds: progress counters of this kernel's launch (8 x 32 words, one cache line per XCD), the
+  // other kernel's set (cleared by this launch) and the allowed lead in plane steps (0: count only)
+  unsigned* sync;
+  unsigned* sync_other;
+  int sync_lag;
   pp_taps_small wx, wy, wz;
 };
 
@@ -1132,6 +1137,11 @@ void fused_grid(fused_args* f, const pp_dims& d, int occupancy, int sh, char ker
               (size_t)d.nx * d.ny * d.nz >= ((size_t)8 << 20);
   if (const char* e = getenv("PP_FUSED_MASK"))   // (0: the branchy kernels; 1: MASK wherever the shape allows -- A/B runs, tests)
     f->masked = atoi(e) != 0 && (f->px % 2 == 0) && 3 * (size_t)f->px * d.ny * d.nz * sizeof(float) < ((size_t)1 << 31);
+  // soft synchronisation (PP_SOFTSYNC builds, MASK instances): only when every block of an XCD's run is resident at once --
+  // 32 CUs x `occupancy` slots -- since a block waits for the MEAN progress of its group (pp_demons_fused2.h)
+  f->sync = f->sync_other = nullptr;   // (set by the caller once the workspace is carved)
+  f->sync_lag = (PP_SOFTSYNC > 0 && f->per_xcd <= 32 * occupancy) ? PP_SOFTSYNC : 0;
+  if (const char* e = getenv("PP_FUSED_SYNC")) f->sync_lag = (f->per_xcd <= 32 * occupancy) ? atoi(e) : 0;
 }
 
 int check_demons_args(pp_ctx* ctx, const pp_geom* g, const pp_demons_params* p) {
@@ -1319,6 +1329,12 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   bool pitched = gen_a == 2 && gen_b == 2 && sum_mode && p->iterations > 0 && d.nx % 4 != 0;
   if (const char* e = getenv("PP_FUSED_PITCH")) pitched = pitched && atoi(e) != 0;
   else pitched = pitched && N >= ((size_t)8 << 20);
+  // (the padded pitch enlarges the component stride: the 32-bit offsets and 24-bit row products that gen2_ok checked on the
+  // dense volume must also hold on the padded one -- e.g. 709 x 709 x 711 passes dense and wraps at px = 712 -- else dense rows)
+  if (pitched) {
+    const size_t pxc = (size_t)(d.nx + 3) / 4 * 4;
+    if (!(3 * pxc * d.ny * d.nz * sizeof(float) < ((size_t)1 << 32) && pxc * sizeof(float) < ((size_t)1 << 24))) pitched = false;
+  }
   const int px = pitched ? (d.nx + 3) / 4 * 4 : d.nx;
   const size_t Np = (size_t)px * d.ny * d.nz;
   // tile shape per kernel: 32 x 32 where the z-chunk model says the 64 x 16 launch wastes >= 10 % (512-thread layouts only)
@@ -1379,8 +1395,9 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   small_taps(td[1], rb, &fd.wy);
   small_taps(td[2], rb, &fd.wz);
   const size_t nblk = ((size_t)fu.gx * fu.gy + (size_t)fu.gx2 * fu.gy2) * fu.gz;
+  constexpr size_t SYNC_WORDS = 8 * 32;   // per kernel: one 128-byte line per XCD
   const size_t need = (pitched ? 4 : 2) * pp_align_up(Np * 4, 256) + (pitched ? 3 : 2) * pp_align_up(3 * Np * 4, 256) +
-                      2 * pp_align_up(3 * nblk * 8, 256) + 256;
+                      2 * pp_align_up(3 * nblk * 8, 256) + 256 + pp_align_up(2 * SYNC_WORDS * sizeof(unsigned), 256);
   rc = pp_reserve(ctx, need);
   if (rc) return rc;
   pp_carver cv{ctx->ws, 0};
@@ -1404,6 +1421,14 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   double* partials2 = cv.take<double>(3 * nblk);   // generation-2 kernel A alternates: it folds the previous launch's sums itself
   pp_dev_stats* dst = cv.take<pp_dev_stats>(1);
   const int* halt = &dst->halt;
+  {   // progress counters of the soft synchronisation: kernel A's set, kernel B's set (each launch clears the other's)
+    unsigned* const sync_words = cv.take<unsigned>(2 * SYNC_WORDS);
+    fu.sync = sync_words;
+    fu.sync_other = sync_words + SYNC_WORDS;
+    fd.sync = sync_words + SYNC_WORDS;
+    fd.sync_other = sync_words;
+    if (PP_SOFTSYNC > 0) PP_HIP(ctx, hipMemsetAsync(sync_words, 0, 2 * SYNC_WORDS * sizeof(unsigned), ctx->stream));
+  }
   hipLaunchKernelGGL(k_stats_init, dim3(1), dim3(1), 0, ctx->stream, dst, hist, ctx->hist_cap);
   PP_LAUNCH_CHECK(ctx, "k_stats_init");
   // D = 0 at the start.  With both generation-2 kernels in SUM mode nothing reads the field's buffer before it is written:
@@ -1486,6 +1511,15 @@ int pp_demons_history(pp_ctx* ctx, double* metric, double* rms_change, int cap) 
   }
   return ran > n ? ran : n;
 }
+
+#ifdef PP_DRIFT
+int pp_debug_drift_read(unsigned long long* out, int cap) {
+  const int n = 2 * 1024 * 4;
+  if (cap < n) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_drift_buf), sizeof(unsigned long long) * n) != hipSuccess) return -2;
+  return n;
+}
+#endif
 
 #ifdef PP_TRACE
 int pp_debug_trace_read(unsigned* out, int cap) {

@@ -560,6 +560,89 @@ __device__ __forceinline__ void fused2_plane_loop3(F& step, int nsteps, int s_lo
   for (; n < nsteps; ++n) step(n, pp_phase<-1>{}, pp_steady<false>{});
 }
 
+
+// ---- Round 5: soft synchronisation of the blocks that share an L2 -------------------------------------------------------
+// The x/y halo of a tile (two 16-byte strips a row in x, 2R rows in y) lies in cache lines that belong to the NEIGHBOUR tiles:
+// a block finds them in its XCD's L2 only while the neighbour's march is within a plane or two of its own (4 MB of L2 see
+// ~1-2 MB of traffic per plane step of the 64 resident blocks).  Nothing keeps them there: the blocks start together and then
+// drift with every HBM-channel conflict, and the measured fetch of kernel B swings between 1.13 and 1.6 x its compulsory
+// reads with launch timing (profiles/round4_pmc_fetch_by_variant.txt).  With PP_SOFTSYNC the blocks of one XCD (block b runs on
+// XCD b % 8, the assumption the tile order already makes -- speed only) count their finished plane steps into one word, and a
+// block starts step n + 1 only when the group's MEAN progress has reached n + 1 - lag: the leaders wait a little, nobody else.
+// The wait is bounded (a group that is not co-resident, or an XCD mapping that differs, costs one time-out per block and
+// switches the block's synchronisation off), so no launch can hang on it.  One wave per block polls; the word it reads was
+// requested a whole step earlier.
+#ifndef PP_SOFTSYNC
+#define PP_SOFTSYNC 0
+#endif
+#ifndef PP_SOFTSYNC_TRIES
+#define PP_SOFTSYNC_TRIES 24
+#endif
+struct pp_softsync {
+  unsigned* word;    // this XCD's progress counter (a cache line of its own)
+  unsigned group;    // blocks that count into it
+  unsigned seen;     // the counter as last read
+  int lag;           // <= 0: count only
+  bool wave0;        // this wave polls and counts for its block (wave-uniform, held in a scalar register)
+};
+// Scope: every block of a group runs on ONE XCD, whose L2 is the coherence point of its CUs -- so the counter is read with
+// the vector cache bypassed and nothing more (workgroup scope: `global_load sc0`, an L2 hit), and counted by an atomic the same
+// L2 executes.  An agent-scope read (`sc1`) is served from beyond the L2, microseconds away, and since a wave's loads retire
+// in issue order every younger load of the step waited behind it: the first version of this ran the kernels 4 x slower
+// (profiles/round5_softsync.md).  If the dispatcher ever spread a group over XCDs the L2s would each count their own blocks
+// only and the waits would time out -- slower, never wrong.
+#ifndef PP_SOFTSYNC_SCOPE
+#define PP_SOFTSYNC_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
+__device__ __forceinline__ unsigned pp_sync_peek(const unsigned* w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, PP_SOFTSYNC_SCOPE); }
+__device__ __forceinline__ void pp_softsync_init(pp_softsync& y, const fused_args& a, unsigned* other_set) {
+  const unsigned xcd = blockIdx.x & 7u;
+  const unsigned ntiles = ((unsigned)a.gx * a.gy + (unsigned)a.gx2 * a.gy2) * (unsigned)a.gz;
+  const unsigned first = xcd * (unsigned)a.per_xcd;
+  y.word = a.sync + xcd * 32u;
+  y.group = ntiles > first ? (ntiles - first < (unsigned)a.per_xcd ? ntiles - first : (unsigned)a.per_xcd) : 0u;
+  y.seen = 0u;
+  y.lag = a.sync_lag;
+  y.wave0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64;
+  // the OTHER kernel's counters are idle while this launch runs: clear them for its next launch
+  if (blockIdx.x < 8u && threadIdx.x == 0) __hip_atomic_store(other_set + blockIdx.x * 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// End of plane step n (0-based) of a block, ahead of the barrier that closes the step; every wave calls it, wave 0 acts.
+__device__ __forceinline__ void pp_softsync_step(pp_softsync& y, int n) {
+  if (y.wave0) {
+    if (y.lag > 0) {
+      const int need = (int)y.group * (n + 1 - y.lag);
+      unsigned seen = (unsigned)__builtin_amdgcn_readfirstlane((int)y.seen);
+      if ((int)seen < need) {
+        int tries = 0;
+        do {
+          __builtin_amdgcn_s_sleep(4);
+          seen = (unsigned)__builtin_amdgcn_readfirstlane((int)pp_sync_peek(y.word));
+        } while ((int)seen < need && ++tries < PP_SOFTSYNC_TRIES);
+        if ((int)seen < need) y.lag = 0;   // timed out: this block stops waiting (it still counts)
+      }
+    }
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(y.word, 1u, __ATOMIC_RELAXED, PP_SOFTSYNC_SCOPE);
+  }
+}
+// A block that marches fewer steps than the nominal chunk (the last z-chunk) counts the difference when it ends.
+__device__ __forceinline__ void pp_softsync_finish(pp_softsync& y, int nsteps, int nominal) {
+  if (threadIdx.x == 0 && nominal > nsteps) __hip_atomic_fetch_add(y.word, (unsigned)(nominal - nsteps), __ATOMIC_RELAXED, PP_SOFTSYNC_SCOPE);
+}
+// Measurement builds (-DPP_DRIFT, tools/kbench): 100 MHz wall-clock stamps of EVERY block at the quarter points of its march.
+#ifdef PP_DRIFT
+__device__ unsigned long long pp_drift_buf[2][1024][4];
+#define PP_DRIFT_MARK(kern, n, nsteps)                                                                                  \
+  do {                                                                                                                  \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                                        \
+      const int q_ = ((n) == (nsteps) / 4) ? 0 : ((n) == (nsteps) / 2) ? 1 : ((n) == 3 * (nsteps) / 4) ? 2 : ((n) == (nsteps)-1) ? 3 : -1; \
+      if (q_ >= 0) pp_drift_buf[kern][blockIdx.x][q_] = wall_clock64();                                                 \
+    }                                                                                                                   \
+  } while (0)
+#else
+#define PP_DRIFT_MARK(kern, n, nsteps) do { } while (0)
+#endif
+
 // ---- kernel B, generation 2: D' = G_d * (D + U), then the next iteration's warped moving image --------
 // SUM: `Us` already holds D + U (kernel A<SUM> added D at its own output voxels, where it needs no halo), `D` is not read:
 // three halo'd arrays instead of six.  The sum is the same fp32 add on the same operands, so the fields are bit-identical.
@@ -631,6 +714,9 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
   const int ze = zo_last + R;
   const int zhi = pp_clampi(ze, 0, d.nz - 1);
   const int nsteps = ze - zs + 1;
+  constexpr bool SYNC = (PP_SOFTSYNC != 0) && MASK;
+  pp_softsync ysync{};
+  if constexpr (SYNC) pp_softsync_init(ysync, a, a.sync_other);
 
   float4 dl[SUM ? 1 : 3][G::NSL], ul[3][G::NSL];   // raw D and U strips of the plane about to be published
   // (ALL: every lane loads -- a lane without a strip re-reads strip 0 of the tile, whose address pp_strip_setup gave it -- so
@@ -715,6 +801,8 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
     const int nxt = ST ? zi + 1 : pp_clampi(zi + 1, 0, d.nz - 1);
     const bool fresh_next = ST || ((n + 1 < nsteps) && (nxt != cur));
     PP_TRACE_MARK(trace_on, 1, n, 0);
+    PP_DRIFT_MARK(1, n, nsteps);
+    if constexpr (SYNC) ysync.seen = pp_sync_peek(ysync.word);   // (consumed at the end of the step)
     // ---- interval 1: y pass of plane `cur` (reads s_x) | publish plane `nxt` (writes s_u) ----
     if (fresh_cur) {
 #pragma unroll
@@ -838,6 +926,7 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
     if constexpr (UNC) __builtin_amdgcn_sched_barrier(0);
     // ---- interval 2: x pass of plane `nxt` (XS: already done above; one barrier hands the buffers over) ----
     PP_TRACE_MARK(trace_on, 1, n, 1);
+    if constexpr (SYNC) pp_softsync_step(ysync, n);
     if (fresh_next) {
       __syncthreads();
       PP_TRACE_MARK(trace_on, 1, n, 2);
@@ -873,6 +962,7 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
   auto step_general = [&](int n, auto phase_tag) { step(n, phase_tag, pp_steady<false>{}); };
   fused2_plane_loop<R, UNROLL>(step_general, nsteps);
 #endif
+  if constexpr (SYNC) pp_softsync_finish(ysync, nsteps, a.zchunk + 2 * R);
 }
 
 // SH 0 / 1: every tile of that shape.  SH 2: tiles of both shapes in one launch (fused_args: gx2 > 0) -- 64 x 16 wherever a
@@ -989,7 +1079,7 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
 
   // Owned smoothing-input voxels.  Image values are fetched at the clamped position, so out-of-volume halo slots
   // replicate the edge update (ZeroFluxNeumann on the smoothing input).
-  unsigned slots[G::KU];  // read slot of the clamped position | write slot << 16   (in s_mf)
+  unsigned slots[G::KU];  // read slot of the clamped position, minus one row | write slot << 16   (in s_mf)
   unsigned uflag[G::KU];  // slot in s_u | flags << 16
   unsigned own_g[G::KU];  // in-plane BYTE offset of the clamped position
   float mprev[G::KU], mcur[G::KU], mnext[G::KU], fprev[G::KU], fcur[G::KU], fnext[G::KU];
@@ -1005,7 +1095,9 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
     const int xc = pp_clampi(xg, 0, d.nx - 1), yc = pp_clampi(yg, 0, d.ny - 1);
     own_g[k] = ((unsigned)yc * sy + (unsigned)xc) * 4u;
     const unsigned wslot = (unsigned)((uy + 1) * G::MWP + (ux + 1));
-    const unsigned rslot = (unsigned)((yc - (ty0 - R - 1)) * G::MWP + (xc - (tx0 - R - 1)));
+    // (read slot stored one tile row UP: the four neighbour reads of the ESM pass are then non-negative constant offsets from
+    // one address register -- DS instructions take no negative immediate, and l - 1 / l - MWP each held a register per round)
+    const unsigned rslot = (unsigned)((yc - (ty0 - R - 1) - 1) * G::MWP + (xc - (tx0 - R - 1)));
     slots[k] = rslot | (wslot << 16);
     unsigned fl = 0;
     if (e < G::NU) fl |= F_VALID;
@@ -1043,6 +1135,9 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
   const int zo_last = (z0 + a.zchunk - 1 < d.nz - 1) ? z0 + a.zchunk - 1 : d.nz - 1;
   const int ze = zo_last + R;
   const int nsteps = ze - zs + 1;
+  constexpr bool SYNC = (PP_SOFTSYNC != 0) && MASK;
+  pp_softsync ysync{};
+  if constexpr (SYNC) pp_softsync_init(ysync, a, a.sync_other);
 
   float bm = 0.0f, bf = 0.0f;          // border ring values of the plane about to be published
   float min_[G::KU], fin_[G::KU];      // plane two ahead of the window centre, in flight
@@ -1113,8 +1208,8 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
       const bool full_round = (k + 1) * NTH <= G::NU;
       const bool valid = full_round || (fl & F_VALID);
       if (full_round || __any(valid)) {
-        const int l = (int)(slots[k] & 0xffffu);
-        const float2 xm = s_mf[l - 1], xp = s_mf[l + 1], ym = s_mf[l - G::MWP], yp = s_mf[l + G::MWP];
+        const float2* const lp = s_mf + (slots[k] & 0xffffu);   // (the slot one row up, see the setup)
+        const float2 xm = lp[G::MWP - 1], xp = lp[G::MWP + 1], ym = lp[0], yp = lp[2 * G::MWP];
         const unsigned flb = pp_opaque(fl);   // (predicates formed here: hoisted, they would hold six scalar registers per voxel)
         const float mmax = fmaxf(fmaxf(fmaxf(xm.x, xp.x), fmaxf(ym.x, yp.x)), fmaxf(fmaxf(mprev[k], mnext[k]), mcur[k]));
         const bool plain = !valid || (((flb & (F_XLO | F_XHI | F_YLO | F_YHI)) == 0u) & (mmax < FLT_MAX));
@@ -1149,8 +1244,8 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
     for (int k = 0; k < G::KU; ++k) {
       const unsigned fl = uflag[k] >> 16;
       if ((k + 1) * NTH <= G::NU || (fl & F_VALID)) {
-        const int l = (int)(slots[k] & 0xffffu);
-        const float2 xm = s_mf[l - 1], xp = s_mf[l + 1], ym = s_mf[l - G::MWP], yp = s_mf[l + G::MWP];
+        const float2* const lp = s_mf + (slots[k] & 0xffffu);   // (the slot one row up, see the setup)
+        const float2 xm = lp[G::MWP - 1], xp = lp[G::MWP + 1], ym = lp[0], yp = lp[2 * G::MWP];
         const unsigned flb = pp_opaque(fl);   // (predicates formed here: hoisted, they would hold six scalar registers per voxel)
         const float hfx = (flb & (F_XLO | F_XHI)) ? 0.0f : 0.5f * K.ix, hfy = (flb & (F_YLO | F_YHI)) ? 0.0f : 0.5f * K.iy;
         const float gx = pp_esm_axis_data(xm.y, xp.y, mcur[k], xm.x, xp.x, hfx, K.ix);
@@ -1268,6 +1363,8 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
     const int zo = zi - R;
     const bool emit = ST || ((zo >= z0) && (zo <= zo_last) && out_ok);
     PP_TRACE_MARK(trace_on, 0, n, 0);
+    PP_DRIFT_MARK(0, n, nsteps);
+    if constexpr (SYNC) ysync.seen = pp_sync_peek(ysync.word);   // (consumed at the end of the step)
     // ---- interval 1: x pass of plane `cur` (s_u -> s_x) | publish the image tile of plane `nxt` ----
     if (fresh_next) publish();
     if (fresh_cur) fused2_xpass<R, NXI, 3 * G::XI>(s_u, s_x, a.wx, xsrc, xdst);
@@ -1352,6 +1449,7 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
     }
     if constexpr (SUM) load_dsum(zo + 1, steady_tag);
     PP_TRACE_MARK(trace_on, 0, n, 3);
+    if constexpr (SYNC) pp_softsync_step(ysync, n);
     if (fresh_cur || fresh_next) __syncthreads();
     PP_TRACE_MARK(trace_on, 0, n, 4);
   };
@@ -1363,6 +1461,7 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
   auto step_general = [&](int n, auto phase_tag) { step(n, phase_tag, pp_steady<false>{}); };
   fused2_plane_loop<R, UNROLL>(step_general, nsteps);
 #endif
+  if constexpr (SYNC) pp_softsync_finish(ysync, nsteps, a.zchunk + 2 * R);
   double r_ssd = (double)a_ssd, r_ssc = (double)a_ssc, r_n = (double)a_n;
   pp_block_sum3_shfl<NTH>(r_ssd, r_ssc, r_n, reinterpret_cast<double*>(s_u));
   if (t == 0) {

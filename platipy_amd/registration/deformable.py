@@ -133,8 +133,14 @@ class HipDemonsFilter:
         f, m = as_image(fixed_image), as_image(moving_image)
         if f.GetSize() != m.GetSize():
             raise ValueError("demons: fixed and moving image must be on the same grid (reference deformable.py:210-211)")
-        if f.direction != (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0):
-            raise NotImplementedError("demons: only identity direction cosines are supported")
+        # Direction cosines other than the identity (axis flips, oblique acquisitions): sitk's filter takes them
+        # (deformable.py:149 hands it whatever grid the pyramid has).  Both images are on ONE grid, so in that grid's
+        # index-aligned frame the iteration is the identity-direction one on the same voxel arrays -- the image gradients,
+        # hence the update, rotate with the frame (|J| and the normaliser do not change), and the component-wise smoothing
+        # commutes with a constant rotation -- and the physical (LPS) field is R times the local one.
+        oriented = f.direction != _IDENTITY
+        if oriented and m.direction != f.direction:
+            raise ValueError("demons: fixed and moving image must be on the same grid (reference deformable.py:210-211)")
         ctx = runtime.context(f.device)
         ft = (f.tensor if f.tensor.dtype == torch.float32 else f.tensor.float()).contiguous()
         mt = (m.tensor if m.tensor.dtype == torch.float32 else m.tensor.float()).contiguous()
@@ -161,7 +167,10 @@ class HipDemonsFilter:
         self._pending = None
         # (the ring holds PP_HIST_CAP = 4096 iterations; beyond that, and with observers, the measurements are read back here)
         lazy = not self._commands and 0 < self._iterations <= 4096
-        final = ctx.demons_execute(ft, mt, f.geom(), p, field, want_stats=not lazy)
+        geom = Image(ft, f.spacing, f.origin, _IDENTITY).geom() if oriented else f.geom()
+        final = ctx.demons_execute(ft, mt, geom, p, field, want_stats=not lazy)
+        if oriented:
+            field = _rotate_field(field, f.direction)
         if self._commands:
             history = ctx.demons_history()
             for k, (metric, rms) in enumerate(history):
@@ -181,6 +190,41 @@ class HipDemonsFilter:
         return to_sitk(out) if wants_sitk else out
 
 
+_IDENTITY = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
+
+
+def _rotate_field(field, direction, transpose=False):
+    """R (or R^T) applied to the three components of a planar field tensor [3, Z, Y, X]."""
+    R = torch.tensor(direction, dtype=field.dtype, device=field.device).reshape(3, 3)
+    return torch.einsum("rc,czyx->rzyx", R.t() if transpose else R, field).contiguous()
+
+
+def _local_frame(fixed_image, moving_image, initial_displacement_field=None):
+    """The images (and an initial field) in the fixed image's index-aligned frame, q_local = R^T (q - o_f) + o_f: every
+    index map is unchanged, an image whose own origin differs from the fixed one's sits at R^T (o - o_f) + o_f there, and a
+    physical displacement d becomes R^T d.  Every stage of the registration is linear in the field and all pyramid grids
+    share one origin and one direction, so the run in this frame is the same computation; its field is rotated back by R."""
+    true_direction = fixed_image.direction
+    if moving_image.direction != true_direction:
+        raise NotImplementedError("demons: fixed and moving image must share their direction cosines")
+    Rm = np.asarray(true_direction, dtype=np.float64).reshape(3, 3)
+    o_f = np.asarray(fixed_image.origin, dtype=np.float64)
+
+    def local_origin(o):
+        return tuple(Rm.T @ (np.asarray(o, dtype=np.float64) - o_f) + o_f)
+
+    moving_l = Image(moving_image.tensor, moving_image.spacing, local_origin(moving_image.origin), _IDENTITY)
+    fixed_l = Image(fixed_image.tensor, fixed_image.spacing, fixed_image.origin, _IDENTITY)
+    field_l = None
+    if initial_displacement_field is not None:
+        f0 = as_image(initial_displacement_field)
+        if f0.direction != true_direction:
+            raise NotImplementedError("demons: the initial displacement field must share the images' direction cosines")
+        field_l = Image(_rotate_field(f0.tensor.float(), true_direction, transpose=True), f0.spacing, local_origin(f0.origin),
+                        _IDENTITY, True)
+    return fixed_l, moving_l, field_l
+
+
 def _zero_field(reference):
     return Image(torch.zeros((3,) + reference.shape, dtype=torch.float32, device=reference.device), reference.spacing,
                  reference.origin, reference.direction, True)
@@ -192,6 +236,17 @@ def multiscale_demons(registration_algorithm, fixed_image, moving_image, initial
     """Run `registration_algorithm` coarse-to-fine (reference deformable.py:31-187).  Any object with
     SetNumberOfIterations / Execute(fixed, moving) -> vector Image / GetStandardDeviations works."""
     fixed_image, moving_image = as_image(fixed_image), as_image(moving_image)
+    if fixed_image.direction != _IDENTITY:
+        # a direct call with oriented images (fast_symmetric_forces_demons_registration converts before it calls): the loop
+        # in the index-aligned frame, the field rotated back to physical components
+        if initial_transform is not None:
+            raise NotImplementedError("multiscale_demons: initial_transform with non-identity direction cosines; pass its "
+                                      "displacement field as initial_displacement_field")
+        true_direction = fixed_image.direction
+        f_l, m_l, d_l = _local_frame(fixed_image, moving_image, initial_displacement_field)
+        out = multiscale_demons(registration_algorithm, f_l, m_l, None, d_l, isotropic_resample, resolution_staging,
+                                smoothing_sigmas, iteration_staging, interp_order)
+        return Image(_rotate_field(out.tensor, true_direction), out.spacing, out.origin, true_direction, True)
     ctx = runtime.context(fixed_image.device)
     fixed_images, moving_images = [], []
     for resolution, smoothing_sigma in zip(resolution_staging, smoothing_sigmas):
@@ -261,28 +316,10 @@ def fast_symmetric_forces_demons_registration(
     fixed_image = fixed_image.astype(torch.float32)    # :236-241 (quirk N1: everything computes in float32)
     moving_image = moving_image.astype(torch.float32)
 
-    identity = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
+    identity = _IDENTITY
     true_direction = fixed_image.direction
     if true_direction != identity:
-        if moving_image.direction != true_direction:
-            raise NotImplementedError("demons: fixed and moving image must share their direction cosines")
-        # work in the fixed image's index-aligned frame, q_local = R^T (q - o_f) + o_f: every index map is unchanged, and
-        # an image whose own origin differs from the fixed one's sits at R^T (o - o_f) + o_f there
-        Rm = np.asarray(true_direction, dtype=np.float64).reshape(3, 3)
-        o_f = np.asarray(fixed_image.origin, dtype=np.float64)
-
-        def local_origin(o):
-            return tuple(Rm.T @ (np.asarray(o, dtype=np.float64) - o_f) + o_f)
-
-        moving_image = Image(moving_image.tensor, moving_image.spacing, local_origin(moving_image.origin), identity)
-        fixed_image = Image(fixed_image.tensor, fixed_image.spacing, fixed_image.origin, identity)
-        if initial_displacement_field is not None:
-            f0 = as_image(initial_displacement_field)
-            if f0.direction != true_direction:
-                raise NotImplementedError("demons: the initial displacement field must share the images' direction cosines")
-            Rt = torch.tensor(true_direction, dtype=torch.float32, device=f0.device).reshape(3, 3).t()
-            initial_displacement_field = Image(torch.einsum("rc,czyx->rzyx", Rt, f0.tensor.float()).contiguous(), f0.spacing,
-                                               local_origin(f0.origin), identity, True)
+        fixed_image, moving_image, initial_displacement_field = _local_frame(fixed_image, moving_image, initial_displacement_field)
 
     registration_method = HipDemonsFilter(variant=variant)
     registration_method.SetNumberOfThreads(ncores)
@@ -316,8 +353,7 @@ def fast_symmetric_forces_demons_registration(
     registered_image = resample_image(moving_image, fixed_image, output_transform, interp_order, default_value)
     registered_image = registered_image.like(cast_tensor(registered_image.tensor, moving_image_type))
     if true_direction != identity:
-        R = torch.tensor(true_direction, dtype=torch.float32, device=deformation_field.device).reshape(3, 3)
-        phys = torch.einsum("rc,czyx->rzyx", R, deformation_field.tensor).contiguous()
+        phys = _rotate_field(deformation_field.tensor, true_direction)
         deformation_field = Image(phys, deformation_field.spacing, deformation_field.origin, true_direction, True)
         output_transform = DisplacementFieldTransform(deformation_field)
         registered_image = Image(registered_image.tensor, registered_image.spacing, registered_image.origin, true_direction)

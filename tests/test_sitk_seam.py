@@ -148,3 +148,62 @@ def test_integration_md_section_2_snippet_runs(host_api, sitk):
     dvf = _multiscale_loop(sitk, registration_method, _sitk_image(sitk, fix, sp, org), _sitk_image(sitk, mov, sp, org), [2, 1], [4, 4])
     a = sitk.GetArrayFromImage(dvf)
     assert a.shape == shape + (3,) and a.dtype == np.float64 and np.isfinite(a).all() and np.abs(a).max() > 0.05
+
+
+def _oriented_cases():
+    ang = 0.3
+    c, s = np.cos(ang), np.sin(ang)
+    return {"x_flipped": (-1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0),
+            "oblique": (c, 0.0, s, 0.0, 1.0, 0.0, -s, 0.0, c)}          # tilted about y, like a gantry-tilted series
+
+
+@pytest.mark.parametrize("case", ["x_flipped", "oblique"])
+def test_hip_filter_takes_oriented_sitk_images(host_api, sitk, case):
+    """Seam 2 with non-identity direction cosines (missing 4): sitk's filter at deformable.py:149 takes any
+    direction, so a maintainer who swaps only the filter must not meet an exception on an oblique CT.  The field that comes
+    back is physical (LPS) on the fixed grid: R times the field of the identity-direction run on the same voxel arrays --
+    checked against the ORACLE's Execute (not against the product's own identity run), the sitk loop around it included."""
+    pa = host_api
+    from oracle import oracle as O
+
+    direction = _oriented_cases()[case]
+    R = np.array(direction).reshape(3, 3)
+    shape, sp, org = (16, 24, 40), (1.0, 1.1, 2.0), (10.0, -20.0, 5.0)
+    fix, mov = _pair(shape, sp, org)
+    fi, mi = _sitk_image(sitk, fix, sp, org), _sitk_image(sitk, mov, sp, org)
+    fi.SetDirection(direction)
+    mi.SetDirection(direction)
+    flt = pa.registration.HipDemonsFilter()
+    flt.SetSmoothUpdateField(True)
+    flt.SetSmoothDisplacementField(True)
+    flt.SetStandardDeviations([1.5 / s for s in sp])
+    flt.SetNumberOfIterations(4)
+    out = flt.Execute(fi, mi)
+    assert type(out).__module__.startswith("SimpleITK") and out.GetPixelID() == sitk.sitkVectorFloat64
+    assert out.GetSize() == fi.GetSize() and out.GetSpacing() == sp and out.GetOrigin() == org
+    np.testing.assert_allclose(out.GetDirection(), direction, rtol=0, atol=0)
+    got = np.moveaxis(sitk.GetArrayFromImage(out), -1, 0)
+    # the oracle's Execute on the same voxel arrays in the index-aligned frame, rotated to physical components
+    orc = O.DemonsFilter()
+    orc.SetSmoothUpdateField(True)
+    orc.SetSmoothDisplacementField(True)
+    orc.SetStandardDeviations([1.5 / s for s in sp])
+    orc.SetNumberOfIterations(4)
+    local = orc.Execute(O.Vol(fix, sp, org), O.Vol(mov, sp, org)).arr
+    want = np.einsum("rc,czyx->rzyx", R, local)
+    err = np.abs(got - want)
+    assert err.max() <= 2e-3 and np.sqrt((err ** 2).mean()) <= 5e-5, (err.max(), np.sqrt((err ** 2).mean()))   # test_demons_execute's bounds
+    assert flt.GetElapsedIterations() == orc.GetElapsedIterations() and np.abs(want).max() > 0.1
+    # different grids are still refused, as the reference's docstring demands (deformable.py:210-211)
+    other = _sitk_image(sitk, mov, sp, org)
+    with pytest.raises(ValueError):
+        flt.Execute(fi, other)
+    # the product's own multiscale_demons, called directly with oriented images, returns the physical field of the
+    # identity-direction run as well
+    kw = dict(resolution_staging=[2, 1], smoothing_sigmas=[2, 1], iteration_staging=[3, 3])
+    d0 = pa.registration.multiscale_demons(registration_algorithm=flt, fixed_image=pa.image_from_array(fix, sp, org),
+                                           moving_image=pa.image_from_array(mov, sp, org), **kw)
+    d1 = pa.registration.multiscale_demons(registration_algorithm=flt, fixed_image=pa.image_from_array(fix, sp, org, direction),
+                                           moving_image=pa.image_from_array(mov, sp, org, direction), **kw)
+    assert d1.direction == direction
+    np.testing.assert_allclose(d1.numpy(), np.einsum("rc,czyx->rzyx", R, d0.numpy().astype(np.float64)), rtol=0, atol=1e-5)

@@ -162,6 +162,38 @@ int main(int argc, char** argv) {
     fflush(stdout);
     for (auto& k : keys) unsetenv(k.c_str());
   }
+  // -DPP_DRIFT builds: 100 MHz wall-clock stamps of every block at the quarter points of its march (the last launch of each
+  // kernel): how far apart are the blocks that share an L2?  Spread = newest - oldest stamp over the blocks of one XCD
+  // (block b -> XCD b % 8), in microseconds and in plane steps of that kernel.
+  if (auto drift_read = reinterpret_cast<int (*)(unsigned long long*, int)>(dlsym(h, "pp_debug_drift_read"))) {
+    std::vector<unsigned long long> buf(2 * 1024 * 4);
+    if (drift_read(buf.data(), (int)buf.size()) > 0) {
+      for (int k = 0; k < 2; ++k) {
+        double step_us = 0.0; int nb = 0;
+        for (int b = 0; b < 1024; ++b) {
+          const unsigned long long* e = &buf[((size_t)k * 1024 + b) * 4];
+          if (e[0] && e[3] > e[0]) { step_us += 0.01 * (double)(e[3] - e[0]); ++nb; }
+        }
+        if (!nb) continue;
+        step_us /= nb;   // mean time from the first to the last quarter mark = 3/4 of a march
+        printf("drift kernel %c: %d blocks, first-to-last quarter mark %.1f us\n", k ? 'B' : 'A', nb, step_us);
+        for (int x = 0; x < 8; ++x) {
+          printf("  xcd %d:", x);
+          for (int q = 0; q < 4; ++q) {
+            unsigned long long lo = ~0ull, hi = 0;
+            for (int b = x; b < 1024; b += 8) {
+              const unsigned long long v = buf[((size_t)k * 1024 + b) * 4 + q];
+              if (!v) continue;
+              if (v < lo) lo = v;
+              if (v > hi) hi = v;
+            }
+            printf(" q%d spread %.2f us", q, hi >= lo ? 0.01 * (double)(hi - lo) : -1.0);
+          }
+          printf("\n");
+        }
+      }
+    }
+  }
   // -DPP_TRACE builds: per-wave shader-clock stamps at the plane loop's barriers (one interior block per kernel)
   if (auto trace_read = reinterpret_cast<int (*)(unsigned*, int)>(dlsym(h, "pp_debug_trace_read"))) {
     const int STEPS = 140, SLOTS = 6;
