@@ -286,6 +286,15 @@ int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, con
                                 const int vsize[3], int stride, const uint8_t* fixed_mask,
                                 const uint8_t* moving_mask, double* result);
 
+/* ITK's sample-point jitter for every metric entry point of this section (registration.SetMetricSamplingPercentage(rate,
+ * seed=42) + SetMetricSamplingStrategy(REGULAR), registration/linear.py:151-152): itk::ImageRegistrationMethodv4 perturbs each
+ * REGULAR sample point by a seeded normal variate times a third of the virtual spacing per axis.  `jitter` (device, caller-owned,
+ * must stay valid until replaced): 3 floats per sample of the raster walk, in VIRTUAL-INDEX units, added to the sample's lattice
+ * index before the fixed and moving maps are applied; `nsamples` its length in samples (>= the lattice's sample count of every
+ * later call, else that call fails).  NULL / 0 restores the plain lattice (the default).  The host draws the variates
+ * (platipy_amd/registration/linear.py, itk_sampling=True). */
+int pp_linear_set_sample_jitter(pp_ctx* ctx, const float* jitter, size_t nsamples);
+
 /* Mutual-information metrics (SetMetricAsMattesMutualInformation / SetMetricAsJointHistogramMutualInformation,
  * registration/linear.py:145-148) over the same sample lattice: pass 1 returns the joint intensity histogram of the valid
  * sample pairs (row = fixed bin; 64-bit fixed-point accumulation, independent of scheduling) and their count; the caller

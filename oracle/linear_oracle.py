@@ -44,13 +44,15 @@ def _nn_mask(mask, c):
     return mask[q[:, 2], q[:, 1], q[:, 0]] != 0
 
 
-def meansq_affine(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None):
+def meansq_affine(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None, jitter=None):
     """-> 14 floats: sum (f-m)^2, count, d/dAm (row-major 9), d/dbm (3)."""
     Af, Am = np.asarray(Af, dtype=np.float64).reshape(3, 3), np.asarray(Am, dtype=np.float64).reshape(3, 3)
     bf, bm = np.asarray(bf, dtype=np.float64), np.asarray(bm, dtype=np.float64)
     nv = int(vsize[0]) * int(vsize[1]) * int(vsize[2])
     lin = np.arange(0, nv, int(stride), dtype=np.int64)
     v = np.stack([lin % vsize[0], (lin // vsize[0]) % vsize[1], lin // (vsize[0] * vsize[1])], axis=1).astype(np.float64)
+    if jitter is not None:      # ITK's perturbed sample points (itk_regular_jitter), virtual-index units
+        v = v + np.asarray(jitter, dtype=np.float64)[:len(v)]
     cf, cm = v @ Af.T + bf, v @ Am.T + bm
     inf_, fval, _ = _sample(np.asarray(fixed), cf)
     inm, mval, g = _sample(np.asarray(moving), cm)
@@ -69,13 +71,15 @@ def meansq_affine(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask=None,
     return out
 
 
-def corr_moments_affine(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None):
+def corr_moments_affine(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None, jitter=None):
     """-> the 42 raw moments pp_corr_moments_affine_f32 accumulates (layout in include/platipy_amd.h)."""
     Af, Am = np.asarray(Af, dtype=np.float64).reshape(3, 3), np.asarray(Am, dtype=np.float64).reshape(3, 3)
     bf, bm = np.asarray(bf, dtype=np.float64), np.asarray(bm, dtype=np.float64)
     nv = int(vsize[0]) * int(vsize[1]) * int(vsize[2])
     lin = np.arange(0, nv, int(stride), dtype=np.int64)
     v = np.stack([lin % vsize[0], (lin // vsize[0]) % vsize[1], lin // (vsize[0] * vsize[1])], axis=1).astype(np.float64)
+    if jitter is not None:      # ITK's perturbed sample points (itk_regular_jitter), virtual-index units
+        v = v + np.asarray(jitter, dtype=np.float64)[:len(v)]
     cf, cm = v @ Af.T + bf, v @ Am.T + bm
     inf_, fval, _ = _sample(np.asarray(fixed), cf)
     inm, mval, g = _sample(np.asarray(moving), cm)
@@ -108,12 +112,14 @@ def _bspline3_deriv(u):
     return np.where(a < 1.0, sg * (-2.0 * a + 1.5 * a * a), np.where(a < 2.0, sg * (-0.5 * (2.0 - a) ** 2), 0.0))
 
 
-def _mi_samples(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask):
+def _mi_samples(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask, jitter=None):
     Af, Am = np.asarray(Af, dtype=np.float64).reshape(3, 3), np.asarray(Am, dtype=np.float64).reshape(3, 3)
     bf, bm = np.asarray(bf, dtype=np.float64), np.asarray(bm, dtype=np.float64)
     nv = int(vsize[0]) * int(vsize[1]) * int(vsize[2])
     lin = np.arange(0, nv, int(stride), dtype=np.int64)
     v = np.stack([lin % vsize[0], (lin // vsize[0]) % vsize[1], lin // (vsize[0] * vsize[1])], axis=1).astype(np.float64)
+    if jitter is not None:      # ITK's perturbed sample points (itk_regular_jitter), virtual-index units
+        v = v + np.asarray(jitter, dtype=np.float64)[:len(v)]
     cf, cm = v @ Af.T + bf, v @ Am.T + bm
     inf_, fval, _ = _sample(np.asarray(fixed), cf)
     inm, mval, g = _sample(np.asarray(moving), cm)
@@ -131,9 +137,9 @@ def _mi_bins(val, width, norm_min, lo, hi):
     return np.clip(np.floor(term).astype(np.int64), lo, hi), term
 
 
-def mi_histogram(fixed, moving, Af, bf, Am, bm, vsize, stride, bins, fixed_mask=None, moving_mask=None):
+def mi_histogram(fixed, moving, Af, bf, Am, bm, vsize, stride, bins, fixed_mask=None, moving_mask=None, jitter=None):
     """bins: dict(nbins, kernel (0 Mattes / 1 joint), f_bin, f_norm_min, m_bin, m_norm_min) -> (hist [nb, nb], count)."""
-    v, f, m, _ = _mi_samples(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask)
+    v, f, m, _ = _mi_samples(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask, jitter)
     nb, pad = int(bins["nbins"]), (2 if bins["kernel"] == 0 else 0)
     fb, _ = _mi_bins(f, bins["f_bin"], bins["f_norm_min"], pad, nb - 1 - pad)
     mb, tm = _mi_bins(m, bins["m_bin"], bins["m_norm_min"], pad, nb - 1 - pad)
@@ -146,8 +152,8 @@ def mi_histogram(fixed, moving, Af, bf, Am, bm, vsize, stride, bins, fixed_mask=
     return hist, float(len(f))
 
 
-def mi_gradient(fixed, moving, Af, bf, Am, bm, vsize, stride, bins, table, fixed_mask=None, moving_mask=None):
-    v, f, m, g = _mi_samples(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask)
+def mi_gradient(fixed, moving, Af, bf, Am, bm, vsize, stride, bins, table, fixed_mask=None, moving_mask=None, jitter=None):
+    v, f, m, g = _mi_samples(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask, jitter)
     nb, pad = int(bins["nbins"]), (2 if bins["kernel"] == 0 else 0)
     tab = np.asarray(table, dtype=np.float64).astype(np.float32).astype(np.float64)
     fb, _ = _mi_bins(f, bins["f_bin"], bins["f_norm_min"], pad, nb - 1 - pad)
@@ -159,3 +165,81 @@ def mi_gradient(fixed, moving, Af, bf, Am, bm, vsize, stride, bins, table, fixed
         w = tab[fb, k0 + 1] - tab[fb, k0]
     gw = g.astype(np.float32).astype(np.float64) * w[:, None]
     return np.concatenate([(gw[:, :, None] * v[:, None, :]).sum(0).ravel(), gw.sum(0)])
+
+
+# ---- ITK's seeded sample jitter (itk_sampling=True) -----------------------------------------------------------------------
+# registration.SetMetricSamplingPercentage(sampling_rate, seed=42) + SetMetricSamplingStrategy(REGULAR)
+# (platipy/imaging/registration/linear.py:151-152) -> itk::ImageRegistrationMethodv4::SetMetricSamplePoints: the virtual domain is
+# walked in raster order, every ceil(1/rate)-th voxel becomes a sample point, and each coordinate of its PHYSICAL point is
+# perturbed by m_Randomizer->GetNormalVariate() * virtualSpacing[d] / 3.  The randomizer is an
+# itk::Statistics::MersenneTwisterRandomVariateGenerator seeded once (MetricSamplingReinitializeSeed), so the levels of a
+# registration draw from ONE stream, one after the other.  Restated from the published MT19937 reference (Matsumoto &
+# Nishimura, init_genrand / genrand_int32) and my reading of ITK 5.3's generator (recollection, PARITY UNPINNED):
+#   GetVariateWithOpenRange()      = (int32 + 0.5) / 2^32          GetVariateWithOpenUpperRange() = int32 / 2^32
+#   GetNormalVariate(0, 1)         = sqrt(-2 ln(1 - open)) * cos(2 pi upper)      (Box-Muller; `open` is drawn first)
+class MersenneTwister:
+    """MT19937, 32-bit outputs, seeded by init_genrand(seed) as itk::Statistics::MersenneTwisterRandomVariateGenerator::Initialize."""
+
+    N, M = 624, 397
+
+    def __init__(self, seed):
+        st = np.zeros(self.N, dtype=np.uint64)
+        st[0] = np.uint64(int(seed) & 0xFFFFFFFF)
+        for i in range(1, self.N):
+            prev = int(st[i - 1])
+            st[i] = np.uint64((1812433253 * (prev ^ (prev >> 30)) + i) & 0xFFFFFFFF)
+        self.state = st
+        self.pos = self.N
+
+    def _twist(self, lo, hi):
+        """state[k] for k in [lo, hi) from state[k], state[k+1] (old) and state[(k+M) % N] (old for k < N-M, new above)."""
+        st = self.state
+        k = np.arange(lo, hi)
+        y = (st[k] & np.uint64(0x80000000)) | (st[(k + 1) % self.N] & np.uint64(0x7FFFFFFF))
+        st[k] = st[(k + self.M) % self.N] ^ (y >> np.uint64(1)) ^ np.where(y & np.uint64(1), np.uint64(0x9908B0DF), np.uint64(0))
+
+    def _reload(self):
+        n, m = self.N, self.M
+        self._twist(0, n - m)                 # reads old state[k + M]
+        self._twist(n - m, 2 * (n - m))       # reads state[k - (N - M)], already new
+        self._twist(2 * (n - m), n - 1)
+        self._twist(n - 1, n)                 # state[N-1] pairs with the NEW state[0]
+        self.pos = 0
+
+    def integers(self, count):
+        out = np.empty(count, dtype=np.uint64)
+        done = 0
+        while done < count:
+            if self.pos >= self.N:
+                self._reload()
+            take = min(count - done, self.N - self.pos)
+            y = self.state[self.pos:self.pos + take].copy()
+            self.pos += take
+            y ^= y >> np.uint64(11)
+            y ^= (y << np.uint64(7)) & np.uint64(0x9D2C5680)
+            y ^= (y << np.uint64(15)) & np.uint64(0xEFC60000)
+            y ^= y >> np.uint64(18)
+            out[done:done + take] = y & np.uint64(0xFFFFFFFF)
+            done += take
+        return out
+
+    def normal_variates(self, count):
+        """GetNormalVariate(0, 1) x count: two integers each, the radius' first."""
+        u = self.integers(2 * count).astype(np.float64)
+        r = np.sqrt(-2.0 * np.log(1.0 - (u[0::2] + 0.5) * (1.0 / 4294967296.0)))
+        phi = 2.0 * np.pi * (u[1::2] * (1.0 / 4294967296.0))
+        return r * np.cos(phi)
+
+
+def itk_regular_jitter(generator, vsize, stride, vspacing, vdirection=None):
+    """Jitter of one level's REGULAR sample points in VIRTUAL-INDEX units, [nsamples, 3] float64: three normal variates per
+    sample in raster order (axis 0, 1, 2), each times a third of the virtual spacing of that axis, added to the physical
+    point; index = inverse(direction * spacing) applied to that physical offset."""
+    nv = int(vsize[0]) * int(vsize[1]) * int(vsize[2])
+    nsamp = (nv + int(stride) - 1) // int(stride)
+    normals = generator.normal_variates(3 * nsamp).reshape(nsamp, 3)
+    sp = np.asarray(vspacing, dtype=np.float64)
+    phys = normals * (sp / 3.0)[None, :]
+    d = np.eye(3) if vdirection is None else np.asarray(vdirection, dtype=np.float64).reshape(3, 3)
+    p2i = np.linalg.inv(d * sp[None, :])
+    return phys @ p2i.T

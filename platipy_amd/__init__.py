@@ -6,8 +6,16 @@ Drop-in for the hot path of pyplati/platipy: `linear_registration`,
 every voxel-level operation runs in hand-written HIP kernels behind the C ABI of
 include/platipy_amd.h.  There is no CPU fallback.
 """
-from .image import Image, image_from_array, array_from_image  # noqa: F401
-from .transform import (  # noqa: F401
+import os as _os
+
+# One hardware queue per worker stream.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of
+# them the null stream's): with config 5's four atlas chains on four HIP streams two chains shared a queue and ran one after
+# the other -- 240 ms of a 269 ms span on that queue alone (profiles/round5_streams_timeline_before.md).  Read when the
+# runtime initialises the device, i.e. at the first CUDA call, which comes after this import; an explicit setting wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from .image import Image, image_from_array, array_from_image  # noqa: E402,F401
+from .transform import (  # noqa: E402,F401
     AffineTransform,
     CompositeTransform,
     DisplacementFieldTransform,

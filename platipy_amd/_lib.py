@@ -146,6 +146,7 @@ _SIGNATURES = {
     "pp_metric_values_affine_f32": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                               C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                               C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(C.c_double)]),
+    "pp_linear_set_sample_jitter": (C.c_int, [_P, _P, C.c_size_t]),
     "pp_mi_histogram_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(MiBins),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -454,6 +455,19 @@ class Context:
                                                        int(stride), ptr(fixed_mask), ptr(moving_mask), res.ctypes.data_as(dp)),
                   "pp_metric_values_affine_f32")
         return res
+
+    def set_sample_jitter(self, jitter):
+        """ITK's per-sample jitter for the metric entry points (pp_linear_set_sample_jitter): a contiguous float32 device
+        tensor [nsamples, 3] in virtual-index units, kept alive by this context until replaced; None restores the lattice."""
+        if jitter is None:
+            self._chk(self.lib.pp_linear_set_sample_jitter(self.h, None, 0), "pp_linear_set_sample_jitter")
+        else:
+            shape, dtype = tuple(jitter.shape), str(jitter.dtype).replace("torch.", "")
+            contiguous = jitter.is_contiguous() if hasattr(jitter, "is_contiguous") else jitter.flags["C_CONTIGUOUS"]
+            if len(shape) != 2 or shape[1] != 3 or dtype != "float32" or not contiguous:
+                raise ValueError("set_sample_jitter: a contiguous float32 array [nsamples, 3]")
+            self._chk(self.lib.pp_linear_set_sample_jitter(self.h, ptr(jitter), int(jitter.shape[0])), "pp_linear_set_sample_jitter")
+        self._sample_jitter = jitter
 
     def linear_optimize(self, fixed, fsize, moving, msize, level, params, fixed_mask=None, moving_mask=None, history=0):
         """One level of linear_registration's optimisation in the library (pp_linear_optimize_f32).

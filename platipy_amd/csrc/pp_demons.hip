@@ -445,8 +445,8 @@ struct fused_args {
   // rows are not whole 16-byte quads into padded rows once: strips are then 16-byte aligned and pairs 8-byte aligned for any
   // row length, and the MASK instances (which need pairs) serve odd row lengths too.  Padding is written, never read as data.
   int px;
-  // generation 2, PP_SOFTSYNC builds: progress counters of this kernel's launch (8 x 32 words, one cache line per XCD), the
-  // other kernel's set (cleared by this launch) and the allowed lead in plane steps (0: count only)
+  // generation 2, PP_SOFTSYNC builds: progress words of this kernel's launch (8 XCDs x 64 resident blocks), the other kernel's
+  // set (cleared by this launch) and the allowed lead in plane steps (0: publish only)
   unsigned* sync;
   unsigned* sync_other;
   int sync_lag;
@@ -1395,7 +1395,7 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   small_taps(td[1], rb, &fd.wy);
   small_taps(td[2], rb, &fd.wz);
   const size_t nblk = ((size_t)fu.gx * fu.gy + (size_t)fu.gx2 * fu.gy2) * fu.gz;
-  constexpr size_t SYNC_WORDS = 8 * 32;   // per kernel: one 128-byte line per XCD
+  constexpr size_t SYNC_WORDS = 8 * 64;   // per kernel: one word per resident block of each XCD (PP_SYNC_GROUP)
   const size_t need = (pitched ? 4 : 2) * pp_align_up(Np * 4, 256) + (pitched ? 3 : 2) * pp_align_up(3 * Np * 4, 256) +
                       2 * pp_align_up(3 * nblk * 8, 256) + 256 + pp_align_up(2 * SYNC_WORDS * sizeof(unsigned), 256);
   rc = pp_reserve(ctx, need);
@@ -1517,6 +1517,12 @@ int pp_debug_drift_read(unsigned long long* out, int cap) {
   const int n = 2 * 1024 * 4;
   if (cap < n) return -1;
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_drift_buf), sizeof(unsigned long long) * n) != hipSuccess) return -2;
+  return n;
+}
+int pp_debug_drift_xcc_read(unsigned* out, int cap) {
+  const int n = 2 * 1024;
+  if (cap < n) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_drift_xcc), sizeof(unsigned) * n) != hipSuccess) return -2;
   return n;
 }
 #endif

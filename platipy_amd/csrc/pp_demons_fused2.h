@@ -539,6 +539,15 @@ struct pp_steady_unroll<W, W> {
 #ifndef PP_A_VOTE
 #define PP_A_VOTE 1
 #endif
+#ifndef PP_A_ESM_PAIRS
+#define PP_A_ESM_PAIRS 1
+#endif
+#ifndef PP_A_FLIP
+#define PP_A_FLIP 1
+#endif
+#ifndef PP_B_FLIP
+#define PP_B_FLIP 1
+#endif
 #ifndef PP_B_FINISH_AFTER_BARRIER
 #define PP_B_FINISH_AFTER_BARRIER 1
 #endif
@@ -564,79 +573,94 @@ __device__ __forceinline__ void fused2_plane_loop3(F& step, int nsteps, int s_lo
 // ---- Round 5: soft synchronisation of the blocks that share an L2 -------------------------------------------------------
 // The x/y halo of a tile (two 16-byte strips a row in x, 2R rows in y) lies in cache lines that belong to the NEIGHBOUR tiles:
 // a block finds them in its XCD's L2 only while the neighbour's march is within a plane or two of its own (4 MB of L2 see
-// ~1-2 MB of traffic per plane step of the 64 resident blocks).  Nothing keeps them there: the blocks start together and then
-// drift with every HBM-channel conflict, and the measured fetch of kernel B swings between 1.13 and 1.6 x its compulsory
-// reads with launch timing (profiles/round4_pmc_fetch_by_variant.txt).  With PP_SOFTSYNC the blocks of one XCD (block b runs on
-// XCD b % 8, the assumption the tile order already makes -- speed only) count their finished plane steps into one word, and a
-// block starts step n + 1 only when the group's MEAN progress has reached n + 1 - lag: the leaders wait a little, nobody else.
-// The wait is bounded (a group that is not co-resident, or an XCD mapping that differs, costs one time-out per block and
-// switches the block's synchronisation off), so no launch can hang on it.  One wave per block polls; the word it reads was
-// requested a whole step earlier.
+// ~1-2 MB of traffic per plane step of the 64 resident blocks).  Nothing keeps them there: measured with -DPP_DRIFT, the 64
+// blocks of an XCD are spread over 45 (kernel A) to 70 (kernel B) plane steps of a 132-step march (the two blocks of a CU do
+// not share it evenly), and kernel B's fetch swings between 1.13 and 1.6 x its compulsory reads with launch timing.
+// With PP_SOFTSYNC each block of an XCD (block b runs on XCD b % 8, the assumption the tile order already makes -- speed
+// only) publishes the number of plane steps it has finished in a word of its own, and starts step n + 1 only when EVERY
+// block of its group has finished step n + 1 - lag: the leaders wait, nobody else.
+//   * Plain stores and L1-bypassing loads (workgroup scope: `global_store / global_load sc0`), both served by the XCD's own
+//     L2.  Not atomics: on this part a device atomic is executed beyond the L2 and takes microseconds, and since a wave's
+//     memory instructions retire in issue order every younger load of the step waited behind it -- the first two versions
+//     (one counter per XCD, agent- and workgroup-scope fetch_add) ran the kernels 2.7-4 x slower (profiles/round5_softsync.md).
+//   * The wait is bounded: a group that is not co-resident, or a dispatcher that spreads a group over XCDs (whose L2s would
+//     then each see their own blocks' words only), costs one time-out per block and switches that block's waiting off.
+//     Slower, never wrong, and no launch can hang on it.
+//   * One wave per block does all of it; the words it tests were requested a whole step earlier.
 #ifndef PP_SOFTSYNC
 #define PP_SOFTSYNC 0
 #endif
 #ifndef PP_SOFTSYNC_TRIES
 #define PP_SOFTSYNC_TRIES 24
 #endif
+constexpr unsigned PP_SYNC_GROUP = 64;      // words per XCD: one per resident block (2 blocks x 32 CUs)
+constexpr unsigned PP_SYNC_DONE = 0x40000000u;
 struct pp_softsync {
-  unsigned* word;    // this XCD's progress counter (a cache line of its own)
-  unsigned group;    // blocks that count into it
-  unsigned seen;     // the counter as last read
-  int lag;           // <= 0: count only
-  bool wave0;        // this wave polls and counts for its block (wave-uniform, held in a scalar register)
+  unsigned* words;   // this XCD's PP_SYNC_GROUP progress words
+  unsigned* mine;    // this block's word
+  const unsigned* peek_at;   // the word this LANE watches (wave 0: lane l watches block l of the group)
+  unsigned seen;     // ... as last read
+  int lag;           // <= 0: publish only
+  bool wave0;        // this wave publishes and waits for its block (wave-uniform, held in scalar registers)
 };
-// Scope: every block of a group runs on ONE XCD, whose L2 is the coherence point of its CUs -- so the counter is read with
-// the vector cache bypassed and nothing more (workgroup scope: `global_load sc0`, an L2 hit), and counted by an atomic the same
-// L2 executes.  An agent-scope read (`sc1`) is served from beyond the L2, microseconds away, and since a wave's loads retire
-// in issue order every younger load of the step waited behind it: the first version of this ran the kernels 4 x slower
-// (profiles/round5_softsync.md).  If the dispatcher ever spread a group over XCDs the L2s would each count their own blocks
-// only and the waits would time out -- slower, never wrong.
-#ifndef PP_SOFTSYNC_SCOPE
-#define PP_SOFTSYNC_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#ifndef PP_SOFTSYNC_LOAD_SCOPE
+#define PP_SOFTSYNC_LOAD_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
 #endif
-__device__ __forceinline__ unsigned pp_sync_peek(const unsigned* w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, PP_SOFTSYNC_SCOPE); }
+#ifndef PP_SOFTSYNC_STORE_SCOPE
+#define PP_SOFTSYNC_STORE_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
+__device__ __forceinline__ unsigned pp_sync_peek(const unsigned* w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, PP_SOFTSYNC_LOAD_SCOPE); }
 __device__ __forceinline__ void pp_softsync_init(pp_softsync& y, const fused_args& a, unsigned* other_set) {
-  const unsigned xcd = blockIdx.x & 7u;
+  const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
   const unsigned ntiles = ((unsigned)a.gx * a.gy + (unsigned)a.gx2 * a.gy2) * (unsigned)a.gz;
   const unsigned first = xcd * (unsigned)a.per_xcd;
-  y.word = a.sync + xcd * 32u;
-  y.group = ntiles > first ? (ntiles - first < (unsigned)a.per_xcd ? ntiles - first : (unsigned)a.per_xcd) : 0u;
+  const unsigned group = ntiles > first ? (ntiles - first < (unsigned)a.per_xcd ? ntiles - first : (unsigned)a.per_xcd) : 0u;
+  y.words = a.sync + xcd * PP_SYNC_GROUP;
+  y.mine = y.words + (j < PP_SYNC_GROUP ? j : 0u);
+  const unsigned lane = threadIdx.x & 63u;
+  y.peek_at = (lane < group && lane < PP_SYNC_GROUP) ? y.words + lane : y.mine;
   y.seen = 0u;
-  y.lag = a.sync_lag;
+  y.lag = (group <= PP_SYNC_GROUP && j < PP_SYNC_GROUP) ? a.sync_lag : 0;
   y.wave0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64;
-  // the OTHER kernel's counters are idle while this launch runs: clear them for its next launch
-  if (blockIdx.x < 8u && threadIdx.x == 0) __hip_atomic_store(other_set + blockIdx.x * 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the OTHER kernel's words are idle while this launch runs: clear this block's for that kernel's next launch
+  if (threadIdx.x == 0 && j < PP_SYNC_GROUP) __hip_atomic_store(other_set + xcd * PP_SYNC_GROUP + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// Start of a plane step: request the group's words (consumed at the end of the step).
+__device__ __forceinline__ void pp_softsync_peek(pp_softsync& y) {
+  if (y.wave0) y.seen = pp_sync_peek(y.peek_at);
 }
 // End of plane step n (0-based) of a block, ahead of the barrier that closes the step; every wave calls it, wave 0 acts.
 __device__ __forceinline__ void pp_softsync_step(pp_softsync& y, int n) {
   if (y.wave0) {
-    if (y.lag > 0) {
-      const int need = (int)y.group * (n + 1 - y.lag);
-      unsigned seen = (unsigned)__builtin_amdgcn_readfirstlane((int)y.seen);
-      if ((int)seen < need) {
+    if (threadIdx.x == 0) __hip_atomic_store(y.mine, (unsigned)(n + 1), __ATOMIC_RELAXED, PP_SOFTSYNC_STORE_SCOPE);
+    if (y.lag > 0 && n + 1 > y.lag) {
+      const unsigned need = (unsigned)(n + 1 - y.lag);
+      if (__any(y.seen < need)) {
         int tries = 0;
+        bool behind;
         do {
           __builtin_amdgcn_s_sleep(4);
-          seen = (unsigned)__builtin_amdgcn_readfirstlane((int)pp_sync_peek(y.word));
-        } while ((int)seen < need && ++tries < PP_SOFTSYNC_TRIES);
-        if ((int)seen < need) y.lag = 0;   // timed out: this block stops waiting (it still counts)
+          behind = __any(pp_sync_peek(y.peek_at) < need);
+        } while (behind && ++tries < PP_SOFTSYNC_TRIES);
+        if (behind) y.lag = 0;   // timed out: this block stops waiting (it still publishes)
       }
     }
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(y.word, 1u, __ATOMIC_RELAXED, PP_SOFTSYNC_SCOPE);
   }
 }
-// A block that marches fewer steps than the nominal chunk (the last z-chunk) counts the difference when it ends.
-__device__ __forceinline__ void pp_softsync_finish(pp_softsync& y, int nsteps, int nominal) {
-  if (threadIdx.x == 0 && nominal > nsteps) __hip_atomic_fetch_add(y.word, (unsigned)(nominal - nsteps), __ATOMIC_RELAXED, PP_SOFTSYNC_SCOPE);
+// A block that has finished its march never holds anybody back.
+__device__ __forceinline__ void pp_softsync_finish(pp_softsync& y) {
+  if (threadIdx.x == 0) __hip_atomic_store(y.mine, PP_SYNC_DONE, __ATOMIC_RELAXED, PP_SOFTSYNC_STORE_SCOPE);
 }
 // Measurement builds (-DPP_DRIFT, tools/kbench): 100 MHz wall-clock stamps of EVERY block at the quarter points of its march.
 #ifdef PP_DRIFT
 __device__ unsigned long long pp_drift_buf[2][1024][4];
+__device__ unsigned pp_drift_xcc[2][1024];   // HW_REG_XCC_ID of the block's first wave: which XCD did block b really run on?
 #define PP_DRIFT_MARK(kern, n, nsteps)                                                                                  \
   do {                                                                                                                  \
     if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                                        \
       const int q_ = ((n) == (nsteps) / 4) ? 0 : ((n) == (nsteps) / 2) ? 1 : ((n) == 3 * (nsteps) / 4) ? 2 : ((n) == (nsteps)-1) ? 3 : -1; \
       if (q_ >= 0) pp_drift_buf[kern][blockIdx.x][q_] = wall_clock64();                                                 \
+      if (q_ == 0) pp_drift_xcc[kern][blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));              \
     }                                                                                                                   \
   } while (0)
 #else
@@ -689,8 +713,11 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
   int xs_off = 0;
   if constexpr (XS) {
     constexpr int RPW = strip_lanes<G>::RPW;
+    // (strip rows by ROLE: three rows a wave for waves 0-5, two for wave 6, none for wave 7 -- the wave index is reversed in
+    // every other block of a CU's pair, as in kernel A, so that a SIMD hosts a heavy wave of one block and a light one of the other)
+    const int wrole = ((PP_B_FLIP != 0) && ((blockIdx.x >> 8) & 1u)) ? (NTH / 64 - 1) - (t >> 6) : (t >> 6);
     const int lane = t & 63, riw = lane / G::SPR, sx = lane - riw * G::SPR;
-    const int uy = (t >> 6) * RPW + riw;
+    const int uy = wrole * RPW + riw;
     const bool valid = riw < RPW && uy < G::UH;
     st[0] = pp_strip_setup(valid ? uy * G::SPR + sx : G::NS, G::NS, G::SPR, G::UW, tx0 - G::RP, ty0 - R, d, a.px);
     xs_out = valid && sx >= 1 && sx <= G::SPR - 2;
@@ -802,7 +829,7 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
     const bool fresh_next = ST || ((n + 1 < nsteps) && (nxt != cur));
     PP_TRACE_MARK(trace_on, 1, n, 0);
     PP_DRIFT_MARK(1, n, nsteps);
-    if constexpr (SYNC) ysync.seen = pp_sync_peek(ysync.word);   // (consumed at the end of the step)
+    if constexpr (SYNC) pp_softsync_peek(ysync);
     // ---- interval 1: y pass of plane `cur` (reads s_x) | publish plane `nxt` (writes s_u) ----
     if (fresh_cur) {
 #pragma unroll
@@ -962,7 +989,7 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
   auto step_general = [&](int n, auto phase_tag) { step(n, phase_tag, pp_steady<false>{}); };
   fused2_plane_loop<R, UNROLL>(step_general, nsteps);
 #endif
-  if constexpr (SYNC) pp_softsync_finish(ysync, nsteps, a.zchunk + 2 * R);
+  if constexpr (SYNC) pp_softsync_finish(ysync);
 }
 
 // SH 0 / 1: every tile of that shape.  SH 2: tiles of both shapes in one launch (fused_args: gx2 > 0) -- 64 x 16 wherever a
@@ -997,6 +1024,32 @@ __device__ __forceinline__ float pp_esm_axis_data(float fm, float fp, float mc, 
   const float fg = (fp - fm) * hf;
   return fg + wg;
 }
+
+// The same on a (warped, fixed) PAIR as it lies in the packed image tile: both differences are one packed subtraction of the
+// two ds_read_b64 results and both products one packed multiply -- registers that are pairs already.  Written as scalar
+// statements the SLP vectoriser formed the same packed operations across the x and y axes instead, and paid eight v_mov_b32 per
+// voxel to assemble their operands (a fifth of the voted path's instructions).  Same operations on the same operands as
+// pp_esm_axis_plain -- two products, each rounded, then their sum -- so the same bits.
+typedef float pp_v2f __attribute__((vector_size(8), may_alias));
+__device__ __forceinline__ float pp_esm_axis_plain2(pp_v2f lo /* (m, f) below */, pp_v2f hi /* (m, f) above */, float inv_sp) {
+  const float h = 0.5f * inv_sp;
+  const pp_v2f hh = {h, h};
+  const pp_v2f d = hi - lo;
+  const pp_v2f p = d * hh;     // {wg, fg}
+  const float wg = p[0], fg = p[1];
+  return fg + wg;
+}
+
+// Kernel A's z window element: the (warped, fixed) values of one owned voxel on one plane -- a register PAIR (PP_A_ZPAIRS: the z
+// gradient is then packed like the x and y ones and the window rotates by 64-bit moves) or two independent registers.
+#ifndef PP_A_ZPAIRS
+#define PP_A_ZPAIRS 0
+#endif
+#if PP_A_ZPAIRS
+#define PP_ZWIN(name, n) pp_v2f name[n]
+#else
+#define PP_ZWIN(name, n) float name[n][2]
+#endif
 
 // One axis of the gradient where both neighbours exist and neither warped value is the sentinel: pp_esm_axis /
 // pp_esm_axis_data with `up`, `um` true and the first / last-index factor h -- the same two statements, so the same roundings.
@@ -1071,6 +1124,13 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
 
   const pp_dims d = a.d;
   const int t = threadIdx.x;
+  // Work that is not tied to an output voxel -- the ESM update of the halo'd smoothing input (22 wave-rounds over 8 waves: 3 3 3
+  // 3 3 3 2 2), the image tile's border ring (waves 0-2) and the x-pass items (2 2 2 2 2 2 2 1) -- is dealt by ROLE: the wave
+  // index reversed in every other block of a CU's pair (blocks j and j + 32 of an XCD's run share a CU when the dispatcher
+  // fills the CUs round-robin), so that the SIMD that hosts the heavy waves 0 / 4 of one block hosts the light waves 7 / 3 of
+  // the other: 11 + 11 + 11 + 11 ESM rounds per SIMD and plane instead of 12 + 12 + 10 + 10.  The lane keeps its place (the
+  // x pass's conflict-free order is by lane).  Same arithmetic by another thread: fields bit-identical.
+  const int tr = ((PP_A_FLIP != 0) && ((blockIdx.x >> 8) & 1u)) ? (((NTH / 64 - 1) - (t >> 6)) << 6 | (t & 63)) : t;
   const int cx = t % G::LX, cy = t / G::LX;
   const unsigned sy = (unsigned)a.px, sz = (unsigned)a.px * d.ny;
   const size_t N = (size_t)sz * d.nz;
@@ -1082,13 +1142,17 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
   unsigned slots[G::KU];  // read slot of the clamped position, minus one row | write slot << 16   (in s_mf)
   unsigned uflag[G::KU];  // slot in s_u | flags << 16
   unsigned own_g[G::KU];  // in-plane BYTE offset of the clamped position
-  float mprev[G::KU], mcur[G::KU], mnext[G::KU], fprev[G::KU], fcur[G::KU], fnext[G::KU];
+  // z window of the image pair at the owned voxels, kept as (warped, fixed) PAIRS: the z gradient is then the packed form of
+  // the x and y ones (pp_esm_axis_plain2), and the window rotates by 64-bit moves
+  PP_ZWIN(wprev, G::KU);
+  PP_ZWIN(wcur, G::KU);
+  PP_ZWIN(wnext, G::KU);
   // (border rules are carried by data -- a slot outside the volume publishes the sentinel in its warped-image half, the
   // fixed-gradient factor is 0 on a first/last index -- and both are derived from the flag bits where they are used: only
   // blocks on the volume's x/y border ever need them, and nine registers held them for every block.)
 #pragma unroll
   for (int k = 0; k < G::KU; ++k) {
-    const int e = t + k * NTH;
+    const int e = tr + k * NTH;
     const int ee = e < G::NU ? e : 0;
     const int uy = ee / G::UW, ux = ee - uy * G::UW;
     const int xg = tx0 - R + ux, yg = ty0 - R + uy;
@@ -1113,18 +1177,18 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
   int brd_w = -1;
   unsigned brd_g = 0;
   float brd_oov = -FLT_MAX;
-  if (t < G::NB) {
+  if (tr < G::NB) {
     int my, mx;
-    if (t < G::MW) { my = 0; mx = t; }
-    else if (t < 2 * G::MW) { my = G::MH - 1; mx = t - G::MW; }
-    else { const int q = t - 2 * G::MW; my = 1 + q / 2; mx = (q & 1) ? G::MW - 1 : 0; }
+    if (tr < G::MW) { my = 0; mx = tr; }
+    else if (tr < 2 * G::MW) { my = G::MH - 1; mx = tr - G::MW; }
+    else { const int q = tr - 2 * G::MW; my = 1 + q / 2; mx = (q & 1) ? G::MW - 1 : 0; }
     const int xc = pp_clampi(tx0 - R - 1 + mx, 0, d.nx - 1), yc = pp_clampi(ty0 - R - 1 + my, 0, d.ny - 1);
     if (xc != tx0 - R - 1 + mx || yc != ty0 - R - 1 + my) brd_oov = FLT_MAX;
     brd_w = my * G::MWP + mx;
     brd_g = ((unsigned)yc * sy + (unsigned)xc) * 4u;
   }
   int xsrc[NXI], xdst[NXI];
-  fused2_xpass_setup<R, SH, NXI>(t, xsrc, xdst);
+  fused2_xpass_setup<R, SH, NXI>(tr, xsrc, xdst);
   const int yb = cy * fused2_xtile<SH>::XP + 2 * cx;
   const int x = tx0 + 2 * cx, y = ty0 + cy;
   const bool out_ok = (y < d.ny) && (x < d.nx);
@@ -1140,7 +1204,7 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
   if constexpr (SYNC) pp_softsync_init(ysync, a, a.sync_other);
 
   float bm = 0.0f, bf = 0.0f;          // border ring values of the plane about to be published
-  float min_[G::KU], fin_[G::KU];      // plane two ahead of the window centre, in flight
+  PP_ZWIN(win_, G::KU);                // plane two ahead of the window centre, in flight
   float bm_n = 0.0f, bf_n = 0.0f;
   float a_ssd = 0.0f, a_ssc = 0.0f, a_n = 0.0f;   // <= ~40 terms per thread: fp32 is exact enough, folded in fp64 below
 
@@ -1149,7 +1213,7 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
     for (int k = 0; k < G::KU; ++k)
       if ((k + 1) * NTH <= G::NU || ((uflag[k] >> 16) & F_VALID)) {
         const float oov = ((pp_opaque(uflag[k]) >> 16) & F_OOV) ? FLT_MAX : -FLT_MAX;
-        s_mf[slots[k] >> 16] = make_float2(fmaxf(mcur[k], oov), fcur[k]);
+        s_mf[slots[k] >> 16] = make_float2(fmaxf(wcur[k][0], oov), wcur[k][1]);
       }
     if (brd_w >= 0) s_mf[brd_w] = make_float2(fmaxf(bm, brd_oov), bf);
   };
@@ -1158,8 +1222,8 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
     {   // (measurement builds: no image loads)
 #pragma unroll
       for (int k = 0; k < G::KU; ++k) {
-        min_[k] = (float)own_g[k] * 1e-3f + (float)zc;
-        fin_[k] = (float)own_g[k] * 2e-3f - (float)zc;
+        win_[k][0] = (float)own_g[k] * 1e-3f + (float)zc;
+        win_[k][1] = (float)own_g[k] * 2e-3f - (float)zc;
       }
       bm_n = 1.0f;
       bf_n = 2.0f;
@@ -1171,8 +1235,8 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
       const unsigned s2 = (unsigned)p2 * 4u, s1 = (unsigned)p1 * 4u;
 #pragma unroll
       for (int k = 0; k < G::KU; ++k) {
-        min_[k] = pp_blds(r_mw, own_g[k], s2);
-        fin_[k] = pp_blds(r_f, own_g[k], s2);
+        win_[k][0] = pp_blds(r_mw, own_g[k], s2);
+        win_[k][1] = pp_blds(r_f, own_g[k], s2);
       }
       if (MASK || brd_w >= 0) {   // (MASK: lanes without a ring element read voxel 0 of the plane)
         bm_n = pp_blds(r_mw, brd_g, s1);
@@ -1182,8 +1246,8 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
       const pp_rsrc rm2 = pp_make_rsrc(Mw + p2), rf2 = pp_make_rsrc(F + p2);
 #pragma unroll
       for (int k = 0; k < G::KU; ++k) {
-        min_[k] = pp_bld(rm2, own_g[k]);
-        fin_[k] = pp_bld(rf2, own_g[k]);
+        win_[k][0] = pp_bld(rm2, own_g[k]);
+        win_[k][1] = pp_bld(rf2, own_g[k]);
       }
       if (MASK || brd_w >= 0) {
         bm_n = pp_bld(pp_make_rsrc(Mw + p1), brd_g);
@@ -1208,23 +1272,33 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
       const bool full_round = (k + 1) * NTH <= G::NU;
       const bool valid = full_round || (fl & F_VALID);
       if (full_round || __any(valid)) {
-        const float2* const lp = s_mf + (slots[k] & 0xffffu);   // (the slot one row up, see the setup)
-        const float2 xm = lp[G::MWP - 1], xp = lp[G::MWP + 1], ym = lp[0], yp = lp[2 * G::MWP];
+        const pp_v2f* const lp2 = reinterpret_cast<const pp_v2f*>(s_mf) + (slots[k] & 0xffffu);   // (the slot one row up, see the setup)
+        const pp_v2f xm2 = lp2[G::MWP - 1], xp2 = lp2[G::MWP + 1], ym2 = lp2[0], yp2 = lp2[2 * G::MWP];
+        const float2 xm = make_float2(xm2[0], xm2[1]), xp = make_float2(xp2[0], xp2[1]), ym = make_float2(ym2[0], ym2[1]), yp = make_float2(yp2[0], yp2[1]);
         const unsigned flb = pp_opaque(fl);   // (predicates formed here: hoisted, they would hold six scalar registers per voxel)
-        const float mmax = fmaxf(fmaxf(fmaxf(xm.x, xp.x), fmaxf(ym.x, yp.x)), fmaxf(fmaxf(mprev[k], mnext[k]), mcur[k]));
+        const float mmax = fmaxf(fmaxf(fmaxf(xm.x, xp.x), fmaxf(ym.x, yp.x)), fmaxf(fmaxf(wprev[k][0], wnext[k][0]), wcur[k][0]));
         const bool plain = !valid || (((flb & (F_XLO | F_XHI | F_YLO | F_YHI)) == 0u) & (mmax < FLT_MAX));
         pp_esm_out o;
         if (z_inner && !__any(!plain)) {
+#if PP_A_ESM_PAIRS
+          const float gx = pp_esm_axis_plain2(xm2, xp2, K.ix);
+          const float gy = pp_esm_axis_plain2(ym2, yp2, K.iy);
+#else
           const float gx = pp_esm_axis_plain(xm.y, xp.y, xm.x, xp.x, K.ix);
           const float gy = pp_esm_axis_plain(ym.y, yp.y, ym.x, yp.x, K.iy);
-          const float gz = pp_esm_axis_plain(fprev[k], fnext[k], mprev[k], mnext[k], K.iz);
-          o = pp_esm_voxel<true>(K, fcur[k], mcur[k], gx, gy, gz);
+#endif
+#if PP_A_ESM_PAIRS && PP_A_ZPAIRS
+          const float gz = pp_esm_axis_plain2(wprev[k], wnext[k], K.iz);
+#else
+          const float gz = pp_esm_axis_plain(wprev[k][1], wnext[k][1], wprev[k][0], wnext[k][0], K.iz);
+#endif
+          o = pp_esm_voxel<true>(K, wcur[k][1], wcur[k][0], gx, gy, gz);
         } else {
           const float hfx = (flb & (F_XLO | F_XHI)) ? 0.0f : 0.5f * K.ix, hfy = (flb & (F_YLO | F_YHI)) ? 0.0f : 0.5f * K.iy;
-          const float gx = pp_esm_axis_data(xm.y, xp.y, mcur[k], xm.x, xp.x, hfx, K.ix);
-          const float gy = pp_esm_axis_data(ym.y, yp.y, mcur[k], ym.x, yp.x, hfy, K.iy);
-          const float gz = pp_esm_axis(fprev[k], fnext[k], mcur[k], mprev[k], mnext[k], zlo_b, zhi_b, K.iz);
-          o = pp_esm_voxel(K, fcur[k], mcur[k], gx, gy, gz);
+          const float gx = pp_esm_axis_data(xm.y, xp.y, wcur[k][0], xm.x, xp.x, hfx, K.ix);
+          const float gy = pp_esm_axis_data(ym.y, yp.y, wcur[k][0], ym.x, yp.x, hfy, K.iy);
+          const float gz = pp_esm_axis(wprev[k][1], wnext[k][1], wcur[k][0], wprev[k][0], wnext[k][0], zlo_b, zhi_b, K.iz);
+          o = pp_esm_voxel(K, wcur[k][1], wcur[k][0], gx, gy, gz);
         }
         if (valid) {
           const int u = (int)(uflag[k] & 0xffffu);
@@ -1248,10 +1322,10 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
         const float2 xm = lp[G::MWP - 1], xp = lp[G::MWP + 1], ym = lp[0], yp = lp[2 * G::MWP];
         const unsigned flb = pp_opaque(fl);   // (predicates formed here: hoisted, they would hold six scalar registers per voxel)
         const float hfx = (flb & (F_XLO | F_XHI)) ? 0.0f : 0.5f * K.ix, hfy = (flb & (F_YLO | F_YHI)) ? 0.0f : 0.5f * K.iy;
-        const float gx = pp_esm_axis_data(xm.y, xp.y, mcur[k], xm.x, xp.x, hfx, K.ix);
-        const float gy = pp_esm_axis_data(ym.y, yp.y, mcur[k], ym.x, yp.x, hfy, K.iy);
-        const float gz = pp_esm_axis(fprev[k], fnext[k], mcur[k], mprev[k], mnext[k], zlo_b, zhi_b, K.iz);
-        const pp_esm_out o = pp_esm_voxel(K, fcur[k], mcur[k], gx, gy, gz);
+        const float gx = pp_esm_axis_data(xm.y, xp.y, wcur[k][0], xm.x, xp.x, hfx, K.ix);
+        const float gy = pp_esm_axis_data(ym.y, yp.y, wcur[k][0], ym.x, yp.x, hfy, K.iy);
+        const float gz = pp_esm_axis(wprev[k][1], wnext[k][1], wcur[k][0], wprev[k][0], wnext[k][0], zlo_b, zhi_b, K.iz);
+        const pp_esm_out o = pp_esm_voxel(K, wcur[k][1], wcur[k][0], gx, gy, gz);
         const int u = (int)(uflag[k] & 0xffffu);
         s_u[u] = o.ux;
         s_u[G::UH * G::UWP + u] = o.uy;
@@ -1266,8 +1340,14 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
     }
 #pragma unroll
     for (int k = 0; k < G::KU; ++k) {
-      mprev[k] = mcur[k]; mcur[k] = mnext[k]; mnext[k] = min_[k];
-      fprev[k] = fcur[k]; fcur[k] = fnext[k]; fnext[k] = fin_[k];
+#if PP_A_ZPAIRS
+      wprev[k] = wcur[k];
+      wcur[k] = wnext[k];
+      wnext[k] = win_[k];
+#else
+      wprev[k][0] = wcur[k][0]; wcur[k][0] = wnext[k][0]; wnext[k][0] = win_[k][0];
+      wprev[k][1] = wcur[k][1]; wcur[k][1] = wnext[k][1]; wnext[k][1] = win_[k][1];
+#endif
     }
     bm = bm_n;
     bf = bf_n;
@@ -1324,9 +1404,9 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
                   rmn = pp_make_rsrc(Mw + pn), rfn = pp_make_rsrc(F + pn);
 #pragma unroll
     for (int k = 0; k < G::KU; ++k) {
-      mprev[k] = pp_bld(rmm, own_g[k]); fprev[k] = pp_bld(rfm, own_g[k]);
-      mcur[k] = pp_bld(rmc, own_g[k]);  fcur[k] = pp_bld(rfc, own_g[k]);
-      mnext[k] = pp_bld(rmn, own_g[k]); fnext[k] = pp_bld(rfn, own_g[k]);
+      wprev[k][0] = pp_bld(rmm, own_g[k]); wprev[k][1] = pp_bld(rfm, own_g[k]);
+      wcur[k][0] = pp_bld(rmc, own_g[k]);  wcur[k][1] = pp_bld(rfc, own_g[k]);
+      wnext[k][0] = pp_bld(rmn, own_g[k]); wnext[k][1] = pp_bld(rfn, own_g[k]);
     }
     if (brd_w >= 0) {
       bm = pp_bld(rmc, brd_g);
@@ -1364,7 +1444,7 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
     const bool emit = ST || ((zo >= z0) && (zo <= zo_last) && out_ok);
     PP_TRACE_MARK(trace_on, 0, n, 0);
     PP_DRIFT_MARK(0, n, nsteps);
-    if constexpr (SYNC) ysync.seen = pp_sync_peek(ysync.word);   // (consumed at the end of the step)
+    if constexpr (SYNC) pp_softsync_peek(ysync);
     // ---- interval 1: x pass of plane `cur` (s_u -> s_x) | publish the image tile of plane `nxt` ----
     if (fresh_next) publish();
     if (fresh_cur) fused2_xpass<R, NXI, 3 * G::XI>(s_u, s_x, a.wx, xsrc, xdst);
@@ -1461,7 +1541,7 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
   auto step_general = [&](int n, auto phase_tag) { step(n, phase_tag, pp_steady<false>{}); };
   fused2_plane_loop<R, UNROLL>(step_general, nsteps);
 #endif
-  if constexpr (SYNC) pp_softsync_finish(ysync, nsteps, a.zchunk + 2 * R);
+  if constexpr (SYNC) pp_softsync_finish(ysync);
   double r_ssd = (double)a_ssd, r_ssc = (double)a_ssc, r_n = (double)a_n;
   pp_block_sum3_shfl<NTH>(r_ssd, r_ssc, r_n, reinterpret_cast<double*>(s_u));
   if (t == 0) {

@@ -238,7 +238,20 @@ struct msq_args {
   double Af[9], bf[3], Am[9], bm[3];
   int vsize[3];
   int stride;
+  const float* jit;   // ITK's per-sample jitter in virtual-index units, 3 floats per sample, or NULL (pp_linear_set_sample_jitter)
 };
+
+// itk::ImageRegistrationMethodv4::SetMetricSamplePoints (REGULAR): every sample point is the lattice voxel's physical point
+// plus a seeded normal variate times a third of the virtual spacing per axis.  The host draws the variates (ITK's
+// MersenneTwister sequence, platipy_amd/registration/linear.py) and hands them over in virtual-index units; sample e of the
+// raster walk takes entries 3 e .. 3 e + 2.  NULL: the lattice itself (the default, a declared deviation from ITK).
+__device__ __forceinline__ void msq_jitter(const float* __restrict__ jit, size_t e, double v[3]) {
+  if (jit) {
+    v[0] += (double)jit[3 * e + 0];
+    v[1] += (double)jit[3 * e + 1];
+    v[2] += (double)jit[3 * e + 2];
+  }
+}
 
 __device__ __forceinline__ bool msq_locate(const double c[3], const pp_dims& n, int b[3], float f[3]) {
   if (!(c[0] >= -0.5 && c[0] < n.nx - 0.5 && c[1] >= -0.5 && c[1] < n.ny - 0.5 && c[2] >= -0.5 && c[2] < n.nz - 0.5)) return false;
@@ -268,8 +281,9 @@ __global__ void __launch_bounds__(NT) k_metric_affine(const float* __restrict__ 
   const size_t nsamp = (nvirt + a.stride - 1) / a.stride;
   for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nsamp; e += (size_t)gridDim.x * NT) {
     const size_t lin = e * (size_t)a.stride;
-    const double v[3] = {(double)(lin % a.vsize[0]), (double)((lin / a.vsize[0]) % a.vsize[1]),
-                         (double)(lin / ((size_t)a.vsize[0] * a.vsize[1]))};
+    double v[3] = {(double)(lin % a.vsize[0]), (double)((lin / a.vsize[0]) % a.vsize[1]),
+                   (double)(lin / ((size_t)a.vsize[0] * a.vsize[1]))};
+    msq_jitter(a.jit, e, v);
     double cf[3], cm[3];
     for (int r = 0; r < 3; ++r) {
       cf[r] = a.Af[r * 3 + 0] * v[0] + a.Af[r * 3 + 1] * v[1] + a.Af[r * 3 + 2] * v[2] + a.bf[r];
@@ -397,6 +411,7 @@ struct mval_args {
   double Am[PP_MAX_CAND][9], bm[PP_MAX_CAND][3];
   int vsize[3];
   int stride;
+  const float* jit;   // (as msq_args)
 };
 
 // pp_trilinear with the two x-neighbours of each corner row fetched as ONE 8-byte access when they are adjacent
@@ -458,8 +473,9 @@ __global__ void __launch_bounds__(NT) k_metric_values(const float* __restrict__ 
   const size_t nsamp = (nvirt + a.stride - 1) / a.stride;
   for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nsamp; e += (size_t)gridDim.x * NT) {
     const size_t lin = e * (size_t)a.stride;
-    const double v[3] = {(double)(lin % a.vsize[0]), (double)((lin / a.vsize[0]) % a.vsize[1]),
-                         (double)(lin / ((size_t)a.vsize[0] * a.vsize[1]))};
+    double v[3] = {(double)(lin % a.vsize[0]), (double)((lin / a.vsize[0]) % a.vsize[1]),
+                   (double)(lin / ((size_t)a.vsize[0] * a.vsize[1]))};
+    msq_jitter(a.jit, e, v);
     double fd;
     if (fsamp) {   // the fixed side of this sample was evaluated once for the level: a coalesced 4-byte read instead of four
                    // sparse cache lines per sample (at shrink 4 a probe dragged a quarter of the fixed image through HBM)
@@ -723,7 +739,8 @@ __global__ void __launch_bounds__(NT, PP_MV_WAVES) k_metric_values_lanes(const f
         const size_t eq = e0 + (size_t)(i0 + j) * MV_SLOTS;
         ok[j] = (i0 + j < spt) && eq < nsamp;
         const size_t e = eq < nsamp ? eq : nsamp - 1;
-        const double v[3] = {(double)px, (double)py, (double)pz};
+        double v[3] = {(double)px, (double)py, (double)pz};
+        msq_jitter(a.jit, e, v);
         {   // next sample of this thread (beyond the lattice the position is never used: ok[j] is false there)
           px += sx_;
           const bool cx = px >= (unsigned)a.vsize[0];
@@ -966,6 +983,7 @@ __global__ void __launch_bounds__(NT) k_metric_grad(const float* __restrict__ F,
         v[j][1] = (double)((lin / a.vsize[0]) % a.vsize[1]);
         v[j][2] = (double)(lin / ((size_t)a.vsize[0] * a.vsize[1]));
       }
+      msq_jitter(a.jit, e, v[j]);
       double cf[3], cm[3];
       for (int r = 0; r < 3; ++r) {
         cf[r] = a.Af[r * 3 + 0] * v[j][0] + a.Af[r * 3 + 1] * v[j][1] + a.Af[r * 3 + 2] * v[j][2] + a.bf[r];
@@ -1131,6 +1149,7 @@ struct mi_args {
   int stride;
   int nbins, kernel;
   double f_bin, f_norm_min, m_bin, m_norm_min;
+  const float* jit;   // (as msq_args)
 };
 
 __device__ __forceinline__ double mi_bspline3(double u) {   // cubic B-spline, support (-2, 2)
@@ -1154,6 +1173,7 @@ __device__ __forceinline__ bool mi_sample(const float* __restrict__ F, const pp_
   v[0] = (double)(lin % a.vsize[0]);
   v[1] = (double)((lin / a.vsize[0]) % a.vsize[1]);
   v[2] = (double)(lin / ((size_t)a.vsize[0] * a.vsize[1]));
+  msq_jitter(a.jit, e, v);
   double cf[3], cm[3];
   for (int r = 0; r < 3; ++r) {
     cf[r] = a.Af[r * 3 + 0] * v[0] + a.Af[r * 3 + 1] * v[1] + a.Af[r * 3 + 2] * v[2] + a.bf[r];
@@ -1281,6 +1301,16 @@ __global__ void __launch_bounds__(NT) k_mi_gradient(const float* __restrict__ F,
   }
 }
 
+// The context's jitter array for a lattice of `nsamp` samples (NULL when none is set); an array too short for the lattice is
+// an error, never a silent read past its end.
+static int pp_jitter_for(pp_ctx* ctx, size_t nsamp, const float** out) {
+  *out = nullptr;
+  if (!ctx->jitter) return PP_OK;
+  PP_REQUIRE(ctx, ctx->jitter_samples >= nsamp, "metric: the sample-jitter array set by pp_linear_set_sample_jitter is shorter than the sampling lattice");
+  *out = ctx->jitter;
+  return PP_OK;
+}
+
 int mi_fill_args(pp_ctx* ctx, mi_args* a, const int fsize[3], const int msize[3], const double Af[9], const double bf[3], const double Am[9],
                  const double bm[3], const int vsize[3], int stride, const pp_mi_bins* bins) {
   PP_REQUIRE(ctx, fsize && msize && Af && bf && Am && bm && vsize && bins, "mutual information: NULL argument");
@@ -1300,6 +1330,11 @@ int mi_fill_args(pp_ctx* ctx, mi_args* a, const int fsize[3], const int msize[3]
   a->f_norm_min = bins->f_norm_min;
   a->m_bin = bins->m_bin;
   a->m_norm_min = bins->m_norm_min;
+  {
+    const size_t nsamp = ((size_t)vsize[0] * vsize[1] * vsize[2] + stride - 1) / stride;
+    const int jrc = pp_jitter_for(ctx, nsamp, &a->jit);
+    if (jrc) return jrc;
+  }
   return PP_OK;
 }
 
@@ -1451,8 +1486,9 @@ __global__ void __launch_bounds__(NT) k_fixed_samples(const float* __restrict__ 
   const size_t nsamp = (nvirt + a.stride - 1) / a.stride;
   for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nsamp; e += (size_t)gridDim.x * NT) {
     const size_t lin = e * (size_t)a.stride;
-    const double v[3] = {(double)(lin % a.vsize[0]), (double)((lin / a.vsize[0]) % a.vsize[1]),
-                         (double)(lin / ((size_t)a.vsize[0] * a.vsize[1]))};
+    double v[3] = {(double)(lin % a.vsize[0]), (double)((lin / a.vsize[0]) % a.vsize[1]),
+                   (double)(lin / ((size_t)a.vsize[0] * a.vsize[1]))};
+    msq_jitter(a.jit, e, v);
     double cf[3];
     for (int r = 0; r < 3; ++r) cf[r] = a.Af[r * 3 + 0] * v[0] + a.Af[r * 3 + 1] * v[1] + a.Af[r * 3 + 2] * v[2] + a.bf[r];
     int bf_[3];
@@ -1473,9 +1509,13 @@ static int pp_fixed_samples(pp_ctx* ctx, const float* fixed, const int fsize[3],
   auto& k = ctx->fsamp_key;
   const bool same = ctx->fsamp_valid && k.fixed == fixed && k.fmask == fmask && k.stride == stride &&
                     memcmp(k.fsize, fsize, sizeof(k.fsize)) == 0 && memcmp(k.vsize, vsize, sizeof(k.vsize)) == 0 &&
-                    memcmp(k.Af, Af, sizeof(k.Af)) == 0 && memcmp(k.bf, bf, sizeof(k.bf)) == 0;
+                    memcmp(k.Af, Af, sizeof(k.Af)) == 0 && memcmp(k.bf, bf, sizeof(k.bf)) == 0 && k.jitter == ctx->jitter &&
+                    k.jitter_gen == ctx->jitter_gen;
   if (!same) {
     const size_t nsamp = ((size_t)vsize[0] * vsize[1] * vsize[2] + stride - 1) / stride;
+    const float* jit = nullptr;
+    const int jrc = pp_jitter_for(ctx, nsamp, &jit);
+    if (jrc) return jrc;
     if (nsamp > ctx->fsamp_cap) {
       if (ctx->fsamp) (void)hipFree(ctx->fsamp);
       ctx->fsamp = nullptr;
@@ -1494,6 +1534,7 @@ static int pp_fixed_samples(pp_ctx* ctx, const float* fixed, const int fsize[3],
     memcpy(a.bf, bf, sizeof(a.bf));
     for (int i = 0; i < 3; ++i) a.vsize[i] = vsize[i];
     a.stride = stride;
+    a.jit = jit;
     const pp_dims df{fsize[0], fsize[1], fsize[2]};
     hipLaunchKernelGGL(k_fixed_samples, dim3(grid_for(nsamp, 2048u)), dim3(NT), 0, ctx->stream, fixed, df, fmask, a, ctx->fsamp);
     PP_LAUNCH_CHECK(ctx, "k_fixed_samples");
@@ -1504,6 +1545,8 @@ static int pp_fixed_samples(pp_ctx* ctx, const float* fixed, const int fsize[3],
     memcpy(k.vsize, vsize, sizeof(k.vsize));
     memcpy(k.Af, Af, sizeof(k.Af));
     memcpy(k.bf, bf, sizeof(k.bf));
+    k.jitter = ctx->jitter;
+    k.jitter_gen = ctx->jitter_gen;
     ctx->fsamp_valid = 1;
   }
   *out = ctx->fsamp;
@@ -1526,6 +1569,10 @@ static int metric_affine(pp_ctx* ctx, int mode, const float* fixed, const int fs
   for (int k = 0; k < 3; ++k) a.vsize[k] = vsize[k];
   a.stride = stride;
   const size_t nsamp = ((size_t)vsize[0] * vsize[1] * vsize[2] + stride - 1) / stride;
+  {
+    const int jrc = pp_jitter_for(ctx, nsamp, &a.jit);
+    if (jrc) return jrc;
+  }
   const pp_dims df{fsize[0], fsize[1], fsize[2]}, dm{msize[0], msize[1], msize[2]};
   const unsigned nb = grid_for(nsamp, 512u);   // (256 measures the same, 128 slower: profiles/round3_metric_probe_latency.txt)
   int rc = pp_reserve(ctx, pp_align_up((size_t)nb * nacc * sizeof(double), 256));
@@ -1608,6 +1655,10 @@ int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, con
   for (int k = 0; k < 3; ++k) a.vsize[k] = vsize[k];
   a.stride = stride;
   const size_t nsamp = ((size_t)vsize[0] * vsize[1] * vsize[2] + stride - 1) / stride;
+  {
+    const int jrc = pp_jitter_for(ctx, nsamp, &a.jit);
+    if (jrc) return jrc;
+  }
   const pp_dims df{fsize[0], fsize[1], fsize[2]}, dm{msize[0], msize[1], msize[2]};
   // Candidates per thread: 16 on big lattices (HBM/L2-bound: the candidates of a sample share cache lines; the straight-line
   // form of the kernel keeps several candidates' gathers in flight), 4 for batches of up to four and on small lattices
@@ -1766,6 +1817,15 @@ int pp_mi_gradient_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], cons
   rc = pp_mail_take(ctx, 0, 14, seq, sums);
   if (rc) return rc;
   memcpy(result, sums + 2, 12 * sizeof(double));
+  return PP_OK;
+}
+
+int pp_linear_set_sample_jitter(pp_ctx* ctx, const float* jitter, size_t nsamples) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, (jitter == nullptr) == (nsamples == 0), "pp_linear_set_sample_jitter: a jitter array needs its sample count, NULL needs 0");
+  ctx->jitter = jitter;
+  ctx->jitter_samples = nsamples;
+  ctx->jitter_gen += 1;
   return PP_OK;
 }
 

@@ -40,7 +40,15 @@ struct pp_ctx {
     const unsigned char* fmask;
     int fsize[3], vsize[3], stride;
     double Af[9], bf[3];
+    const float* jitter;
+    unsigned long long jitter_gen;
   } fsamp_key;
+  // ITK's per-sample jitter of the metric lattice (pp_linear_set_sample_jitter): a caller-owned device array of 3 floats per
+  // sample in virtual-index units, NULL = the lattice itself.  `jitter_gen` counts the calls, so that the fixed-sample cache
+  // never serves samples taken under another jitter array that happens to live at the same address.
+  const float* jitter;
+  size_t jitter_samples;
+  unsigned long long jitter_gen;
   char err[512];
 };
 

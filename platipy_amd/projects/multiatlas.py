@@ -399,7 +399,7 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
         from ..label.iar import run_iar, run_iar_distributed
 
         dd.label = "iar_exchange"
-        if dd.world > 1:
+        if dd.dist is not None:   # (also a process group of ONE rank: the exchanges then run through its communicator)
             # every rank scores its own atlases; consensus, distance samples and Q values are exchanged (label/iar.py)
             weights = {i: float(compute_weight_map(img_crop, atlas_set[i]["DIR"]["CT Image"], vote_type="global").tensor.flatten()[0])
                        for i in my_ids}

@@ -124,15 +124,19 @@ def install_emu_runtime(setattr_fn=None):
     sa(runtime, "context", lambda device=None: be.ctx)
     sa(runtime, "default_device", lambda: torch.device("cpu"))
 
+    def jit():      # the jitter array the host code set on the context (linear_registration(itk_sampling=True)), or None
+        t = getattr(be.ctx, "_sample_jitter", None)
+        return None if t is None else (t.numpy() if hasattr(t, "numpy") else np.asarray(t))
+
     def fake_meansq(fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None):
         tn = lambda t: None if t is None else t.numpy()  # noqa: E731
         return list(linear_oracle.meansq_affine(fixed.numpy(), moving.numpy(), Af, bf, Am, bm, vsize, stride, tn(fixed_mask),
-                                                tn(moving_mask)))
+                                                tn(moving_mask), jitter=jit()))
 
     def fake_corr(fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None):
         tn = lambda t: None if t is None else t.numpy()  # noqa: E731
         return list(linear_oracle.corr_moments_affine(fixed.numpy(), moving.numpy(), Af, bf, Am, bm, vsize, stride, tn(fixed_mask),
-                                                      tn(moving_mask)))
+                                                      tn(moving_mask), jitter=jit()))
 
     def fake_values(metric, fixed, fsize, moving, msize, Af, bf, Ams, bms, vsize, stride, fixed_mask=None, moving_mask=None):
         out = np.zeros((len(Ams), 6))

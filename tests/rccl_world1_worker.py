@@ -29,8 +29,12 @@ def main():
     st = _settings(ids)
     plain, plain_prob = multiatlas.run_segmentation(target, st, atlases=atlases)
     assert multiatlas.run_segmentation.last_world_size == 1
-    t_iar, iar_ids, aset = _iar_case(pa)
-    kept_plain = run_iar(aset, "HEART", min_best_atlases=3, z_score_statistic="mad", outlier_method="iqr", outlier_factor=1.5)
+    t_iar, iar_ids, aset_w = _iar_case(pa)
+    for i in iar_ids:
+        aset_w[i]["DIR"]["Weight Map"] = pa.label.compute_weight_map(t_iar, aset_w[i]["DIR"]["CT Image"], vote_type="global")
+    kept_plain = run_iar(atlas_set=aset_w, reference_structure="HEART", min_best_atlases=3, z_score_statistic="mad",
+                         outlier_method="iqr", outlier_factor=1.5)
+    _, _, aset = _iar_case(pa)
 
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     out = {}
@@ -49,21 +53,13 @@ def main():
         assert "fusion_reduce" in ms2 and "fusion_allreduce" not in ms2, ms2
         for k in plain:
             assert np.array_equal(res2[k].numpy(), plain[k].numpy()), k
-        # ... and with atlas selection inside the pipeline (the IAR exchange on device tensors)
-        st3 = _settings(ids + ["003"])
-        _, _, _, atl3 = _data(pa, ids + ["003"])
-        st3["iar_settings"] = dict(st3.get("iar_settings") or {}, reference_structure="WHOLEHEART", min_best_atlases=2)
-        try:
-            multiatlas.run_segmentation(target, st3, atlases=atl3)
-            out["iar_in_pipeline_ms"] = dict(multiatlas.run_segmentation.last_exchange_ms).get("iar_exchange")
-        except Exception as e:   # noqa: BLE001 -- reported, judged by the caller
-            out["iar_in_pipeline_error"] = repr(e)
-        # distributed atlas removal on its own: same atlases kept as the single-process run_iar
+        # distributed atlas removal (the pipeline takes this path when world > 1): every exchange of it on device tensors
+        # through the communicator, same atlases kept as the single-process run_iar
         weights = {i: float(pa.label.compute_weight_map(t_iar, aset[i]["DIR"]["CT Image"], vote_type="global").tensor.flatten()[0])
                    for i in iar_ids}
         kept = run_iar_distributed(multiatlas._Dist(), aset, iar_ids, iar_ids, "HEART", t_iar, weights, min_best_atlases=3,
                                    z_score_statistic="mad", outlier_method="iqr", outlier_factor=1.5)
-        assert sorted(kept) == sorted(kept_plain.keys() if isinstance(kept_plain, dict) else kept_plain), (kept, kept_plain)
+        assert sorted(kept) == sorted(kept_plain), (kept, list(kept_plain))
         out["iar_kept"] = sorted(kept)
         out["exchange_ms"] = {k: round(float(v), 4) for k, v in ms.items()}
         out["exchange_ms_reduce"] = {k: round(float(v), 4) for k, v in ms2.items()}

@@ -551,3 +551,111 @@ def test_fixed_sample_cache_does_not_change_the_optimisation(backend, monkeypatc
         out[off] = np.asarray(tfm.transforms[1].GetParameters())
     assert np.abs(out[None] - np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0.0])).max() > 1e-3
     np.testing.assert_array_equal(out["1"], out[None])
+
+
+# ---- ITK's seeded sample jitter (linear_registration(itk_sampling=True)) ----------------------------------------------------
+
+def test_itk_jitter_generators_agree_and_know_the_published_answer():
+    """The product draws ITK's variates with numpy's legacy RandomState (MT19937, init_genrand), the oracle with its own
+    restatement of the published generator: the same stream, over a state reload, and the reference implementation's
+    known first output for its default seed (3499211612 for 5489).  Variates: Box-Muller as ITK writes it."""
+    from oracle.linear_oracle import MersenneTwister, itk_regular_jitter
+    from platipy_amd.registration.linear import ItkRegularJitter
+
+    assert int(MersenneTwister(5489).integers(1)[0]) == 3499211612
+    assert np.array_equal(MersenneTwister(42).integers(2000), np.random.RandomState(42).randint(0, 2 ** 32, size=2000, dtype=np.uint64))
+    prod, orc = ItkRegularJitter(42), MersenneTwister(42)
+    # two levels from one stream, as ImageRegistrationMethodv4 draws them
+    for vsize, stride, sp in (((9, 7, 5), 2, (6.0, 6.0, 10.0)), ((18, 14, 10), 4, (3.0, 3.0, 5.0))):
+        a = prod.level(vsize, stride, sp, np.eye(3))
+        b = itk_regular_jitter(orc, vsize, stride, sp)
+        assert a.shape == b.shape == ((vsize[0] * vsize[1] * vsize[2] + stride - 1) // stride, 3) and a.dtype == np.float32
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-7)
+        assert 0.25 < a.std() < 0.42                      # a third of a voxel per axis in index units
+    # an oblique virtual domain: the perturbation is per PHYSICAL axis, the index offset its image under the inverse index map
+    ang = 0.4
+    d = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+    a = ItkRegularJitter(7).level((5, 4, 3), 1, (2.0, 3.0, 4.0), d)
+    n = ItkRegularJitter(7).normal_variates(3 * 60).reshape(60, 3)
+    np.testing.assert_allclose((d * np.array([2.0, 3.0, 4.0])) @ a.T.astype(np.float64), (n * np.array([2.0, 3.0, 4.0]) / 3.0).T, atol=2e-6)
+
+
+def test_metric_kernels_with_sample_jitter_match_the_oracle(backend):
+    """pp_linear_set_sample_jitter: every metric entry point evaluates at lattice index + jitter -- compared with the numpy
+    restatement given the same offsets, for the gradient kernel, the batched value probes and both MI passes; the plain
+    lattice comes back when the array is taken away, and a too-short array is refused."""
+    from oracle import linear_oracle as L
+    from platipy_amd._lib import MI_MATTES, MiBins, PlatipyAmdError
+
+    F = phantom((10, 14, 18), seed=300, noise=0)
+    M = phantom((12, 13, 17), seed=301, noise=0)
+    Af, bf = np.eye(3) * 2.0, np.array([0.5, 0.5, 0.5])
+    Am = np.array([[1.9137, 0.1071, 0.0031], [-0.0813, 2.0519, 0.0207], [0.0109, 0.0043, 2.3011]])
+    bm = np.array([0.7123, -0.4057, 0.9131])
+    vsize, stride = (9, 7, 5), 2
+    jit = L.itk_regular_jitter(L.MersenneTwister(42), vsize, stride, (2.0, 2.0, 2.0)).astype(np.float32)
+    ctx = backend.ctx
+    args = (backend.dev(F), (18, 14, 10), backend.dev(M), (17, 13, 12), Af.ravel(), bf, Am.ravel(), bm, vsize, stride)
+    plain = np.array(ctx.meansq_affine(*args))
+    dev_jit = backend.dev(jit)
+    ctx.set_sample_jitter(dev_jit)
+    try:
+        got = np.array(ctx.meansq_affine(*args))
+        want = L.meansq_affine(F, M, Af, bf, Am, bm, vsize, stride, jitter=jit)
+        assert got[1] == want[1] and want[1] > 50 and abs(got[0] - plain[0]) > 1e-3 * plain[0]      # the jitter moved the samples
+        np.testing.assert_allclose(got[0], want[0], rtol=1e-5)
+        np.testing.assert_allclose(got[2:], want[2:], rtol=2e-4, atol=1e-3 * np.abs(want[2:]).max())
+        gc = np.array(ctx.corr_moments_affine(*args))
+        wc = L.corr_moments_affine(F, M, Af, bf, Am, bm, vsize, stride, jitter=jit)
+        np.testing.assert_allclose(gc, wc, rtol=3e-4, atol=1e-3 * np.abs(wc).max())
+        vals = np.asarray(ctx.metric_values_affine(0, args[0], args[1], args[2], args[3], Af.ravel(), bf, [Am, Am * 1.01], [bm, bm + 0.2],
+                                                   vsize, stride))
+        np.testing.assert_allclose(vals[0, :2], got[:2], rtol=1e-9)
+        w1 = L.meansq_affine(F, M, Af, bf, Am * 1.01, bm + 0.2, vsize, stride, jitter=jit)
+        np.testing.assert_allclose(vals[1, :2], w1[:2], rtol=1e-5)
+        b = MiBins()
+        b.nbins, b.kernel = 16, MI_MATTES
+        b.f_bin, b.m_bin = (float(F.max() - F.min()) / 12), (float(M.max() - M.min()) / 12)
+        b.f_norm_min, b.m_norm_min = float(F.min()) / b.f_bin - 2, float(M.min()) / b.m_bin - 2
+        hist, count = ctx.mi_histogram(*args, b)
+        bd = dict(nbins=b.nbins, kernel=b.kernel, f_bin=b.f_bin, f_norm_min=b.f_norm_min, m_bin=b.m_bin, m_norm_min=b.m_norm_min)
+        wh, wcnt = L.mi_histogram(F, M, Af, bf, Am, bm, vsize, stride, bd, jitter=jit)
+        assert count == wcnt
+        np.testing.assert_allclose(hist, wh, atol=2e-4)
+        with pytest.raises(PlatipyAmdError):          # a lattice with more samples than the array holds
+            ctx.meansq_affine(*args[:8], (9, 7, 5), 1)
+    finally:
+        ctx.set_sample_jitter(None)
+    np.testing.assert_array_equal(np.array(ctx.meansq_affine(*args)), plain)
+
+
+def test_linear_registration_with_itk_sampling(host_api):
+    """itk_sampling=True: the registration still recovers the known rigid motion (sub-voxel jitter of the sample points does
+    not change where the optimum is), its result differs from the lattice run's (the flag does something), it is
+    reproducible (seeded), and the context's jitter is gone afterwards."""
+    pa = host_api
+    from platipy_amd import runtime
+
+    shape, spacing, origin = (24, 40, 48), (1.5, 1.5, 2.5), (-30.0, -20.0, 10.0)
+    fix, mov, (R, t, c) = _rigid_pair(pa, shape, spacing, origin)
+    kw = dict(reg_method="rigid", optimiser="gradient_descent_line_search", shrink_factors=[4, 2], smooth_sigmas=[2, 1],
+              sampling_rate=0.5, number_of_iterations=30)
+    fi, mi = pa.image_from_array(fix, spacing, origin), pa.image_from_array(mov, spacing, origin)
+    _, t0 = pa.registration.linear_registration(fi, mi, **kw)
+    img, t1 = pa.registration.linear_registration(fi, mi, itk_sampling=True, **kw)
+    _, t2 = pa.registration.linear_registration(fi, mi, itk_sampling=True, **kw)
+    assert getattr(runtime.context(fi.device), "_sample_jitter", None) is None
+    A0, o0 = t0.matrix_offset()
+    A1, o1 = t1.matrix_offset()
+    A2, o2 = t2.matrix_offset()
+    np.testing.assert_allclose(A1, A2, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(o1, o2, rtol=0, atol=1e-7)
+    assert np.abs(A1 - A0).max() + np.abs(o1 - o0).max() > 1e-6
+    n = np.array(shape[::-1], dtype=np.float64) - 1
+    corners = np.array([[i, j, k] for i in (0, n[0]) for j in (0, n[1]) for k in (0, n[2])]) * np.array(spacing) + np.array(origin)
+    want = (corners - c) @ R.T + c + t
+    err0, err1 = np.abs(corners @ A0.T + o0 - want).max(), np.abs(corners @ A1.T + o1 - want).max()
+    assert err1 < max(1.0, err0 + 0.5), (err0, err1)       # two levels, 30 iterations: the lattice run sets the scale
+    assert float(((fix - img.numpy()) ** 2).mean()) < 0.12 * float(((fix - mov) ** 2).mean())
+    _, t3 = pa.registration.linear_registration(fi, mi, itk_sampling=True, sampling_seed=7, **kw)
+    assert np.abs(t3.matrix_offset()[1] - o1).max() > 1e-9          # another seed, other sample points

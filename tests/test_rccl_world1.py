@@ -29,7 +29,7 @@ def test_multiatlas_exchanges_and_bench_ranks_over_rccl_world_1(gpu_backend):
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("RCCL_WORLD1 ")][-1]
     out = json.loads(line[len("RCCL_WORLD1 "):])
     assert out["ok"] and out["rccl_mapped"], out
-    assert "iar_in_pipeline_error" not in out, out
+    assert len(out["iar_kept"]) >= 3, out
     assert {"crop_allreduce", "fusion_allreduce", "fusion_layout"} <= set(out["exchange_ms"]), out
     assert "fusion_reduce" in out["exchange_ms_reduce"], out
 

@@ -167,6 +167,21 @@ int main(int argc, char** argv) {
   // (block b -> XCD b % 8), in microseconds and in plane steps of that kernel.
   if (auto drift_read = reinterpret_cast<int (*)(unsigned long long*, int)>(dlsym(h, "pp_debug_drift_read"))) {
     std::vector<unsigned long long> buf(2 * 1024 * 4);
+    if (auto xcc_read = reinterpret_cast<int (*)(unsigned*, int)>(dlsym(h, "pp_debug_drift_xcc_read"))) {
+      std::vector<unsigned> xcc(2 * 1024);
+      if (xcc_read(xcc.data(), (int)xcc.size()) > 0) {
+        // HW_REG_XCC_ID (low 4 bits: the XCD) of blocks 0..23 of kernel A, and how many blocks b have XCC_ID & 15 == b % 8
+        int agree = 0, nb = 0;
+        for (int b = 0; b < 1024; ++b) if (buf.size() && xcc[b]) { ++nb; }
+        printf("xcc ids of blocks 0..23 (kernel A, raw register & 0xff):");
+        for (int b = 0; b < 24; ++b) printf(" %u", xcc[b] & 0xffu);
+        for (int b = 0; b < 512; ++b) agree += ((xcc[b] & 15u) == (unsigned)(b % 8));
+        printf("\n  blocks 0..511 with XCC_ID & 15 == b %% 8: %d of 512; distinct ids per residue:", agree);
+        for (int r = 0; r < 8; ++r) { unsigned m = 0; for (int b = r; b < 512; b += 8) m |= 1u << (xcc[b] & 15u); printf(" %d:%#x", r, m); }
+        printf("\n");
+        (void)nb;
+      }
+    }
     if (drift_read(buf.data(), (int)buf.size()) > 0) {
       for (int k = 0; k < 2; ++k) {
         double step_us = 0.0; int nb = 0;
