@@ -140,6 +140,15 @@ int pp_recursive_gaussian_field_f32(pp_ctx* ctx, float* field, const pp_geom* g,
 int pp_recursive_gaussian_f32(pp_ctx* ctx, const float* in, float* out, const pp_geom* g,
                               const double sigma[3]);
 
+/* ONE directional pass of itk::RecursiveGaussianImageFilter over a scalar volume (in != out): order 0 the Gaussian, order 1 its
+ * first derivative along `axis` per VOXEL (a unit ramp answers 1; times sigma when normalize_across_scale, as ITK's
+ * NormalizeAcrossScale).  The building block of itk::GradientRecursiveGaussianImageFilter -- derivative along one axis, then
+ * Gaussians along the others -- which itk::ImageToImageMetricv4 runs over the moving image (sigma = its largest spacing) inside
+ * registration.Execute (registration/linear.py:238) as the metric's default gradient source; the host chains the passes
+ * (platipy_amd/registration/linear.py, itk_sampling=True). */
+int pp_recursive_gaussian_pass_f32(pp_ctx* ctx, const float* in, float* out, const pp_geom* g, int axis, double sigma, int order,
+                                   int normalize_across_scale);
+
 /* ---- warp / resample --------------------------------------------------------------- */
 /* out(x) = moving(x + D(x)), moving/field/out on one grid: itk::WarpImageFilter inside the
  * demons loop (edge = FLT_MAX sentinel) and sitk.Resample(m_image, tfm_total, interp)
@@ -294,6 +303,15 @@ int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, con
  * later call, else that call fails).  NULL / 0 restores the plain lattice (the default).  The host draws the variates
  * (platipy_amd/registration/linear.py, itk_sampling=True). */
 int pp_linear_set_sample_jitter(pp_ctx* ctx, const float* jitter, size_t nsamples);
+
+/* ITK's moving-image gradient source for the gradient-bearing metric entry points of this section (pp_meansq_affine_f32,
+ * pp_corr_moments_affine_f32, pp_mi_gradient_f32, pp_linear_optimize_f32): itk::ImageToImageMetricv4 (inside
+ * registration.Execute, registration/linear.py:238) by default does not differentiate the intensity interpolant but LINEARLY
+ * interpolates a gradient image it computes once per level with itk::GradientRecursiveGaussianImageFilter (sigma = the moving
+ * image's largest spacing).  `gradient` (device, caller-owned, valid until replaced): that image as three volumes
+ * [3][Z][Y][X] of the moving image's size `msize`, converted to moving-INDEX units (d intensity / d index); NULL restores the
+ * interpolant's analytic gradient (the default).  Built by the host from pp_recursive_gaussian_pass_f32. */
+int pp_linear_set_moving_gradient(pp_ctx* ctx, const float* gradient, const int msize[3]);
 
 /* Mutual-information metrics (SetMetricAsMattesMutualInformation / SetMetricAsJointHistogramMutualInformation,
  * registration/linear.py:145-148) over the same sample lattice: pass 1 returns the joint intensity histogram of the valid

@@ -44,7 +44,7 @@ def _nn_mask(mask, c):
     return mask[q[:, 2], q[:, 1], q[:, 0]] != 0
 
 
-def meansq_affine(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None, jitter=None):
+def meansq_affine(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None, jitter=None, moving_gradient=None):
     """-> 14 floats: sum (f-m)^2, count, d/dAm (row-major 9), d/dbm (3)."""
     Af, Am = np.asarray(Af, dtype=np.float64).reshape(3, 3), np.asarray(Am, dtype=np.float64).reshape(3, 3)
     bf, bm = np.asarray(bf, dtype=np.float64), np.asarray(bm, dtype=np.float64)
@@ -56,6 +56,8 @@ def meansq_affine(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask=None,
     cf, cm = v @ Af.T + bf, v @ Am.T + bm
     inf_, fval, _ = _sample(np.asarray(fixed), cf)
     inm, mval, g = _sample(np.asarray(moving), cm)
+    if moving_gradient is not None:     # ITK's filtered gradient image, linearly interpolated (index units), instead of the interpolant's
+        g = np.stack([_sample(np.asarray(moving_gradient[r]), cm)[1] for r in range(3)], axis=1)
     ok = inf_ & inm
     if fixed_mask is not None:
         ok &= np.where(inf_, _nn_mask(np.asarray(fixed_mask), np.where(inf_[:, None], cf, 0.0)), False)
@@ -71,7 +73,7 @@ def meansq_affine(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask=None,
     return out
 
 
-def corr_moments_affine(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None, jitter=None):
+def corr_moments_affine(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None, jitter=None, moving_gradient=None):
     """-> the 42 raw moments pp_corr_moments_affine_f32 accumulates (layout in include/platipy_amd.h)."""
     Af, Am = np.asarray(Af, dtype=np.float64).reshape(3, 3), np.asarray(Am, dtype=np.float64).reshape(3, 3)
     bf, bm = np.asarray(bf, dtype=np.float64), np.asarray(bm, dtype=np.float64)
@@ -83,6 +85,8 @@ def corr_moments_affine(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask
     cf, cm = v @ Af.T + bf, v @ Am.T + bm
     inf_, fval, _ = _sample(np.asarray(fixed), cf)
     inm, mval, g = _sample(np.asarray(moving), cm)
+    if moving_gradient is not None:     # ITK's filtered gradient image, linearly interpolated (index units), instead of the interpolant's
+        g = np.stack([_sample(np.asarray(moving_gradient[r]), cm)[1] for r in range(3)], axis=1)
     ok = inf_ & inm
     if fixed_mask is not None:
         ok &= np.where(inf_, _nn_mask(np.asarray(fixed_mask), np.where(inf_[:, None], cf, 0.0)), False)
@@ -112,7 +116,7 @@ def _bspline3_deriv(u):
     return np.where(a < 1.0, sg * (-2.0 * a + 1.5 * a * a), np.where(a < 2.0, sg * (-0.5 * (2.0 - a) ** 2), 0.0))
 
 
-def _mi_samples(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask, jitter=None):
+def _mi_samples(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask, jitter=None, moving_gradient=None):
     Af, Am = np.asarray(Af, dtype=np.float64).reshape(3, 3), np.asarray(Am, dtype=np.float64).reshape(3, 3)
     bf, bm = np.asarray(bf, dtype=np.float64), np.asarray(bm, dtype=np.float64)
     nv = int(vsize[0]) * int(vsize[1]) * int(vsize[2])
@@ -123,6 +127,8 @@ def _mi_samples(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask, moving
     cf, cm = v @ Af.T + bf, v @ Am.T + bm
     inf_, fval, _ = _sample(np.asarray(fixed), cf)
     inm, mval, g = _sample(np.asarray(moving), cm)
+    if moving_gradient is not None:     # ITK's filtered gradient image, linearly interpolated (index units), instead of the interpolant's
+        g = np.stack([_sample(np.asarray(moving_gradient[r]), cm)[1] for r in range(3)], axis=1)
     ok = inf_ & inm
     if fixed_mask is not None:
         ok &= np.where(inf_, _nn_mask(np.asarray(fixed_mask), np.where(inf_[:, None], cf, 0.0)), False)
@@ -152,8 +158,8 @@ def mi_histogram(fixed, moving, Af, bf, Am, bm, vsize, stride, bins, fixed_mask=
     return hist, float(len(f))
 
 
-def mi_gradient(fixed, moving, Af, bf, Am, bm, vsize, stride, bins, table, fixed_mask=None, moving_mask=None, jitter=None):
-    v, f, m, g = _mi_samples(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask, jitter)
+def mi_gradient(fixed, moving, Af, bf, Am, bm, vsize, stride, bins, table, fixed_mask=None, moving_mask=None, jitter=None, moving_gradient=None):
+    v, f, m, g = _mi_samples(fixed, moving, Af, bf, Am, bm, vsize, stride, fixed_mask, moving_mask, jitter, moving_gradient)
     nb, pad = int(bins["nbins"]), (2 if bins["kernel"] == 0 else 0)
     tab = np.asarray(table, dtype=np.float64).astype(np.float32).astype(np.float64)
     fb, _ = _mi_bins(f, bins["f_bin"], bins["f_norm_min"], pad, nb - 1 - pad)

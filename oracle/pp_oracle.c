@@ -769,11 +769,18 @@ typedef struct {
   double N0, N1, N2, N3, D1, D2, D3, D4, M1, M2, M3, M4, BN1, BN2, BN3, BN4, BM1, BM2, BM3, BM4;
 } rg_coef;
 
-static void rg_setup(double sigma, double spacing, rg_coef* k) {
+/* order 0: the Gaussian (RecursiveGaussianImageFilter::ZeroOrder).  order 1: its first derivative (FirstOrder): the
+ * second column of ITK's A1 / B1 / A2 / B2 tables, normalised by alpha1 = 2 (SN DD - DN SD) / SD^2 so that a unit ramp
+ * per voxel answers 1, times `scale` (sigma when NormalizeAcrossScale is on, negated for a negative spacing), and the
+ * anti-causal coefficients of an ANTISYMMETRIC response (ComputeRemainingCoefficients(symmetric = false)).  Recollection of
+ * ITK 5.3, parity unpinned; tests/test_oracle_independent.py holds the response against the analytic derivative of a
+ * Gaussian. */
+static void rg_setup_order(double sigma, double spacing, rg_coef* k, int order, double scale) {
   if (spacing < 0.0) spacing = -spacing;
   const double sigmad = sigma / spacing;
   const double W1 = 0.6681, L1 = -1.3932, W2 = 2.0787, L2 = -1.3732;
-  const double A1 = 1.3530, B1 = 1.8151, A2 = -0.3531, B2 = 0.0902; /* zero order */
+  const double A1 = order == 0 ? 1.3530 : -0.6724, B1 = order == 0 ? 1.8151 : -3.4327;
+  const double A2 = order == 0 ? -0.3531 : 0.6724, B2 = order == 0 ? 0.0902 : 0.6100;
   /* ComputeDCoefficients */
   {
     const double Cos1 = cos(W1 / sigmad), Cos2 = cos(W2 / sigmad);
@@ -803,16 +810,26 @@ static void rg_setup(double sigma, double spacing, rg_coef* k) {
     k->N3 += Exp1 * Exp2 * Exp2 * (B1 * Sin1 - A1 * Cos1);
     SN = k->N0 + k->N1 + k->N2 + k->N3;
   }
-  const double alpha0 = 2 * SN / SD - k->N0;
-  k->N0 *= 1.0 / alpha0; /* across_scale_normalization = 1 (NormalizeAcrossScale off) */
-  k->N1 *= 1.0 / alpha0;
-  k->N2 *= 1.0 / alpha0;
-  k->N3 *= 1.0 / alpha0;
-  /* ComputeRemainingCoefficients(symmetric = true) */
-  k->M1 = k->N1 - k->D1 * k->N0;
-  k->M2 = k->N2 - k->D2 * k->N0;
-  k->M3 = k->N3 - k->D3 * k->N0;
-  k->M4 = -k->D4 * k->N0;
+  double norm;
+  if (order == 0) {
+    const double alpha0 = 2 * SN / SD - k->N0;
+    norm = 1.0 / alpha0; /* across_scale_normalization = 1 for the zero order, whatever NormalizeAcrossScale says */
+  } else {
+    const double DD = k->D1 + 2 * k->D2 + 3 * k->D3 + 4 * k->D4;
+    const double DN = k->N1 + 2 * k->N2 + 3 * k->N3;
+    const double alpha1 = 2 * (SN * DD - DN * SD) / (SD * SD);
+    norm = scale / alpha1;
+  }
+  k->N0 *= norm;
+  k->N1 *= norm;
+  k->N2 *= norm;
+  k->N3 *= norm;
+  /* ComputeRemainingCoefficients(symmetric = (order == 0)) */
+  const double sgn = order == 0 ? 1.0 : -1.0;
+  k->M1 = sgn * (k->N1 - k->D1 * k->N0);
+  k->M2 = sgn * (k->N2 - k->D2 * k->N0);
+  k->M3 = sgn * (k->N3 - k->D3 * k->N0);
+  k->M4 = sgn * (-k->D4 * k->N0);
   const double SN2 = k->N0 + k->N1 + k->N2 + k->N3;
   const double SM = k->M1 + k->M2 + k->M3 + k->M4;
   const double SD2 = 1.0 + k->D1 + k->D2 + k->D3 + k->D4;
@@ -862,13 +879,19 @@ static void rg_filter_line(double* outs, const double* data, double* scratch, lo
 }
 
 /* one directional pass: read (double or float) -> filter in double -> store float */
+static int rg_pass_order(const double* in_d, const float* in_f, float* out, const int* n, int axis,
+                         double sigma, double spacing, int order, double scale);
 static int rg_pass(const double* in_d, const float* in_f, float* out, const int* n, int axis,
                    double sigma, double spacing) {
+  return rg_pass_order(in_d, in_f, out, n, axis, sigma, spacing, 0, 1.0);
+}
+static int rg_pass_order(const double* in_d, const float* in_f, float* out, const int* n, int axis,
+                         double sigma, double spacing, int order, double scale) {
   const long nx = n[0], ny = n[1], nz = n[2];
   const long len = n[axis];
   if (len < 4) return -5; /* ITK: "The number of pixels along direction is less than 4" */
   rg_coef k;
-  rg_setup(sigma, spacing, &k);
+  rg_setup_order(sigma, spacing, &k, order, scale);
   const long stride = axis == 0 ? 1 : (axis == 1 ? nx : nx * ny);
   const long na = axis == 0 ? ny : nx;               /* inner line-origin count */
   const long nb = axis == 2 ? ny : nz;               /* outer */
@@ -919,6 +942,15 @@ int orc_recursive_gaussian_vec_f64(double* field, const orc_geom* g, const doubl
   free(a);
   free(b);
   return rc;
+}
+
+/* One directional filter of the chain itk::GradientRecursiveGaussianImageFilter builds (the derivative filter along one axis,
+ * smoothing filters along the others): float image in, float image out, the line filtered in double. */
+int orc_recursive_gaussian_pass_f32(const float* in, float* out, const orc_geom* g, int axis, double sigma,
+                                    int order, int normalize_across_scale) {
+  if (axis < 0 || axis > 2 || (order != 0 && order != 1) || in == out) return -4;
+  const double scale = order == 1 ? (normalize_across_scale ? sigma : 1.0) * (g->spacing[axis] < 0.0 ? -1.0 : 1.0) : 1.0;
+  return rg_pass_order(NULL, in, out, g->size, axis, sigma, g->spacing[axis], order, scale);
 }
 
 int orc_recursive_gaussian_f32(const float* in, float* out, const orc_geom* g,

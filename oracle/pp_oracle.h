@@ -104,6 +104,9 @@ int orc_resample_vec_f64(const double* in, const orc_geom* gin, const orc_geom* 
 int orc_recursive_gaussian_vec_f64(double* field, const orc_geom* g, const double sigma[3]);
 int orc_recursive_gaussian_f32(const float* in, float* out, const orc_geom* g,
                                const double sigma[3]);
+/* one directional pass (order 0 / 1) of itk::RecursiveGaussianImageFilter: the parts of GradientRecursiveGaussianImageFilter */
+int orc_recursive_gaussian_pass_f32(const float* in, float* out, const orc_geom* g, int axis, double sigma,
+                                    int order, int normalize_across_scale);
 
 /* fusion.py:148-169 (vote_type "local"):  w = 1 / (DiscreteGaussian((T-M)^2, sigma^2) + eps). */
 int orc_weight_map_local(const float* target, const float* moving, const int size[3],

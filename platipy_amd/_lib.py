@@ -147,6 +147,8 @@ _SIGNATURES = {
                                               C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                               C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(C.c_double)]),
     "pp_linear_set_sample_jitter": (C.c_int, [_P, _P, C.c_size_t]),
+    "pp_linear_set_moving_gradient": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
+    "pp_recursive_gaussian_pass_f32": (C.c_int, [_P, _P, _P, C.POINTER(Geom), C.c_int, C.c_double, C.c_int, C.c_int]),
     "pp_mi_histogram_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(MiBins),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -468,6 +470,25 @@ class Context:
                 raise ValueError("set_sample_jitter: a contiguous float32 array [nsamples, 3]")
             self._chk(self.lib.pp_linear_set_sample_jitter(self.h, ptr(jitter), int(jitter.shape[0])), "pp_linear_set_sample_jitter")
         self._sample_jitter = jitter
+
+    def set_moving_gradient(self, gradient, msize=None):
+        """ITK's filtered gradient image for the gradient-bearing metric entry points (pp_linear_set_moving_gradient): a
+        contiguous float32 device tensor [3, Z, Y, X] in moving-index units, kept alive by this context until replaced; None
+        restores the interpolant's analytic gradient."""
+        if gradient is None:
+            self._chk(self.lib.pp_linear_set_moving_gradient(self.h, None, None), "pp_linear_set_moving_gradient")
+        else:
+            shape = tuple(gradient.shape)
+            if len(shape) != 4 or shape[0] != 3 or str(gradient.dtype).replace("torch.", "") != "float32":
+                raise ValueError("set_moving_gradient: a float32 array [3, Z, Y, X]")
+            size = msize if msize is not None else (shape[3], shape[2], shape[1])
+            self._chk(self.lib.pp_linear_set_moving_gradient(self.h, ptr(gradient), _i3(size)), "pp_linear_set_moving_gradient")
+        self._moving_gradient = gradient
+
+    def recursive_gaussian_pass(self, src, dst, geom, axis, sigma, order=0, normalize_across_scale=False):
+        """One directional pass of itk::RecursiveGaussianImageFilter (pp_recursive_gaussian_pass_f32): order 0 / 1 along `axis`."""
+        self._chk(self.lib.pp_recursive_gaussian_pass_f32(self.h, ptr(src), ptr(dst), C.byref(geom), int(axis), float(sigma), int(order),
+                                                          int(bool(normalize_across_scale))), "pp_recursive_gaussian_pass_f32")
 
     def linear_optimize(self, fixed, fsize, moving, msize, level, params, fixed_mask=None, moving_mask=None, history=0):
         """One level of linear_registration's optimisation in the library (pp_linear_optimize_f32).

@@ -1434,7 +1434,12 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   // D = 0 at the start.  With both generation-2 kernels in SUM mode nothing reads the field's buffer before it is written:
   // kernel A of iteration 0 replaces what it loads by zeros (nprev == 0), kernel B reads A's output only -- so the buffer
   // is cleared only when something else will read it (0 iterations, the first generation, PP_FUSED_SUM=0).
-  if (!(gen_a == 2 && gen_b == 2 && sum_mode && p->iterations > 0)) PP_HIP(ctx, hipMemsetAsync(field, 0, 3 * N * sizeof(float), ctx->stream));
+  // The skipped clear rests on one invariant: iteration 0's kernel B always runs (the halt flag can only be raised by the fold at
+  // the head of iteration 1's kernel A), so the buffer is written before anything returns it.  It is worth keeping only where it
+  // costs something -- an 805 MB memset at 512 x 512 x 256 -- so the latency-bound levels below 8 M voxels clear anyway (a few
+  // microseconds) and cannot return uninitialised memory whatever a later change does to the halt logic.
+  const bool skip_clear = gen_a == 2 && gen_b == 2 && sum_mode && p->iterations > 0 && N >= ((size_t)8 << 20);
+  if (!skip_clear) PP_HIP(ctx, hipMemsetAsync(field, 0, 3 * N * sizeof(float), ctx->stream));
   for (int it = 0; it < p->iterations; ++it) {
     // D = 0 warps the moving image onto itself exactly, so iteration 0 reads it directly.
     const float* mw_in = it == 0 ? moving : ((it & 1) ? MwA : MwB);

@@ -543,7 +543,7 @@ struct pp_steady_unroll<W, W> {
 #define PP_A_ESM_PAIRS 1
 #endif
 #ifndef PP_A_FLIP
-#define PP_A_FLIP 1
+#define PP_A_FLIP 0   // (measured, tools/r5/gpu6.sh: kernel B's role flip -1 % on B in three alternating rounds, kernel A's none)
 #endif
 #ifndef PP_B_FLIP
 #define PP_B_FLIP 1

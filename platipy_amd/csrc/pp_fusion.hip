@@ -239,6 +239,7 @@ struct msq_args {
   int vsize[3];
   int stride;
   const float* jit;   // ITK's per-sample jitter in virtual-index units, 3 floats per sample, or NULL (pp_linear_set_sample_jitter)
+  const float* grad;  // ITK's filtered gradient image of the moving image, 3 volumes in moving-INDEX units, or NULL (pp_linear_set_moving_gradient)
 };
 
 // itk::ImageRegistrationMethodv4::SetMetricSamplePoints (REGULAR): every sample point is the lattice voxel's physical point
@@ -261,6 +262,27 @@ __device__ __forceinline__ bool msq_locate(const double c[3], const pp_dims& n, 
     f[k] = (float)(c[k] - fl);
   }
   return true;
+}
+
+// itk::ImageToImageMetricv4 with UseMovingImageGradientFilter (the default): the moving-image gradient at a mapped point is the
+// LINEAR interpolation of a gradient image (GradientRecursiveGaussianImageFilter, sigma = the moving image's largest spacing),
+// not the derivative of the intensity interpolant.  `grad`: that image as three volumes of the moving image's size, already in
+// moving-index units; same eight corners and weights as the intensity sample.
+__device__ __forceinline__ void msq_gradient_image(const float* __restrict__ grad, const pp_dims& dm, int x0, int x1, int y0, int y1, int z0,
+                                                   int z1, float wx, float wy, float wz, float g[3]) {
+  const size_t sy = dm.nx, sz = (size_t)dm.nx * dm.ny, N = sz * dm.nz;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float* G = grad + r * N;
+    const float a000 = G[z0 * sz + y0 * sy + x0], a100 = G[z0 * sz + y0 * sy + x1];
+    const float a010 = G[z0 * sz + y1 * sy + x0], a110 = G[z0 * sz + y1 * sy + x1];
+    const float a001 = G[z1 * sz + y0 * sy + x0], a101 = G[z1 * sz + y0 * sy + x1];
+    const float a011 = G[z1 * sz + y1 * sy + x0], a111 = G[z1 * sz + y1 * sy + x1];
+    const float v00 = a000 + (a100 - a000) * wx, v10 = a010 + (a110 - a010) * wx;
+    const float v01 = a001 + (a101 - a001) * wx, v11 = a011 + (a111 - a011) * wx;
+    const float v0 = v00 + (v10 - v00) * wy, v1 = v01 + (v11 - v01) * wy;
+    g[r] = v0 + (v1 - v0) * wz;
+  }
 }
 
 // MODE 0: mean squares, NACC = 14 (layout above).
@@ -325,9 +347,14 @@ __global__ void __launch_bounds__(NT) k_metric_affine(const float* __restrict__ 
     // gradient of the trilinear interpolant, per moving voxel
     const float gx0 = (a100 - a000) + ((a110 - a010) - (a100 - a000)) * wy;
     const float gx1 = (a101 - a001) + ((a111 - a011) - (a101 - a001)) * wy;
-    const float gx = gx0 + (gx1 - gx0) * wz;
-    const float gy = (v10 - v00) + ((v11 - v01) - (v10 - v00)) * wz;
-    const float gz = v1 - v0;
+    float gx = gx0 + (gx1 - gx0) * wz;
+    float gy = (v10 - v00) + ((v11 - v01) - (v10 - v00)) * wz;
+    float gz = v1 - v0;
+    if (a.grad) {   // (uniform) ITK's filtered gradient image instead of the interpolant's derivative
+      float gi[3];
+      msq_gradient_image(a.grad, dm, x0, x1, y0, y1, z0, z1, wx, wy, wz, gi);
+      gx = gi[0]; gy = gi[1]; gz = gi[2];
+    }
     if (MODE == 0) {
       const double diff = (double)fval - (double)m;
       acc[0] += diff * diff;
@@ -943,7 +970,9 @@ struct mg_corners {
   float a000, a100, a010, a110, a001, a101, a011, a111;
   float wx, wy, wz;
 };
-template <int MODE>
+// GI: the moving-image gradient is sampled from ITK's filtered gradient image (msq_args::grad) instead of being derived from the
+// eight intensity corners -- its own instance, so that the default path keeps its registers.
+template <int MODE, bool GI = false>
 __global__ void __launch_bounds__(NT) k_metric_grad(const float* __restrict__ F, pp_dims df, const float* __restrict__ M, pp_dims dm,
                                                     const uint8_t* __restrict__ fmask, const uint8_t* __restrict__ mmask, msq_args a,
                                                     double* partials /* [grid][NACC] */, unsigned* __restrict__ ticket, void* mailbox,
@@ -966,6 +995,7 @@ __global__ void __launch_bounds__(NT) k_metric_grad(const float* __restrict__ F,
     double v[G][3];
     float fval[G];
     bool ok[G];
+    float gimg[GI ? G : 1][3];
 #pragma unroll
     for (int j = 0; j < G; ++j) {
       const size_t eq = e0 + (size_t)j * nthr;
@@ -1018,6 +1048,7 @@ __global__ void __launch_bounds__(NT) k_metric_grad(const float* __restrict__ F,
       g[j].a010 = M[z0 * sz + y1 * sy + x0]; g[j].a110 = M[z0 * sz + y1 * sy + x1];
       g[j].a001 = M[z1 * sz + y0 * sy + x0]; g[j].a101 = M[z1 * sz + y0 * sy + x1];
       g[j].a011 = M[z1 * sz + y1 * sy + x0]; g[j].a111 = M[z1 * sz + y1 * sy + x1];
+      if constexpr (GI) msq_gradient_image(a.grad, dm, x0, x1, y0, y1, z0, z1, g[j].wx, g[j].wy, g[j].wz, gimg[j]);
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     // every corner request before the first interpolation (see k_metric_values_lanes)
@@ -1037,16 +1068,18 @@ __global__ void __launch_bounds__(NT) k_metric_grad(const float* __restrict__ F,
       const float m = v0 + (v1 - v0) * c.wz;
       const float gx0 = (c.a100 - c.a000) + ((c.a110 - c.a010) - (c.a100 - c.a000)) * c.wy;
       const float gx1 = (c.a101 - c.a001) + ((c.a111 - c.a011) - (c.a101 - c.a001)) * c.wy;
-      const float gx = gx0 + (gx1 - gx0) * c.wz;
-      const float gy = (v10 - v00) + ((v11 - v01) - (v10 - v00)) * c.wz;
-      const float gz = v1 - v0;
-      const double w = ok[j] ? 1.0 : 0.0;   // (a rejected sample adds exact zeros)
+      const float gx = GI ? gimg[GI ? j : 0][0] : gx0 + (gx1 - gx0) * c.wz;
+      const float gy = GI ? gimg[GI ? j : 0][1] : (v10 - v00) + ((v11 - v01) - (v10 - v00)) * c.wz;
+      const float gz = GI ? gimg[GI ? j : 0][2] : v1 - v0;
+      const double w = ok[j] ? 1.0 : 0.0;   // (a rejected sample adds exact zeros -- also when the voxels under its clamped
+      // position hold Inf / NaN padding: the gradient is SELECTED away, not multiplied by zero)
+      const float gx_ = ok[j] ? gx : 0.0f, gy_ = ok[j] ? gy : 0.0f, gz_ = ok[j] ? gz : 0.0f;
       if constexpr (MODE == 0) {
         const double diff = ok[j] ? (double)fval[j] - (double)m : 0.0;
         acc[0] += diff * diff;
         acc[1] += w;
         const double sc = -2.0 * diff;
-        const double gg[3] = {sc * gx, sc * gy, sc * gz};
+        const double gg[3] = {sc * gx_, sc * gy_, sc * gz_};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           acc[2 + r * 3 + 0] += gg[r] * v[j][0];
@@ -1062,7 +1095,7 @@ __global__ void __launch_bounds__(NT) k_metric_grad(const float* __restrict__ F,
         acc[3] += fd * fd;
         acc[4] += md * md;
         acc[5] += fd * md;
-        const double gg[3] = {w * gx, w * gy, w * gz};
+        const double gg[3] = {w * gx_, w * gy_, w * gz_};
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -1150,6 +1183,7 @@ struct mi_args {
   int nbins, kernel;
   double f_bin, f_norm_min, m_bin, m_norm_min;
   const float* jit;   // (as msq_args)
+  const float* grad;  // (as msq_args)
 };
 
 __device__ __forceinline__ double mi_bspline3(double u) {   // cubic B-spline, support (-2, 2)
@@ -1210,6 +1244,7 @@ __device__ __forceinline__ bool mi_sample(const float* __restrict__ F, const pp_
   g[0] = gx0 + (gx1 - gx0) * wz;
   g[1] = (v10 - v00) + ((v11 - v01) - (v10 - v00)) * wz;
   g[2] = v1 - v0;
+  if (a.grad) msq_gradient_image(a.grad, dm, x0, x1, y0, y1, z0, z1, wx, wy, wz, g);   // (uniform; see msq_gradient_image)
   return true;
 }
 
@@ -1311,6 +1346,16 @@ static int pp_jitter_for(pp_ctx* ctx, size_t nsamp, const float** out) {
   return PP_OK;
 }
 
+// The context's gradient image for a moving image of `msize` voxels (NULL when none is set); one set for another size is an error.
+static int pp_gradient_for(pp_ctx* ctx, const int msize[3], const float** out) {
+  *out = nullptr;
+  if (!ctx->mgrad) return PP_OK;
+  PP_REQUIRE(ctx, ctx->mgrad_size[0] == msize[0] && ctx->mgrad_size[1] == msize[1] && ctx->mgrad_size[2] == msize[2],
+             "metric: the gradient image set by pp_linear_set_moving_gradient does not have the moving image's size");
+  *out = ctx->mgrad;
+  return PP_OK;
+}
+
 int mi_fill_args(pp_ctx* ctx, mi_args* a, const int fsize[3], const int msize[3], const double Af[9], const double bf[3], const double Am[9],
                  const double bm[3], const int vsize[3], int stride, const pp_mi_bins* bins) {
   PP_REQUIRE(ctx, fsize && msize && Af && bf && Am && bm && vsize && bins, "mutual information: NULL argument");
@@ -1334,6 +1379,8 @@ int mi_fill_args(pp_ctx* ctx, mi_args* a, const int fsize[3], const int msize[3]
     const size_t nsamp = ((size_t)vsize[0] * vsize[1] * vsize[2] + stride - 1) / stride;
     const int jrc = pp_jitter_for(ctx, nsamp, &a->jit);
     if (jrc) return jrc;
+    const int grc = pp_gradient_for(ctx, msize, &a->grad);
+    if (grc) return grc;
   }
   return PP_OK;
 }
@@ -1572,6 +1619,8 @@ static int metric_affine(pp_ctx* ctx, int mode, const float* fixed, const int fs
   {
     const int jrc = pp_jitter_for(ctx, nsamp, &a.jit);
     if (jrc) return jrc;
+    const int grc = pp_gradient_for(ctx, msize, &a.grad);
+    if (grc) return grc;
   }
   const pp_dims df{fsize[0], fsize[1], fsize[2]}, dm{msize[0], msize[1], msize[2]};
   const unsigned nb = grid_for(nsamp, 512u);   // (256 measures the same, 128 slower: profiles/round3_metric_probe_latency.txt)
@@ -1590,12 +1639,12 @@ static int metric_affine(pp_ctx* ctx, int mode, const float* fixed, const int fs
     unsigned long long seq1 = 0;
     rc = pp_mailbox(ctx, &mail1, &seq1);
     if (rc) return rc;
-    if (mode == 0)
-      hipLaunchKernelGGL((k_metric_grad<0>), dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, partials,
-                         ticket, mail1, seq1, fsamp);
-    else
-      hipLaunchKernelGGL((k_metric_grad<1>), dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, partials,
-                         ticket, mail1, seq1, fsamp);
+#define PP_MG_GO(MODEV, GIV)                                                                                                              \
+  hipLaunchKernelGGL((k_metric_grad<MODEV, GIV>), dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, \
+                     partials, ticket, mail1, seq1, fsamp)
+    if (a.grad) { if (mode == 0) PP_MG_GO(0, true); else PP_MG_GO(1, true); }
+    else { if (mode == 0) PP_MG_GO(0, false); else PP_MG_GO(1, false); }
+#undef PP_MG_GO
     PP_LAUNCH_CHECK(ctx, "k_metric_grad");
     return pp_mail_take(ctx, 0, nacc, seq1, result);
   }
@@ -1817,6 +1866,14 @@ int pp_mi_gradient_f32(pp_ctx* ctx, const float* fixed, const int fsize[3], cons
   rc = pp_mail_take(ctx, 0, 14, seq, sums);
   if (rc) return rc;
   memcpy(result, sums + 2, 12 * sizeof(double));
+  return PP_OK;
+}
+
+int pp_linear_set_moving_gradient(pp_ctx* ctx, const float* gradient, const int msize[3]) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, gradient == nullptr || msize != nullptr, "pp_linear_set_moving_gradient: a gradient image needs the moving image's size");
+  ctx->mgrad = gradient;
+  for (int k = 0; k < 3; ++k) ctx->mgrad_size[k] = gradient ? msize[k] : 0;
   return PP_OK;
 }
 

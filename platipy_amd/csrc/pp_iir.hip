@@ -24,11 +24,16 @@ struct rg_coef {
   double kn, km;  // steady-state gains SN/SD and SM/SD (edge extension)
 };
 
-// Deriche zero-order coefficients with ITK's normalisation (unit DC gain, symmetric).
-void rg_setup(double sigma, double spacing, rg_coef* k) {
+// Deriche coefficients with ITK's normalisation (itk::RecursiveGaussianImageFilter::SetUp).  order 0: the Gaussian (unit DC
+// gain, symmetric; what SmoothingRecursiveGaussian chains).  order 1: its first derivative (antisymmetric, normalised so that
+// a ramp of slope 1 per VOXEL answers 1; `scale` multiplies the response -- sigma in physical units when the caller asked
+// for NormalizeAcrossScale, and the sign of the spacing): the directional filter of itk::GradientRecursiveGaussianImageFilter,
+// which ImageToImageMetricv4 runs over the moving image (sigma = the largest spacing) for its default gradient source.
+void rg_setup(double sigma, double spacing, rg_coef* k, int order = 0, double scale = 1.0) {
   const double sd = sigma / std::fabs(spacing);
   const double W1 = 0.6681, L1 = -1.3932, W2 = 2.0787, L2 = -1.3732;
-  const double A1 = 1.3530, B1 = 1.8151, A2 = -0.3531, B2 = 0.0902;
+  const double A1 = order == 0 ? 1.3530 : -0.6724, B1 = order == 0 ? 1.8151 : -3.4327;
+  const double A2 = order == 0 ? -0.3531 : 0.6724, B2 = order == 0 ? 0.0902 : 0.6100;
   const double c1 = std::cos(W1 / sd), c2 = std::cos(W2 / sd), s1 = std::sin(W1 / sd), s2 = std::sin(W2 / sd);
   const double e1 = std::exp(L1 / sd), e2 = std::exp(L2 / sd);
   k->d4 = e1 * e1 * e2 * e2;
@@ -36,18 +41,27 @@ void rg_setup(double sigma, double spacing, rg_coef* k) {
   k->d2 = 4 * c2 * c1 * e1 * e2 + e1 * e1 + e2 * e2;
   k->d1 = -2 * (e2 * c2 + e1 * c1);
   const double SD = 1.0 + k->d1 + k->d2 + k->d3 + k->d4;
+  const double DD = k->d1 + 2 * k->d2 + 3 * k->d3 + 4 * k->d4;
   double n0 = A1 + A2;
   double n1 = e2 * (B2 * s2 - (A2 + 2 * A1) * c2) + e1 * (B1 * s1 - (A1 + 2 * A2) * c1);
   double n2 = 2 * e1 * e2 * ((A1 + A2) * c2 * c1 - (B1 * c2 * s1 + B2 * c1 * s2)) + A2 * e1 * e1 + A1 * e2 * e2;
   double n3 = e2 * e1 * e1 * (B2 * s2 - A2 * c2) + e1 * e2 * e2 * (B1 * s1 - A1 * c1);
   const double SN = n0 + n1 + n2 + n3;
-  const double alpha0 = 2 * SN / SD - n0;
-  n0 /= alpha0; n1 /= alpha0; n2 /= alpha0; n3 /= alpha0;
+  const double DN = n1 + 2 * n2 + 3 * n3;
+  double norm;
+  if (order == 0) {
+    norm = 1.0 / (2 * SN / SD - n0);                       // alpha0
+  } else {
+    const double alpha1 = 2 * (SN * DD - DN * SD) / (SD * SD);
+    norm = scale / alpha1;
+  }
+  n0 *= norm; n1 *= norm; n2 *= norm; n3 *= norm;
   k->n0 = n0; k->n1 = n1; k->n2 = n2; k->n3 = n3;
-  k->m1 = n1 - k->d1 * n0;
-  k->m2 = n2 - k->d2 * n0;
-  k->m3 = n3 - k->d3 * n0;
-  k->m4 = -k->d4 * n0;
+  const double sgn = order == 0 ? 1.0 : -1.0;              // ComputeRemainingCoefficients(symmetric = order 0)
+  k->m1 = sgn * (n1 - k->d1 * n0);
+  k->m2 = sgn * (n2 - k->d2 * n0);
+  k->m3 = sgn * (n3 - k->d3 * n0);
+  k->m4 = sgn * (-k->d4 * n0);
   k->kn = (n0 + n1 + n2 + n3) / SD;
   k->km = (k->m1 + k->m2 + k->m3 + k->m4) / SD;
 }
@@ -364,12 +378,13 @@ unsigned grid_for(size_t work) {
   return (unsigned)blocks;
 }
 
-int rg_pass(pp_ctx* ctx, int axis, const float* in, float* out, const pp_dims& d, int ncomp, double sigma, double spacing) {
+int rg_pass(pp_ctx* ctx, int axis, const float* in, float* out, const pp_dims& d, int ncomp, double sigma, double spacing, int order = 0,
+            double scale = 1.0) {
   const int len = axis == 0 ? d.nx : (axis == 1 ? d.ny : d.nz);
   if (len < 4) return pp_fail(ctx, PP_ERR_SIZE, "recursive Gaussian needs at least 4 voxels along axis %d (got %d)", axis, len);
   if (!(sigma > 0.0)) return pp_fail(ctx, PP_ERR_ARG, "recursive Gaussian: sigma must be positive");
   rg_coef k;
-  rg_setup(sigma, spacing, &k);
+  rg_setup(sigma, spacing, &k, order, scale);
   const size_t cstride = (size_t)d.nx * d.ny * d.nz;
   if (axis == 0) {
     const bool v4 = d.nx % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0) && cstride % 4 == 0;
@@ -423,6 +438,21 @@ int pp_recursive_gaussian_field_f32(pp_ctx* ctx, float* field, const pp_geom* g,
   float* t1 = cv.take<float>(3 * N);
   float* t2 = cv.take<float>(3 * N);
   return rg_all(ctx, field, field, t1, t2, g, 3, sigma);
+}
+
+int pp_recursive_gaussian_pass_f32(pp_ctx* ctx, const float* in, float* out, const pp_geom* g, int axis, double sigma, int order,
+                                   int normalize_across_scale) {
+  if (!ctx) return PP_ERR_ARG;
+  pp_device_guard dev_guard_(ctx);
+  PP_REQUIRE(ctx, in && out && in != out, "pp_recursive_gaussian_pass_f32: two distinct volumes");
+  PP_REQUIRE(ctx, axis >= 0 && axis < 3 && (order == 0 || order == 1), "pp_recursive_gaussian_pass_f32: axis 0..2, order 0 or 1");
+  int rc = pp_geom_check(ctx, g, "grid");
+  if (rc) return rc;
+  const pp_dims d{g->size[0], g->size[1], g->size[2]};
+  // first order: the response to a unit ramp per voxel is 1; ITK multiplies it by sigma (physical) when NormalizeAcrossScale
+  // is on and by the sign of the spacing
+  const double scale = order == 1 ? (normalize_across_scale ? sigma : 1.0) * (g->spacing[axis] < 0.0 ? -1.0 : 1.0) : 1.0;
+  return rg_pass(ctx, axis, in, out, d, 1, sigma, g->spacing[axis], order, scale);
 }
 
 int pp_recursive_gaussian_f32(pp_ctx* ctx, const float* in, float* out, const pp_geom* g, const double sigma[3]) {

@@ -49,6 +49,10 @@ struct pp_ctx {
   const float* jitter;
   size_t jitter_samples;
   unsigned long long jitter_gen;
+  // ITK's filtered gradient image of the moving image (pp_linear_set_moving_gradient): caller-owned, 3 volumes of mgrad_size
+  // voxels in moving-index units, NULL = the interpolant's analytic gradient.
+  const float* mgrad;
+  int mgrad_size[3];
   char err[512];
 };
 

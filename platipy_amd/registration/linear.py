@@ -488,10 +488,12 @@ def linear_registration(
 
     Returns (registered_image, CompositeTransform([initial_centering_transform, optimised_transform])).
 
-    `itk_sampling=True` (extension, default off) switches the declared sampling deviation off: the REGULAR sample points carry
-    ITK's seeded sub-voxel jitter -- registration.SetMetricSamplingPercentage(sampling_rate, seed=42), linear.py:151 -- drawn from
-    one Mersenne-Twister stream over the levels (`sampling_seed`, the reference's 42), for every metric and optimiser.  The
-    moving-image gradient stays the interpolant's analytic one (ITK filters a gradient image with a recursive Gaussian).
+    `itk_sampling=True` (extension, default off) switches the two declared metric deviations off: (i) the REGULAR sample points
+    carry ITK's seeded sub-voxel jitter -- registration.SetMetricSamplingPercentage(sampling_rate, seed=42), linear.py:151 --
+    drawn from one Mersenne-Twister stream over the levels (`sampling_seed`, the reference's 42); (ii) the moving-image gradient
+    is the linear interpolation of ITK's filtered gradient image (GradientRecursiveGaussianImageFilter with sigma = the moving
+    image's largest spacing, NormalizeAcrossScale, once per level: ImageToImageMetricv4's default) instead of the derivative
+    of the intensity interpolant.  For every metric and optimiser.
 
     The last three arguments are extensions for optimiser="exhaustive" (the reference hard-codes numberOfSteps = [10] * 6 at
     linear.py:221, 21^6 = 85.8 M evaluations on a six-parameter model, and says itself that "use is not currently
@@ -539,6 +541,7 @@ def linear_registration(
             params = _optimise_levels(ctx, ItkRegularJitter(sampling_seed), **_level_args(locals()))
         finally:
             ctx.set_sample_jitter(None)
+            ctx.set_moving_gradient(None)
 
     model.SetParameters(params)
     output_transform = model
@@ -581,6 +584,33 @@ class ItkRegularJitter:
         return np.ascontiguousarray((phys @ p2i.T).astype(np.float32))
 
 
+def itk_moving_gradient(ctx, moving):
+    """ImageToImageMetricv4's default moving-image gradient source, in moving-INDEX units [3, Z, Y, X] float32:
+    itk::GradientRecursiveGaussianImageFilter(sigma = largest spacing, NormalizeAcrossScale, UseImageDirection) -- per component
+    d the first-order recursive Gaussian along d, then the zero-order ones along the other axes in increasing order, divided by
+    spacing[d]; rotated to physical axes by the direction cosines; then d m / d index = (direction * spacing)^T applied to it."""
+    src = moving.tensor if moving.tensor.dtype == torch.float32 else moving.tensor.float()
+    src = src.contiguous()
+    geom = moving.geom()
+    sp = np.asarray(moving.spacing, dtype=np.float64)
+    sigma = float(sp.max())
+    comps = []
+    for d in range(3):
+        cur = torch.empty_like(src)
+        ctx.recursive_gaussian_pass(src, cur, geom, d, sigma, order=1, normalize_across_scale=True)
+        for ax in range(3):
+            if ax != d:
+                nxt = torch.empty_like(src)
+                ctx.recursive_gaussian_pass(cur, nxt, geom, ax, sigma, order=0, normalize_across_scale=True)
+                cur = nxt
+        comps.append(cur / float(sp[d]))
+    phys = torch.stack(comps)
+    D = np.asarray(moving.direction, dtype=np.float64).reshape(3, 3)
+    to_index = (D * sp[None, :]).T @ D          # (direction * spacing)^T (direction g): physical gradient -> per-index gradient
+    T = torch.tensor(to_index, dtype=torch.float32, device=src.device)
+    return torch.einsum("rc,czyx->rzyx", T, phys).contiguous()
+
+
 def _level_args(scope):
     keys = ("fixed_image", "moving_image", "fixed_mask", "moving_mask", "initial_transform", "model", "params", "metric", "opt",
             "shrink_factors", "smooth_sigmas", "sampling_rate", "number_of_iterations", "verbose", "exhaustive_steps",
@@ -601,6 +631,7 @@ def _optimise_levels(ctx, jitter, fixed_image, moving_image, fixed_mask, moving_
                           metric=metric)
         if jitter is not None:      # this level's perturbed sample points, for every metric kernel until the next level replaces them
             ctx.set_sample_jitter(torch.from_numpy(jitter.level(ms.vsize, ms.stride, vspacing, vdir)).to(fixed_image.device))
+            ctx.set_moving_gradient(itk_moving_gradient(ctx, m_l))      # ... and this level's filtered gradient image
 
         if opt == "lbfgsb":
             from scipy.optimize import fmin_l_bfgs_b

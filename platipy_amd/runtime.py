@@ -43,7 +43,13 @@ def release_all():
     import torch
 
     if torch.cuda.is_available():
-        torch.cuda.synchronize()          # nothing queued may still read what is about to be freed
+        # nothing queued may still read what is about to be freed -- on ANY device that owns a context (synchronize() alone
+        # waits for the current device only; ranks / threads may have driven others)
+        with _LOCK:
+            devices = {idx for idx, _ in _CTX}
+        devices.add(torch.cuda.current_device())
+        for idx in sorted(devices):
+            torch.cuda.synchronize(idx)
     with _LOCK:
         for c in _CTX.values():
             c.close()

@@ -128,15 +128,19 @@ def install_emu_runtime(setattr_fn=None):
         t = getattr(be.ctx, "_sample_jitter", None)
         return None if t is None else (t.numpy() if hasattr(t, "numpy") else np.asarray(t))
 
+    def mgrad():    # ... and the filtered gradient image, or None
+        t = getattr(be.ctx, "_moving_gradient", None)
+        return None if t is None else (t.numpy() if hasattr(t, "numpy") else np.asarray(t))
+
     def fake_meansq(fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None):
         tn = lambda t: None if t is None else t.numpy()  # noqa: E731
         return list(linear_oracle.meansq_affine(fixed.numpy(), moving.numpy(), Af, bf, Am, bm, vsize, stride, tn(fixed_mask),
-                                                tn(moving_mask), jitter=jit()))
+                                                tn(moving_mask), jitter=jit(), moving_gradient=mgrad()))
 
     def fake_corr(fixed, fsize, moving, msize, Af, bf, Am, bm, vsize, stride, fixed_mask=None, moving_mask=None):
         tn = lambda t: None if t is None else t.numpy()  # noqa: E731
         return list(linear_oracle.corr_moments_affine(fixed.numpy(), moving.numpy(), Af, bf, Am, bm, vsize, stride, tn(fixed_mask),
-                                                      tn(moving_mask), jitter=jit()))
+                                                      tn(moving_mask), jitter=jit(), moving_gradient=mgrad()))
 
     def fake_values(metric, fixed, fsize, moving, msize, Af, bf, Ams, bms, vsize, stride, fixed_mask=None, moving_mask=None):
         out = np.zeros((len(Ams), 6))

@@ -659,3 +659,58 @@ def test_linear_registration_with_itk_sampling(host_api):
     assert float(((fix - img.numpy()) ** 2).mean()) < 0.12 * float(((fix - mov) ** 2).mean())
     _, t3 = pa.registration.linear_registration(fi, mi, itk_sampling=True, sampling_seed=7, **kw)
     assert np.abs(t3.matrix_offset()[1] - o1).max() > 1e-9          # another seed, other sample points
+
+
+def test_itk_gradient_image_kernels_match_the_oracle(backend):
+    """itk_sampling's second half: the directional first / zero order recursive Gaussian passes against the oracle's, the
+    assembled gradient image (index units), and the metric kernels sampling it instead of differentiating the interpolant."""
+    import torch
+
+    from oracle import linear_oracle as L
+    from platipy_amd import _lib
+    from platipy_amd.image import Image
+    from platipy_amd.registration.linear import itk_moving_gradient
+
+    M = phantom((12, 13, 17), seed=301, noise=0)
+    sp = (1.5, 1.2, 2.5)
+    ctx = backend.ctx
+    geom = _lib.make_geom((17, 13, 12), sp)
+    for axis in range(3):
+        for order in (0, 1):
+            out = backend.dev(np.zeros_like(M))
+            ctx.recursive_gaussian_pass(backend.dev(M), out, geom, axis, 2.5, order, True)
+            want = O.recursive_gaussian_pass(O.Vol(M, sp), axis, 2.5, order, True).arr
+            np.testing.assert_allclose(backend.host(out), want, rtol=0, atol=2e-6 * np.abs(want).max() + 1e-6)
+    probe = backend.dev(M)
+    mt = probe if isinstance(probe, torch.Tensor) else torch.from_numpy(M)      # a cuda tensor (gpu) or a host tensor (emulator)
+    img = Image(mt, sp)
+    gi = itk_moving_gradient(ctx, img)
+    g_phys = O.gradient_recursive_gaussian(O.Vol(M, sp))
+    want_gi = g_phys * np.asarray(sp, dtype=np.float32)[:, None, None, None]
+    got_gi = gi.cpu().numpy() if hasattr(gi, "cpu") else np.asarray(gi)
+    np.testing.assert_allclose(got_gi, want_gi, rtol=0, atol=5e-6 * np.abs(want_gi).max())
+    # the metric with that gradient image
+    F = phantom((10, 14, 18), seed=300, noise=0)
+    Af, bf = np.eye(3) * 2.0, np.array([0.5, 0.5, 0.5])
+    Am = np.array([[1.9137, 0.1071, 0.0031], [-0.0813, 2.0519, 0.0207], [0.0109, 0.0043, 2.3011]])
+    bm = np.array([0.7123, -0.4057, 0.9131])
+    vsize, stride = (9, 7, 5), 2
+    args = (backend.dev(F), (18, 14, 10), backend.dev(M), (17, 13, 12), Af.ravel(), bf, Am.ravel(), bm, vsize, stride)
+    plain = np.array(ctx.meansq_affine(*args))
+    dev_gi = backend.dev(np.ascontiguousarray(want_gi))
+    ctx.set_moving_gradient(dev_gi, (17, 13, 12))
+    try:
+        got = np.array(ctx.meansq_affine(*args))
+        want = L.meansq_affine(F, M, Af, bf, Am, bm, vsize, stride, moving_gradient=want_gi)
+        assert got[1] == want[1] == plain[1]
+        np.testing.assert_allclose(got[0], plain[0], rtol=1e-12)                       # the value does not involve the gradient
+        np.testing.assert_allclose(got[2:], want[2:], rtol=2e-4, atol=1e-3 * np.abs(want[2:]).max())
+        assert np.abs(got[2:] - plain[2:]).max() > 1e-2 * np.abs(plain[2:]).max()      # ... its derivative does
+        gc = np.array(ctx.corr_moments_affine(*args))
+        wc = L.corr_moments_affine(F, M, Af, bf, Am, bm, vsize, stride, moving_gradient=want_gi)
+        np.testing.assert_allclose(gc, wc, rtol=3e-4, atol=1e-3 * np.abs(wc).max())
+        with pytest.raises(_lib.PlatipyAmdError):          # a gradient image of another size than the moving image's
+            ctx.meansq_affine(backend.dev(F), (18, 14, 10), backend.dev(F), (18, 14, 10), Af.ravel(), bf, Am.ravel(), bm, vsize, stride)
+    finally:
+        ctx.set_moving_gradient(None)
+    np.testing.assert_array_equal(np.array(ctx.meansq_affine(*args)), plain)

@@ -225,3 +225,30 @@ def test_recursive_gaussian_impulse_response(sigma):
         assert np.abs(line - gauss).max() <= 0.004 * gauss.max()                    # Deriche's 4th-order fit: 0.3 % of the peak
         # its small negative side lobes lower the second moment by 6.2 % at every scale (a property of the published fit)
         np.testing.assert_allclose((line * x * x).sum() / (sigma * sigma), 0.938, atol=0.003)
+
+
+def test_first_order_recursive_gaussian_is_the_derivative_of_a_gaussian():
+    """The FirstOrder directional filter (ITK's second column of Deriche constants, recalled from memory) held to things that do
+    not share its code: a ramp of slope s per voxel answers s exactly (the alpha1 normalisation), the impulse response is
+    antisymmetric, and it is the analytic derivative of the sampled Gaussian to within Deriche's approximation error (0.3 % of
+    the peak); NormalizeAcrossScale multiplies by sigma."""
+    n = 64
+    for sp, sigma in ((1.0, 2.0), (1.5, 2.5), (2.5, 2.5)):
+        ramp = np.zeros((n, 4, 4), np.float32) + (np.arange(n, dtype=np.float32) * 3.0)[:, None, None]
+        out = O.recursive_gaussian_pass(O.Vol(ramp, (1.0, 1.0, sp)), 2, sigma, 1, False).arr
+        np.testing.assert_allclose(out[24:40, 1, 2], 3.0, rtol=0, atol=3e-6)      # (away from the edge-extended ends)
+        imp = np.zeros((n, 4, 4), np.float32)
+        imp[32] = 1.0
+        r = O.recursive_gaussian_pass(O.Vol(imp, (1.0, 1.0, sp)), 2, sigma, 1, False).arr[:, 0, 0].astype(np.float64)
+        assert np.abs(r[33:42] + r[31:22:-1]).max() < 1e-7 and abs(r[32]) < 1e-7
+        x, sd = np.arange(n) - 32.0, sigma / sp
+        dG = -x / sd ** 2 * np.exp(-0.5 * (x / sd) ** 2) / (sd * np.sqrt(2 * np.pi))
+        assert np.abs(r - dG).max() < 4e-3 * np.abs(dG).max()
+        scaled = O.recursive_gaussian_pass(O.Vol(imp, (1.0, 1.0, sp)), 2, sigma, 1, True).arr[:, 0, 0]
+        np.testing.assert_allclose(scaled, sigma * r, rtol=0, atol=2e-6)
+    # the gradient filter of the metric: a linear intensity field a.x + b.y + c.z (mm) has the gradient sigma * (a, b, c) per mm
+    zz, yy, xx = np.meshgrid(np.arange(24) * 2.5, np.arange(30) * 1.2, np.arange(32) * 1.5, indexing="ij")
+    lin = (2.0 * xx - 3.0 * yy + 0.5 * zz).astype(np.float32)
+    g = O.gradient_recursive_gaussian(O.Vol(lin, (1.5, 1.2, 2.5)))
+    for c, want in enumerate((2.0, -3.0, 0.5)):
+        np.testing.assert_allclose(g[c][9:15, 12:18, 13:19], 2.5 * want, rtol=5e-4, atol=2e-5)   # (the volume's middle: the ends feel the edge extension)

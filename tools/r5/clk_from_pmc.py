@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Effective shader clock of the fused demons kernels from a `rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace` pass:
-clock = GRBM_GUI_ACTIVE / dispatch duration (MI355X_MICROARCH.md's method), mean over the launches of each kernel.
+clock = GRBM_GUI_ACTIVE / (XCDs x dispatch duration) (MI355X_MICROARCH.md's method; the counter is summed over the 8 XCDs of
+the device -- 8.6e6 cycles in 546 us would be 15.8 GHz otherwise), mean over the launches of each kernel.
 
     python tools/r5/clk_from_pmc.py <output dir> <label>
 """
@@ -36,6 +37,6 @@ for key in sorted(acc):
     rows = [(c, ns) for c, ns, g in acc[key] if g == gmax]
     cyc = sum(c for c, _ in rows) / len(rows)
     ns = sum(n for _, n in rows) / len(rows)
-    print(f"CLOCK {label}: {key}: {len(rows)} launches, GRBM_GUI_ACTIVE {cyc:.4g} cycles in {ns / 1e3:.1f} us -> {cyc / ns * 1e3:.0f} MHz")
+    print(f"CLOCK {label}: {key}: {len(rows)} launches, GRBM_GUI_ACTIVE {cyc:.4g} cycles (8 XCDs) in {ns / 1e3:.1f} us -> {cyc / ns * 1e3 / 8:.0f} MHz per XCD")
 if not acc:
     print(f"CLOCK {label}: no GRBM_GUI_ACTIVE rows under {d}")
