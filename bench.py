@@ -289,7 +289,8 @@ class Ranks:
         # (also a world of ONE rank when a launcher set WORLD_SIZE -- `torchrun --nproc-per-node 1 bench.py --gpus 1`: the
         # RCCL communicator, `device_id=` and every collective below then run on the one GPU there is, so the plumbing of
         # the N > 1 line is exercised wherever a single MI355X is; a plain `python bench.py` opens no process group)
-        if world > 1 or os.environ.get("WORLD_SIZE"):
+        launched = all(os.environ.get(k) for k in ("WORLD_SIZE", "RANK", "MASTER_PORT"))     # (a launcher's complete rendezvous)
+        if world > 1 or launched:
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
