@@ -1427,7 +1427,9 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     fu.sync_other = sync_words + SYNC_WORDS;
     fd.sync = sync_words + SYNC_WORDS;
     fd.sync_other = sync_words;
-    if (PP_SOFTSYNC > 0) PP_HIP(ctx, hipMemsetAsync(sync_words, 0, 2 * SYNC_WORDS * sizeof(unsigned), ctx->stream));
+    // (only the MASK instances publish progress: the latency-bound levels do not pay for the memset)
+    if ((PP_SOFTSYNC > 0 || PP_PAIRPRIO > 0) && (fu.masked || fd.masked))
+      PP_HIP(ctx, hipMemsetAsync(sync_words, 0, 2 * SYNC_WORDS * sizeof(unsigned), ctx->stream));
   }
   hipLaunchKernelGGL(k_stats_init, dim3(1), dim3(1), 0, ctx->stream, dst, hist, ctx->hist_cap);
   PP_LAUNCH_CHECK(ctx, "k_stats_init");

@@ -647,6 +647,65 @@ __device__ __forceinline__ void pp_softsync_step(pp_softsync& y, int n) {
     }
   }
 }
+// ---- Round 5: the two blocks of a CU, kept level by wave priority ------------------------------------------------------
+// -DPP_DRIFT shows where the drift comes from: block b + 256 of a 512-block launch -- the SECOND block on the CU that block b
+// got first (XCD-local indices j and j + 32) -- finishes 75-115 us (kernel A) / 125-175 us (kernel B) after block b, every pair,
+// while the first blocks of an XCD finish within 20 us of each other: the SIMD arbiter serves the older wave first, so the older
+// block runs as if alone and the younger one fills its gaps, and for the last fifth to third of the launch every CU runs ONE
+// block (8 waves: half the latency hiding).  With PP_PAIRPRIO each block publishes its finished plane steps (the soft barrier's
+// words), reads its partner's once a step, and every wave of the block that is BEHIND raises its issue priority (s_setprio) for
+// the next step: bang-bang control that keeps the pair within a step or two of each other, so that both finish together and
+// the CU runs two blocks to the end.  Wrong pairing (another dispatcher, another kernel's block as neighbour) only means a
+// priority that helps nobody.
+#ifndef PP_PAIRPRIO
+#define PP_PAIRPRIO 1   // (measured, tools/kbench/ab.sh main prio1 ...: pair end difference 97 / 153 us -> 6 us, iteration -1.9 .. -3.5 % at
+                        // 512 x 512 x 256, -3 % at 341 x 341 x 171, kernel B's fetch -11 %; profiles/round5_pair_priority.md)
+#endif
+#ifndef PP_PAIRPRIO_LEVEL
+#define PP_PAIRPRIO_LEVEL 1
+#endif
+#ifndef PP_PAIRPRIO_ASYM
+#define PP_PAIRPRIO_ASYM 0    // (measurement: the second block of a pair tolerates being this many more steps behind -- an anti-phase pair)
+#endif
+#ifndef PP_PAIRPRIO_SLACK
+#define PP_PAIRPRIO_SLACK 1   // behind = the partner's count (a step old) exceeds this block's finished steps n + 1 - 1 + SLACK
+#endif
+struct pp_pairprio {
+  unsigned* mine;            // this block's progress word
+  const unsigned* partner;   // the progress word of the block that shares the CU
+  unsigned seen;             // ... as last read (requested at the start of a step, used at its end)
+  bool has;                  // a partner exists in this launch
+  bool wave0;
+};
+__device__ __forceinline__ void pp_pairprio_init(pp_pairprio& y, const fused_args& a, unsigned* other_set) {
+  const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+  const unsigned ntiles = ((unsigned)a.gx * a.gy + (unsigned)a.gx2 * a.gy2) * (unsigned)a.gz;
+  const unsigned first = xcd * (unsigned)a.per_xcd;
+  const unsigned group = ntiles > first ? (ntiles - first < (unsigned)a.per_xcd ? ntiles - first : (unsigned)a.per_xcd) : 0u;
+  unsigned* const words = a.sync + xcd * PP_SYNC_GROUP;
+  const unsigned pj = j ^ 32u;
+  y.has = j < PP_SYNC_GROUP && pj < group && group <= PP_SYNC_GROUP;
+  y.mine = words + (j < PP_SYNC_GROUP ? j : 0u);
+  y.partner = words + (y.has ? pj : (j < PP_SYNC_GROUP ? j : 0u));
+  y.seen = 0u;
+  y.wave0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64;
+  if (threadIdx.x == 0 && j < PP_SYNC_GROUP) __hip_atomic_store(other_set + xcd * PP_SYNC_GROUP + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void pp_pairprio_peek(pp_pairprio& y) {   // every wave: one uniform word, beyond the (stale) vector cache AND L2 copy
+  if (y.has) y.seen = __hip_atomic_load(y.partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pp_pairprio_step(pp_pairprio& y, int n) {
+  if (y.wave0 && threadIdx.x == 0) __hip_atomic_store(y.mine, (unsigned)(n + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (y.has) {
+    const unsigned theirs = (unsigned)__builtin_amdgcn_readfirstlane((int)y.seen);
+    if (theirs > (unsigned)(n + PP_PAIRPRIO_SLACK + (PP_PAIRPRIO_ASYM ? (int)((blockIdx.x >> 8) & 1u) * PP_PAIRPRIO_ASYM : 0))) __builtin_amdgcn_s_setprio(PP_PAIRPRIO_LEVEL);
+    else __builtin_amdgcn_s_setprio(0);
+  }
+}
+__device__ __forceinline__ void pp_pairprio_finish(pp_pairprio& y) {
+  if (threadIdx.x == 0) __hip_atomic_store(y.mine, PP_SYNC_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // A block that has finished its march never holds anybody back.
 __device__ __forceinline__ void pp_softsync_finish(pp_softsync& y) {
   if (threadIdx.x == 0) __hip_atomic_store(y.mine, PP_SYNC_DONE, __ATOMIC_RELAXED, PP_SOFTSYNC_STORE_SCOPE);
@@ -744,6 +803,9 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
   constexpr bool SYNC = (PP_SOFTSYNC != 0) && MASK;
   pp_softsync ysync{};
   if constexpr (SYNC) pp_softsync_init(ysync, a, a.sync_other);
+  constexpr bool PRIO = (PP_PAIRPRIO != 0) && MASK;
+  pp_pairprio yprio{};
+  if constexpr (PRIO) pp_pairprio_init(yprio, a, a.sync_other);
 
   float4 dl[SUM ? 1 : 3][G::NSL], ul[3][G::NSL];   // raw D and U strips of the plane about to be published
   // (ALL: every lane loads -- a lane without a strip re-reads strip 0 of the tile, whose address pp_strip_setup gave it -- so
@@ -830,6 +892,7 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
     PP_TRACE_MARK(trace_on, 1, n, 0);
     PP_DRIFT_MARK(1, n, nsteps);
     if constexpr (SYNC) pp_softsync_peek(ysync);
+    if constexpr (PRIO) pp_pairprio_peek(yprio);
     // ---- interval 1: y pass of plane `cur` (reads s_x) | publish plane `nxt` (writes s_u) ----
     if (fresh_cur) {
 #pragma unroll
@@ -954,6 +1017,7 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
     // ---- interval 2: x pass of plane `nxt` (XS: already done above; one barrier hands the buffers over) ----
     PP_TRACE_MARK(trace_on, 1, n, 1);
     if constexpr (SYNC) pp_softsync_step(ysync, n);
+    if constexpr (PRIO) pp_pairprio_step(yprio, n);
     if (fresh_next) {
       __syncthreads();
       PP_TRACE_MARK(trace_on, 1, n, 2);
@@ -990,6 +1054,7 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
   fused2_plane_loop<R, UNROLL>(step_general, nsteps);
 #endif
   if constexpr (SYNC) pp_softsync_finish(ysync);
+  if constexpr (PRIO) pp_pairprio_finish(yprio);
 }
 
 // SH 0 / 1: every tile of that shape.  SH 2: tiles of both shapes in one launch (fused_args: gx2 > 0) -- 64 x 16 wherever a
@@ -1202,6 +1267,9 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
   constexpr bool SYNC = (PP_SOFTSYNC != 0) && MASK;
   pp_softsync ysync{};
   if constexpr (SYNC) pp_softsync_init(ysync, a, a.sync_other);
+  constexpr bool PRIO = (PP_PAIRPRIO != 0) && MASK;
+  pp_pairprio yprio{};
+  if constexpr (PRIO) pp_pairprio_init(yprio, a, a.sync_other);
 
   float bm = 0.0f, bf = 0.0f;          // border ring values of the plane about to be published
   PP_ZWIN(win_, G::KU);                // plane two ahead of the window centre, in flight
@@ -1445,6 +1513,7 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
     PP_TRACE_MARK(trace_on, 0, n, 0);
     PP_DRIFT_MARK(0, n, nsteps);
     if constexpr (SYNC) pp_softsync_peek(ysync);
+    if constexpr (PRIO) pp_pairprio_peek(yprio);
     // ---- interval 1: x pass of plane `cur` (s_u -> s_x) | publish the image tile of plane `nxt` ----
     if (fresh_next) publish();
     if (fresh_cur) fused2_xpass<R, NXI, 3 * G::XI>(s_u, s_x, a.wx, xsrc, xdst);
@@ -1530,6 +1599,7 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
     if constexpr (SUM) load_dsum(zo + 1, steady_tag);
     PP_TRACE_MARK(trace_on, 0, n, 3);
     if constexpr (SYNC) pp_softsync_step(ysync, n);
+    if constexpr (PRIO) pp_pairprio_step(yprio, n);
     if (fresh_cur || fresh_next) __syncthreads();
     PP_TRACE_MARK(trace_on, 0, n, 4);
   };
@@ -1542,6 +1612,7 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
   fused2_plane_loop<R, UNROLL>(step_general, nsteps);
 #endif
   if constexpr (SYNC) pp_softsync_finish(ysync);
+  if constexpr (PRIO) pp_pairprio_finish(yprio);
   double r_ssd = (double)a_ssd, r_ssc = (double)a_ssc, r_n = (double)a_n;
   pp_block_sum3_shfl<NTH>(r_ssd, r_ssc, r_n, reinterpret_cast<double*>(s_u));
   if (t == 0) {

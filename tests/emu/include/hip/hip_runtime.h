@@ -162,6 +162,7 @@ static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c);
 static inline float __fdividef(float a, float b) { return a / b; }
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))   // v_rcp_f32 (1 ulp) on the GPU
 static inline void __builtin_amdgcn_sched_barrier(int) {}                  // (a scheduling hint: nothing to emulate)
+static inline void __builtin_amdgcn_s_setprio(short) {}                    // (an issue-priority hint: nothing to emulate)
 static inline void __builtin_amdgcn_s_sleep(int) {}                        // (a pause between two polls of a word another block writes)
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // (only ever applied to wave-uniform values)
 static inline unsigned __umul24(unsigned a, unsigned b) { return (unsigned)((unsigned long long)(a & 0xffffffu) * (b & 0xffffffu)); }

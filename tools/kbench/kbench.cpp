@@ -192,6 +192,25 @@ int main(int argc, char** argv) {
         if (!nb) continue;
         step_us /= nb;   // mean time from the first to the last quarter mark = 3/4 of a march
         printf("drift kernel %c: %d blocks, first-to-last quarter mark %.1f us\n", k ? 'B' : 'A', nb, step_us);
+        // Do the two blocks that (presumably) share a CU -- XCD-local indices j and j + 32, i.e. blocks b and b + 256 of a
+        // 512-block launch -- finish together?  d = end stamp of b + 256 minus end stamp of b.
+        {
+          double sum = 0.0, sabs = 0.0, lo = 1e30, hi = -1e30; int np = 0;
+          double lo_first = 1e30, hi_first = -1e30, lo_second = 1e30, hi_second = -1e30;
+          for (int b = 0; b < 256; ++b) {
+            const unsigned long long e0 = buf[((size_t)k * 1024 + b) * 4 + 3], e1 = buf[((size_t)k * 1024 + b + 256) * 4 + 3];
+            if (!e0 || !e1) continue;
+            const double dd = 0.01 * ((double)e1 - (double)e0);
+            sum += dd; sabs += dd < 0 ? -dd : dd; if (dd < lo) lo = dd; if (dd > hi) hi = dd; ++np;
+            if ((b & 7) == 0) {   // XCD 0 only: spread inside each half of the run
+              const double t0 = 0.01 * (double)e0, t1 = 0.01 * (double)e1;
+              if (t0 < lo_first) lo_first = t0; if (t0 > hi_first) hi_first = t0;
+              if (t1 < lo_second) lo_second = t1; if (t1 > hi_second) hi_second = t1;
+            }
+          }
+          if (np) printf("  pairs (b, b + 256): end(b + 256) - end(b) mean %.1f us, mean |.| %.1f us, min %.1f, max %.1f over %d pairs; xcd 0: end spread of blocks j < 32 %.1f us, of j >= 32 %.1f us\n",
+                         sum / np, sabs / np, lo, hi, np, hi_first - lo_first, hi_second - lo_second);
+        }
         for (int x = 0; x < 8; ++x) {
           printf("  xcd %d:", x);
           for (int q = 0; q < 4; ++q) {
