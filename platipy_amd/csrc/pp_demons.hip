@@ -455,9 +455,27 @@ struct fused_args {
 
 // Tile of this block (see the grid note above); false for the few surplus blocks of the last XCD run.  `region`: which
 // of the two tile regions of a mixed launch the caller's tile shape belongs to (0 when there is one shape).
+// PP_PAIR_MIX (round 5): tile columns differ systematically in how long a block takes on them (x-border tiles re-read their
+// clamped halo from lines they already hold; at 512 x 512 x 256 kernel A's columns 0, 3, 4, 7 end ~18 us and kernel B's
+// columns 0, 7 ~33 us before the others), and the dispatcher gives a CU the XCD run's blocks j and j + 32 -- the SAME column
+// twice when the run is a whole number of tile rows.  So the second block of a CU takes its x-NEIGHBOUR's tile instead
+// (rank ^ 1, where both ranks lie in the second half of this XCD's run, in the 64 x 16 region and in one tile row: a bijection
+// on the tiles): every CU then hosts a slow and a fast column, and the pair priority (pp_demons_fused2.h) levels them.
+// Measured with it: an XCD's blocks end within 11 us (A) / 16 us (B) of each other instead of 27 / 40, iteration -2.0 .. -2.8 %.
+#ifndef PP_PAIR_MIX
+#define PP_PAIR_MIX 1
+#endif
 __device__ __forceinline__ unsigned fused_rank(const fused_args& a) {
   const unsigned b = blockIdx.x;
-  return (b & 7u) * (unsigned)a.per_xcd + (b >> 3);
+  const unsigned first = (b & 7u) * (unsigned)a.per_xcd, j = b >> 3;
+  unsigned rank = first + j;
+#if PP_PAIR_MIX
+  if (j >= 32u) {
+    const unsigned lo = rank & ~1u, hi = lo | 1u, n1 = (unsigned)a.gx * a.gy * a.gz;
+    if (lo >= first + 32u && hi < first + (unsigned)a.per_xcd && hi < n1 && (hi % (unsigned)a.gx) != 0u) rank ^= 1u;
+  }
+#endif
+  return rank;
 }
 __device__ __forceinline__ int fused_region(const fused_args& a) {   // (surplus blocks report region 0 and fail fused_tile there)
   const unsigned n1 = (unsigned)a.gx * a.gy * a.gz, n2 = (unsigned)a.gx2 * a.gy2 * a.gz, rank = fused_rank(a);

@@ -838,3 +838,34 @@ def test_fused_discrete_gaussian_equals_the_three_passes(backend, shape, monkeyp
             out[mode] = backend.host(o).copy()
         np.testing.assert_array_equal(out["0"], out["1"])
         assert np.abs(out["1"] - img).max() > 1.0
+
+
+def test_fused_demons_pair_mix_visits_every_tile_once(backend, monkeypatch):
+    """PP_PAIR_MIX: the second block of a CU (XCD-run index j >= 32) takes its x-neighbour's tile.  Only launches with more
+    than 32 tiles per XCD ever swap, which the other tests' volumes never reach: 512 x 544 x 2 has 8 x 34 = 272 tiles of
+    64 x 16 (34 per XCD), so ranks 32 / 33 of every XCD trade places.  A tile computed twice or never shows at once: against
+    the ORACLE (and the staged schedule), MASK instances forced (pair priority and the progress words included)."""
+    shape, spacing, origin = (2, 544, 512), (1.0, 1.0, 2.0), (0.0, 0.0, 0.0)
+    fix = phantom(shape, seed=60)
+    mov = (phantom(shape, seed=60, noise=0) + 30.0 * smooth_noise(shape, 61, cells=6)).astype(np.float32)
+    p = _demons_params(backend.ctx, 2, spacing, _lib.DEMONS_FUSED, max_rms=0.0)
+    monkeypatch.setenv("PP_FUSED_MASK", "1")
+    monkeypatch.setenv("PP_FUSED_TILE", "0")
+    f = backend.empty((3,) + shape)
+    st = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, f)
+    got = backend.host(f).copy()
+    flt = O.DemonsFilter()
+    flt.SetSmoothUpdateField(True)
+    flt.SetSmoothDisplacementField(True)
+    flt.SetStandardDeviations([1.5 / s for s in spacing])
+    flt.SetNumberOfIterations(2)
+    flt.SetMaximumRMSError(0.0)
+    want = flt.Execute(O.Vol(fix, spacing, origin), O.Vol(mov, spacing, origin)).arr
+    err = np.abs(got - want)
+    assert err.max() <= 2e-3 and np.sqrt((err ** 2).mean()) <= 5e-5, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    assert st.n_pixels == flt.stats.n_pixels == fix.size and st.elapsed_iterations == 2
+    np.testing.assert_allclose(st.metric, flt.stats.metric, rtol=1e-6)
+    monkeypatch.setenv("PP_FUSED_MASK", "0")      # the branchy instances on the same launch geometry: bit-identical
+    f2 = backend.empty((3,) + shape)
+    backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, f2)
+    np.testing.assert_array_equal(backend.host(f2).view(np.uint32), got.view(np.uint32))

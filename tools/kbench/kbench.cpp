@@ -183,6 +183,16 @@ int main(int argc, char** argv) {
       }
     }
     if (drift_read(buf.data(), (int)buf.size()) > 0) {
+      if (const char* dump = getenv("KB_DRIFT_DUMP")) {   // raw stamps: kernel block q0 q1 q2 q3 (10 ns ticks), for offline analysis
+        if (FILE* fh = fopen(dump, "w")) {
+          for (int k = 0; k < 2; ++k)
+            for (int b = 0; b < 1024; ++b) {
+              const unsigned long long* e = &buf[((size_t)k * 1024 + b) * 4];
+              if (e[3]) fprintf(fh, "%d %d %llu %llu %llu %llu\n", k, b, e[0], e[1], e[2], e[3]);
+            }
+          fclose(fh);
+        }
+      }
       for (int k = 0; k < 2; ++k) {
         double step_us = 0.0; int nb = 0;
         for (int b = 0; b < 1024; ++b) {
