@@ -411,6 +411,10 @@ def main():
     ap.add_argument("--no-registration", action="store_true")
     ap.add_argument("--no-atlas", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="time the region without the per-launch HIP events (no roofline block)")
+    ap.add_argument("--kernel-events-every", type=int, default=5, metavar="K",
+                    help="bracket every K-th launch of each kernel with HIP events inside the timed region (a pair of events costs the "
+                         "stream ~7 us, 1.4 %% of a 0.5 ms kernel: with K = 5 the timed region carries a fifth of that and `avg_launch_ms` "
+                         "is the mean of steps * repeats / K bracketed launches per kernel); 1 brackets every launch")
     ap.add_argument("--repeats", type=int, default=5, help="the timed block of --steps iterations is run this many times; `value` and "
                     "`ms_per_step` are the MEDIAN block's, min / max are reported beside it (boxes differ by several per cent run to run)")
     ap.add_argument("--pmc-calibration", action="store_true",
@@ -468,7 +472,7 @@ def main():
         p.iterations = args.warmup
         ctx.demons_execute(fixed, moving, geom, p, field, want_stats=False)
     torch.cuda.synchronize()
-    ctx.profile_enable(not args.no_kernel_events)
+    ctx.profile_enable(not args.no_kernel_events, every=max(1, args.kernel_events_every))
     p.iterations = args.steps
     # The timed region -- exactly --steps iterations between barrier + synchronize on both sides, maximum over ranks -- is
     # run --repeats times; the MEDIAN block is the one reported (per-kernel HIP events accumulate over all of them).
@@ -547,6 +551,8 @@ def main():
                                    f"schedule {args.variant}", "parallelism": f"1 atlas-to-target registration per GPU x{world}"},
             "ranks": balance,
             "repeats": repeats,
+            # HIP events bracket every K-th launch of each kernel inside the timed region (kernels[*].launches = bracketed launches)
+            "kernel_events_every": (None if args.no_kernel_events else max(1, args.kernel_events_every)),
             "roofline": roofline,
             "roofline_iteration": {"achieved": iter_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": iter_gbps / HBM_PEAK_GBS,
                                    "compulsory_bytes_per_voxel": iter_bytes,

@@ -98,8 +98,10 @@ size_t pp_workspace_bytes(const pp_ctx* ctx);
 
 /* Optional per-kernel timing with HIP events recorded on the ctx stream around every kernel
  * launch of the demons loop (bench.py's roofline figures).  Off by default: when off no event
- * is created or recorded.  pp_profile_read synchronises, returns the number of distinct
- * kernels (<= cap entries written) and resets the accumulators. */
+ * is created or recorded.  `on` = 1 brackets every launch, `on` = k > 1 every k-th launch of each
+ * kernel (a pair of events costs the stream ~7 us); `launches` counts the bracketed ones.
+ * pp_profile_read synchronises, returns the number of distinct kernels (<= cap entries written)
+ * and resets the accumulators. */
 typedef struct {
   char name[48];
   int launches;

@@ -273,8 +273,9 @@ class Context:
     def workspace_bytes(self):
         return self.lib.pp_workspace_bytes(self.h)
 
-    def profile_enable(self, on=True):
-        self._chk(self.lib.pp_profile_enable(self.h, int(bool(on))), "pp_profile_enable")
+    def profile_enable(self, on=True, every=1):
+        """Per-launch HIP events around the demons kernels; `every` = k > 1 brackets every k-th launch of each kernel."""
+        self._chk(self.lib.pp_profile_enable(self.h, (max(1, int(every)) if on else 0)), "pp_profile_enable")
 
     def profile_read(self):
         """{kernel name: (launches, total ms)} since the last read (synchronises the stream)."""

@@ -22,6 +22,10 @@ struct pp_profiler {
   std::vector<hipEvent_t> pool;      // idle events
   int open_slot = -1;
   hipEvent_t open_a = nullptr;
+  // Sampling: a pair of events costs the stream ~7 us (3.7 us each: measured as profiled - unprofiled time per launch in
+  // tools/kbench), 1.4 % of a 0.5 ms kernel.  With period k only every k-th launch of each kernel name is bracketed.
+  int period = 1;
+  std::vector<int> seen;             // launches met per slot (bracketed or not)
 };
 
 static hipEvent_t prof_event(pp_profiler* p) {
@@ -44,6 +48,12 @@ void pp_prof_begin(pp_ctx* ctx, const char* kernel_name) {
   if (slot < 0) {
     p->names.emplace_back(kernel_name);
     slot = (int)p->names.size() - 1;
+  }
+  if ((int)p->seen.size() <= slot) p->seen.resize(slot + 1, 0);
+  const int nth = p->seen[slot]++;
+  if (p->period > 1 && (nth % p->period) != 0) {   // not a sampled launch
+    p->open_slot = -1;
+    return;
   }
   p->open_slot = slot;
   p->open_a = prof_event(p);
@@ -228,6 +238,7 @@ int pp_profile_enable(pp_ctx* ctx, int on) {
   if (!ctx) return PP_ERR_ARG;
   pp_device_guard dev_guard_(ctx);
   if (on && !ctx->prof) ctx->prof = new pp_profiler();
+  if (on && ctx->prof) ctx->prof->period = on > 1 ? on : 1;   // on = k > 1: bracket every k-th launch of each kernel
   if (!on && ctx->prof) {
     PP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (auto& s : ctx->prof->spans) {
