@@ -198,6 +198,106 @@ __global__ void __launch_bounds__(NT) k_rg_strided_seg(const float* __restrict__
   }
 }
 
+// Round 5: the same single sweep at FOUR waves per SIMD instead of one.  k_rg_strided_seg keeps two 32-voxel segments, the
+// causal results of a segment and two filter states in registers, its loops fully unrolled: 256 VGPRs (AGPR spills included),
+// ONE wave per SIMD -- a wave issues a burst of 32 loads, waits out the HBM latency with nothing else to run, computes, stores:
+// 2.6 TB/s on 8 B/voxel, neither the fp64 pipe (~35 % busy) nor HBM anywhere near its limit.  Here the causal results of the
+// segment in flight live in LDS (128 B a thread, [i][thread] layout: conflict-free), whole segments run a branch-free body and
+// only the line's last, partial segments the guarded one: <= 128 VGPRs, four waves a SIMD.  Same operations in the same order
+// per voxel: bit-identical to k_rg_strided_seg (tests: test_recursive_gaussian_*).
+// (Addressing: one buffer resource per volume, a 32-bit per-lane byte offset of the line's first voxel and the plane / row
+// offset in the instruction's SCALAR offset -- with 64-bit per-element pointers the compiler kept 32 strided offsets alive in
+// 64 more registers.  The host takes this kernel only when a component spans < 2^32 bytes.)
+__device__ __forceinline__ float rg_bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void rg_bst(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+#ifndef PP_RG_SEG2_BLOCKS
+#define PP_RG_SEG2_BLOCKS 2   // resident 256-thread blocks per CU the kernel is compiled for (measured, 512 x 512 x 256 field: 2 -> 1.31 ms, 3 -> 1.44 (168 VGPRs), 4 -> 1.96 (128 VGPRs + 208 B of scratch); the old kernel 1.87)
+#endif
+// (RG_AFTER: the conversion of sample i may not run ahead of the recursion -- left alone, the scheduler converts a whole
+// segment up front and the 32 doubles cost 64 registers.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RG_AFTER(x, dep) asm volatile("" : "+v"(x) : "v"(dep))
+#else
+#define RG_AFTER(x, dep) ((void)0)
+#endif
+template <int AXIS>
+__global__ void __launch_bounds__(NT, PP_RG_SEG2_BLOCKS) k_rg_strided_seg2(const float* __restrict__ in, float* __restrict__ out, pp_dims d,
+                                                           size_t cstride, rg_coef k) {
+  constexpr int S = RG_SEG;
+  __shared__ float cbuf[S][NT];   // causal result i of this thread's segment: cbuf[i][threadIdx.x]
+  const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (size_t)blockIdx.y * cstride), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)blockIdx.y * cstride, 0, -1, 0x00020000);
+  const int nother = AXIS == 1 ? d.nz : d.ny;
+  const size_t nlines = (size_t)d.nx * nother;
+  const int len = AXIS == 1 ? d.ny : d.nz;
+  const unsigned stride4 = (AXIS == 1 ? (unsigned)d.nx : (unsigned)d.nx * (unsigned)d.ny) * 4u;   // bytes between a line's voxels
+  const int t = threadIdx.x;
+  {   // ONE line per thread, the grid covers the lines exactly (inside a grid-stride loop the compiler moves the two segment
+      // arrays to scratch: 4.3 KB a lane); no barrier in this kernel, so surplus threads simply leave
+    const size_t l = (size_t)blockIdx.x * NT + t;
+    if (l >= nlines) return;
+    const unsigned x = (unsigned)(l % d.nx);
+    const unsigned o = (unsigned)(l / d.nx);
+    const unsigned voff = (AXIS == 1 ? o * (unsigned)d.nx * (unsigned)d.ny + x : o * (unsigned)d.nx + x) * 4u;
+    float wa[S], wb[S];
+    // One body for every segment: voxels past the line's end are read as its LAST voxel (a clamped scalar offset) and never
+    // stored.  The anti-causal state that ITK initialises at the line's end -- x = edge, y = edge * km, the filter's steady
+    // state for a constant -- is then initialised up to 2 S - 1 voxels further on, on the replicated edge, and stays at that
+    // steady state until it reaches the line (to double rounding: the stored floats are those of the guarded form but for
+    // the one-in-millions value at a rounding boundary).
+    auto load = [&](float (&w)[S], int a) __attribute__((always_inline)) {
+      if (a + S <= len) {
+        const unsigned s0 = (unsigned)a * stride4;
+#pragma unroll
+        for (int i = 0; i < S; ++i) w[i] = rg_bld(r_in, voff, s0 + (unsigned)i * stride4);
+      } else {
+#pragma unroll
+        for (int i = 0; i < S; ++i) w[i] = rg_bld(r_in, voff, (unsigned)(a + i < len ? a + i : len - 1) * stride4);
+      }
+    };
+    rg_state sc;
+    auto segment = [&](const float (&m)[S], const float (&la)[S], int a) __attribute__((always_inline)) {
+      const unsigned s0 = (unsigned)a * stride4;
+      const bool whole = a + S <= len;
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        double xd = (double)m[i];
+        RG_AFTER(xd, sc.y1);
+        cbuf[i][t] = (float)rg_step_causal(sc, xd, k);
+      }
+      rg_state sa;
+      rg_init_anti(sa, (double)la[S - 1], k);
+#pragma unroll
+      for (int i = S - 1; i >= 0; --i) {
+        double xd = (double)la[i];
+        RG_AFTER(xd, sa.y1);
+        (void)rg_step_anti(sa, xd, k);
+      }
+#pragma unroll
+      for (int i = S - 1; i >= 0; --i) {
+        double xd = (double)m[i];
+        RG_AFTER(xd, sa.y1);
+        const float y = (float)((double)cbuf[i][t] + rg_step_anti(sa, xd, k));
+        if (whole || a + i < len) rg_bst(r_out, voff, s0 + (unsigned)i * stride4, y);
+      }
+    };
+    load(wa, 0);
+    load(wb, S);
+    rg_init_causal(sc, (double)wa[0], k);
+    for (int a = 0; a < len; a += 2 * S) {
+      segment(wa, wb, a);
+      if (a + S >= len) break;
+      load(wa, a + 2 * S);
+      segment(wb, wa, a + S);
+      load(wb, a + 3 * S);
+    }
+  }
+}
+
 // Lines along x: a block owns 256 consecutive rows and walks them in 16-column chunks that are
 // transposed through LDS (pitch 17 keeps the per-row accesses conflict-free).  VEC4: rows are 16-byte aligned
 // (nx % 4 == 0, aligned base), so the chunk is moved with one 16-byte access per lane and 4 columns -- a quarter of the
@@ -289,6 +389,9 @@ __global__ void __launch_bounds__(NT) k_rg_x(const float* __restrict__ in, float
 // consecutive rows; 32-column chunks are transposed through LDS by the 16-byte mover, pitch 33 keeps the per-row walks
 // conflict-free).  Per segment: causal recursion over the main half (results in registers), anti-causal warm-up over the
 // other half, anti-causal over the main half with the sum written back into the tile, tile -> global, next chunk in.
+struct rg_f4u {
+  float x, y, z, w;
+} __attribute__((aligned(4)));   // 16 bytes at 4-byte alignment (global_load / store_dwordx4 take it)
 template <bool VEC4>
 __global__ void __launch_bounds__(NT) k_rg_x_seg(const float* __restrict__ in, float* __restrict__ out, pp_dims d, size_t cstride, rg_coef k) {
   constexpr int S = RG_SEG, P = S + 1;
@@ -297,23 +400,34 @@ __global__ void __launch_bounds__(NT) k_rg_x_seg(const float* __restrict__ in, f
   out += (size_t)blockIdx.y * cstride;
   const size_t nrows = (size_t)d.ny * d.nz;
   const int t = threadIdx.x, len = d.nx;
-  constexpr int LPR = VEC4 ? S / 4 : S;        // lanes per row of the mover
+  constexpr int LPR = S / 4;                   // lanes per row of the mover: a lane moves a quad of columns (VEC4: rows are 16-byte
+                                               // aligned; otherwise 16-byte accesses at 4-byte alignment and element-wise row ends)
   constexpr int RPI = NT / LPR;                // rows per mover round
   const int lc = t % LPR, lr = t / LPR;
+  auto load_quad = [&](size_t row, int cq, float (&q)[4]) {   // columns cq .. cq + 3 of a row (zeros past the row's end)
+    q[0] = q[1] = q[2] = q[3] = 0.0f;
+    if (row < nrows && cq + 3 < len) {
+      if (VEC4) {
+        const float4 v = *reinterpret_cast<const float4*>(in + row * len + cq);
+        q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+      } else {
+        const rg_f4u v = *reinterpret_cast<const rg_f4u*>(in + row * len + cq);
+        q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+      }
+    } else if (row < nrows) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (cq + e < len) q[e] = in[row * len + cq + e];
+    }
+  };
   auto fetch = [&](float* __restrict__ dst, size_t r0, int c0) {
 #pragma unroll
     for (int j = 0; j < NT / RPI; ++j) {
       const int rr = lr + RPI * j;
-      const size_t row = r0 + rr;
-      if (VEC4) {
-        if (row < nrows && c0 + 4 * lc < len) {
-          const float4 v = *reinterpret_cast<const float4*>(in + row * len + c0 + 4 * lc);
-          float* p = dst + rr * P + 4 * lc;
-          p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
-        }
-      } else {
-        if (row < nrows && c0 + lc < len) dst[rr * P + lc] = in[row * len + c0 + lc];
-      }
+      float q[4];
+      load_quad(r0 + rr, c0 + 4 * lc, q);
+      float* p = dst + rr * P + 4 * lc;
+      p[0] = q[0]; p[1] = q[1]; p[2] = q[2]; p[3] = q[3];
     }
   };
   auto put = [&](const float* __restrict__ src, size_t r0, int c0) {
@@ -321,13 +435,20 @@ __global__ void __launch_bounds__(NT) k_rg_x_seg(const float* __restrict__ in, f
     for (int j = 0; j < NT / RPI; ++j) {
       const int rr = lr + RPI * j;
       const size_t row = r0 + rr;
-      if (VEC4) {
-        if (row < nrows && c0 + 4 * lc < len) {
-          const float* p = src + rr * P + 4 * lc;
-          *reinterpret_cast<float4*>(out + row * len + c0 + 4 * lc) = make_float4(p[0], p[1], p[2], p[3]);
+      const int cq = c0 + 4 * lc;
+      const float* p = src + rr * P + 4 * lc;
+      if (row < nrows && cq + 3 < len) {
+        if (VEC4) {
+          *reinterpret_cast<float4*>(out + row * len + cq) = make_float4(p[0], p[1], p[2], p[3]);
+        } else {
+          rg_f4u v;
+          v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];
+          *reinterpret_cast<rg_f4u*>(out + row * len + cq) = v;
         }
-      } else {
-        if (row < nrows && c0 + lc < len) out[row * len + c0 + lc] = src[rr * P + lc];
+      } else if (row < nrows) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cq + e < len) out[row * len + cq + e] = p[e];
       }
     }
   };
@@ -343,25 +464,48 @@ __global__ void __launch_bounds__(NT) k_rg_x_seg(const float* __restrict__ in, f
     for (int a = 0; a < len; a += S, cur ^= 1) {
       float* const m = half[cur] + t * P;
       const float* const la = half[cur ^ 1] + t * P;
+      // Round 5: the chunk after next is REQUESTED here, ahead of this chunk's arithmetic, and lands in registers; it goes into
+      // the tile this chunk frees once that has been written out.  (It used to be fetched behind the write-out, between two
+      // barriers, with nothing to hide its latency.)
+      const bool more = a + 2 * S < len;
+      float pre[NT / RPI][4];
+      if (more) {
+#pragma unroll
+        for (int j = 0; j < NT / RPI; ++j) load_quad(r0 + lr + RPI * j, a + 2 * S + 4 * lc, pre[j]);
+      }
       if (have) {
         const int nm = len - a < S ? len - a : S;
         const int nl = len - (a + S) < 0 ? 0 : (len - (a + S) < S ? len - (a + S) : S);
         float c[S];
 #pragma unroll
         for (int i = 0; i < S; ++i)
-          if (i < nm) c[i] = (float)rg_step_causal(sc, (double)m[i], k);
+          if (i < nm) {
+            double xd = (double)m[i];
+            RG_AFTER(xd, sc.y1);
+            c[i] = (float)rg_step_causal(sc, xd, k);
+          }
         const float edge = nl > 0 ? la[nl - 1] : m[nm - 1];
         rg_state sa;
         rg_init_anti(sa, (double)edge, k);
         for (int i = nl - 1; i >= 0; --i) (void)rg_step_anti(sa, (double)la[i], k);
 #pragma unroll
         for (int i = S - 1; i >= 0; --i)
-          if (i < nm) m[i] = (float)((double)c[i] + rg_step_anti(sa, (double)m[i], k));
+          if (i < nm) {
+            double xd = (double)m[i];
+            RG_AFTER(xd, sa.y1);
+            m[i] = (float)((double)c[i] + rg_step_anti(sa, xd, k));
+          }
       }
       __syncthreads();
       put(half[cur], r0, a);
       __syncthreads();
-      if (a + 2 * S < len) fetch(half[cur], r0, a + 2 * S);
+      if (more) {
+#pragma unroll
+        for (int j = 0; j < NT / RPI; ++j) {
+          float* q = half[cur] + (lr + RPI * j) * P + 4 * lc;
+          q[0] = pre[j][0]; q[1] = pre[j][1]; q[2] = pre[j][2]; q[3] = pre[j][3];
+        }
+      }
       __syncthreads();
     }
   }
@@ -399,11 +543,14 @@ int rg_pass(pp_ctx* ctx, int axis, const float* in, float* out, const pp_dims& d
       hipLaunchKernelGGL(k_rg_x<false>, dim3(grid_for((size_t)d.ny * d.nz), ncomp), dim3(NT), 0, ctx->stream, in, out, d, cstride, k);
   } else {
     const bool seg = sigma / std::fabs(spacing) <= RG_SEG_MAX_SD && in != out && getenv("PP_RG_TWO_SWEEP") == nullptr;
+    const bool small = cstride * sizeof(float) < ((size_t)1 << 32);   // k_rg_strided_seg2 addresses a component with 32-bit byte offsets
     if (axis == 1) {
-      if (seg) hipLaunchKernelGGL((k_rg_strided_seg<1>), dim3(grid_for((size_t)d.nx * d.nz), ncomp), dim3(NT), 0, ctx->stream, in, out, d, cstride, k);
+      if (seg && small && !getenv("PP_RG_SEG_V1")) hipLaunchKernelGGL((k_rg_strided_seg2<1>), dim3((unsigned)(((size_t)d.nx * d.nz + NT - 1) / NT), ncomp), dim3(NT), 0, ctx->stream, in, out, d, cstride, k);
+      else if (seg) hipLaunchKernelGGL((k_rg_strided_seg<1>), dim3(grid_for((size_t)d.nx * d.nz), ncomp), dim3(NT), 0, ctx->stream, in, out, d, cstride, k);
       else hipLaunchKernelGGL((k_rg_strided<1>), dim3(grid_for((size_t)d.nx * d.nz), ncomp), dim3(NT), 0, ctx->stream, in, out, d, cstride, k);
     } else {
-      if (seg) hipLaunchKernelGGL((k_rg_strided_seg<2>), dim3(grid_for((size_t)d.nx * d.ny), ncomp), dim3(NT), 0, ctx->stream, in, out, d, cstride, k);
+      if (seg && small && !getenv("PP_RG_SEG_V1")) hipLaunchKernelGGL((k_rg_strided_seg2<2>), dim3((unsigned)(((size_t)d.nx * d.ny + NT - 1) / NT), ncomp), dim3(NT), 0, ctx->stream, in, out, d, cstride, k);
+      else if (seg) hipLaunchKernelGGL((k_rg_strided_seg<2>), dim3(grid_for((size_t)d.nx * d.ny), ncomp), dim3(NT), 0, ctx->stream, in, out, d, cstride, k);
       else hipLaunchKernelGGL((k_rg_strided<2>), dim3(grid_for((size_t)d.nx * d.ny), ncomp), dim3(NT), 0, ctx->stream, in, out, d, cstride, k);
     }
   }

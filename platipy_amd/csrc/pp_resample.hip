@@ -156,6 +156,7 @@ struct pp_xform {
   double A[9], t[3];
   double p2i_in[9], o_in[3];
   int has_affine;
+  int diag;   // host side: both grids axis-aligned, no linear transform (the marching kernels' case)
 };
 
 // itk::ImageBase::TransformIndexToPhysicalPoint -> MatrixOffsetTransformBase::TransformPoint ->
@@ -375,6 +376,212 @@ __global__ void __launch_bounds__(NT) k_resample_field(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Round 5: the gathers above for the common geometry -- both grids axis-aligned, no linear transform, every volume below
+// 2^32 bytes.  Same values bit for bit (tests/test_kernels.py holds them to the general kernels); what changes is the cost
+// around the arithmetic.  The general kernels spend ~90 fp64 operations on the two 3 x 3 index <-> physical products and
+// ~35 64-bit address operations per voxel, and without a field to read they are bound by instruction issue, not memory (an
+// identity resample moved 8 B / voxel at 1.9 TB/s).  On axis-aligned grids the off-diagonal products are exact zeros
+// (x + (+-0) = x), so one multiply per axis gives the same bits; offsets are 32-bit byte offsets from wave-uniform bases.
+// (Measured and dropped: the same kernels marching z in 64 x 4 tiles handed out XCD by XCD, so that the upper plane of
+// corners of a step is the next step's lower plane in cache -- the warp through a field went 408 -> 478 us and the
+// composition 863 -> 1134 us inside config 2's registration; plane-by-plane launch order keeps every block of the chip
+// on two planes of DRAM pages.  Only the field up-sampling marches: its source is small and it keeps its corners in
+// registers, below.)
+bool rs_small(const pp_dims& d, size_t bytes_per_voxel) {
+  return (size_t)d.nx * d.ny * d.nz * bytes_per_voxel < ((size_t)1 << 32);
+}
+
+template <typename T>
+__device__ __forceinline__ T rs_ld(const T* base, unsigned byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ void rs_st(T* base, unsigned byte_off, T v) {
+  *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+// The address half of pp_trilinear_pairs / pp_trilinear once for every volume sampled at the same point.
+struct rs_corner {
+  unsigned o00, o10, o01, o11;   // element offsets of the four x pairs (or, nx == 1, of the four single corners)
+  float wx, wy, wz;
+  bool xlast;
+};
+__device__ __forceinline__ void rs_corners(const pp_dims& n, int bx, float fx, int by, float fy, int bz, float fz, rs_corner& a) {
+  int x0, x1, y0, y1, z0, z1;
+  pp_axis_setup(bx, fx, n.nx, x0, x1, a.wx);
+  pp_axis_setup(by, fy, n.ny, y0, y1, a.wy);
+  pp_axis_setup(bz, fz, n.nz, z0, z1, a.wz);
+  a.xlast = x0 > n.nx - 2;
+  const unsigned xs = n.nx >= 2 ? (unsigned)(a.xlast ? n.nx - 2 : x0) : 0u;
+  const unsigned r0 = (unsigned)z0 * (unsigned)n.ny, r1 = (unsigned)z1 * (unsigned)n.ny;
+  a.o00 = (r0 + (unsigned)y0) * (unsigned)n.nx + xs;
+  a.o10 = (r0 + (unsigned)y1) * (unsigned)n.nx + xs;
+  a.o01 = (r1 + (unsigned)y0) * (unsigned)n.nx + xs;
+  a.o11 = (r1 + (unsigned)y1) * (unsigned)n.nx + xs;
+}
+// the two x corners of a row: one access of 2 sizeof(T) bytes from an element-aligned position (pp_trilinear_pairs), or
+// the single column's voxel twice
+template <bool WIDE, typename T>
+__device__ __forceinline__ void rs_row(const T* __restrict__ im, bool xlast, unsigned off, float& lo, float& hi) {
+  if (WIDE) {
+    const pp_pair<T> p = rs_ld(reinterpret_cast<const pp_pair<T>*>(im), off * (unsigned)sizeof(T));
+    lo = (float)(xlast ? p.y : p.x);
+    hi = (float)p.y;
+  } else {
+    lo = hi = (float)rs_ld(im, off * (unsigned)sizeof(T));
+  }
+}
+__device__ __forceinline__ float rs_lerp(float a000, float a100, float a010, float a110, float a001, float a101, float a011, float a111,
+                                         float wx, float wy, float wz) {
+  const float v00 = a000 + (a100 - a000) * wx;
+  const float v10 = a010 + (a110 - a010) * wx;
+  const float v01 = a001 + (a101 - a001) * wx;
+  const float v11 = a011 + (a111 - a011) * wx;
+  const float v0 = v00 + (v10 - v00) * wy;
+  const float v1 = v01 + (v11 - v01) * wy;
+  return v0 + (v1 - v0) * wz;
+}
+template <bool WIDE, typename T>
+__device__ __forceinline__ float rs_sample(const T* __restrict__ im, const rs_corner& a) {
+  float a000, a100, a010, a110, a001, a101, a011, a111;
+  rs_row<WIDE>(im, a.xlast, a.o00, a000, a100);   // (four loads in flight together: no branch between them)
+  rs_row<WIDE>(im, a.xlast, a.o10, a010, a110);
+  rs_row<WIDE>(im, a.xlast, a.o01, a001, a101);
+  rs_row<WIDE>(im, a.xlast, a.o11, a011, a111);
+  return rs_lerp(a000, a100, a010, a110, a001, a101, a011, a111, a.wx, a.wy, a.wz);
+}
+
+// pp_map_point on axis-aligned grids without a linear transform: per axis ((spacing_out * idx + origin_out) [+ d]) -
+// origin_in, times 1 / spacing_in -- the terms pp_map_point adds besides these are products with exact zeros.
+struct rs_axes {
+  double s_out[3], o_out[3], o_in[3], p_in[3];
+};
+template <bool HASFIELD>
+__device__ __forceinline__ double rs_axis(const rs_axes& X, int r, int idx, double dd) {
+#pragma clang fp contract(off)
+  double p = X.s_out[r] * (double)idx;
+  p = p + X.o_out[r];
+  if (HASFIELD) p = p + dd;
+  const double v = p - X.o_in[r];
+  return X.p_in[r] * v;
+}
+
+// pp_inside_d without short-circuit evaluation: with it the compiler sinks each component's field load behind the test of
+// the component before -- three dependent round trips to memory.
+__device__ __forceinline__ bool rs_inside(const double c[3], const pp_dims& n) {
+  const int ok = (int)(c[0] >= -0.5) & (int)(c[0] < (double)n.nx - 0.5) & (int)(c[1] >= -0.5) & (int)(c[1] < (double)n.ny - 0.5) &
+                 (int)(c[2] >= -0.5) & (int)(c[2] < (double)n.nz - 0.5);
+  return ok != 0;
+}
+
+// k_resample on axis-aligned grids (same launch geometry: grid3_for)
+template <typename T, int INTERP, bool HASFIELD, bool WIDE>
+__global__ void __launch_bounds__(NT) k_resample_axis(const T* __restrict__ in, pp_dims din, const float* __restrict__ field,
+                                                      T* __restrict__ out, pp_dims dout, rs_axes X, T default_value) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z;
+  if (x >= dout.nx || y >= dout.ny) return;
+  const unsigned N4 = (unsigned)dout.nx * (unsigned)dout.ny * (unsigned)dout.nz * 4u;
+  const unsigned i = ((unsigned)z * (unsigned)dout.ny + (unsigned)y) * (unsigned)dout.nx + (unsigned)x;
+  double ddx = 0.0, ddy = 0.0, ddz = 0.0;
+  if (HASFIELD) {
+    ddx = (double)rs_ld(field, i * 4u);
+    ddy = (double)rs_ld(field, N4 + i * 4u);
+    ddz = (double)rs_ld(field, 2u * N4 + i * 4u);
+  }
+  double c[3];
+  c[0] = rs_axis<HASFIELD>(X, 0, x, ddx);
+  c[1] = rs_axis<HASFIELD>(X, 1, y, ddy);
+  c[2] = rs_axis<HASFIELD>(X, 2, z, ddz);
+  T res = default_value;
+  if (rs_inside(c, din)) {
+    if (INTERP == PP_INTERP_NEAREST) {
+      const int qx = (int)floor(c[0] + 0.5), qy = (int)floor(c[1] + 0.5), qz = (int)floor(c[2] + 0.5);
+      res = rs_ld(in, (((unsigned)qz * (unsigned)din.ny + (unsigned)qy) * (unsigned)din.nx + (unsigned)qx) * (unsigned)sizeof(T));
+    } else {
+      const double flx = floor(c[0]), fly = floor(c[1]), flz = floor(c[2]);
+      rs_corner a;
+      rs_corners(din, (int)flx, (float)(c[0] - flx), (int)fly, (float)(c[1] - fly), (int)flz, (float)(c[2] - flz), a);
+      res = pp_cast_out<T>(rs_sample<WIDE>(in, a));
+    }
+  }
+  rs_st(out, i * (unsigned)sizeof(T), res);
+}
+
+// k_resample_field on axis-aligned grids, marching z.  A thread's x and y corners do not change along its column, and its
+// z corners change once per (output planes per input plane) steps -- the pyramid's up-sampling is x2 to x4 -- for the whole
+// block at once (the z coordinate depends on z alone): the twelve corner pairs of the three components stay in registers,
+// a step onto the next input plane moves the upper six down and loads six, and most steps load nothing.
+struct rs_grid {
+  unsigned gx, gy, gz, zc;
+};
+constexpr int RS_TX = 64, RS_TY = NT / RS_TX;
+rs_grid rs_grid_for(const pp_dims& d) {
+  rs_grid g;
+  g.gx = (unsigned)((d.nx + RS_TX - 1) / RS_TX);
+  g.gy = (unsigned)((d.ny + RS_TY - 1) / RS_TY);
+  g.zc = 32;
+  static const char* e = getenv("PP_RS_ZCHUNK");
+  if (e && atoi(e) > 0) g.zc = (unsigned)atoi(e);
+  while (g.zc > 1 && (size_t)g.gx * g.gy * ((d.nz + g.zc - 1) / g.zc) < 4096) g.zc >>= 1;
+  g.gz = (unsigned)((d.nz + g.zc - 1) / g.zc);
+  return g;
+}
+template <bool WIDE>
+__global__ void __launch_bounds__(NT) k_resample_field_march(const float* __restrict__ in, pp_dims din, float* __restrict__ out,
+                                                             pp_dims dout, rs_axes X, rs_grid G) {
+  const int x = (int)(blockIdx.x * RS_TX + threadIdx.x), y = (int)(blockIdx.y * RS_TY + threadIdx.y);
+  const int zb = (int)(blockIdx.z * G.zc), ze = zb + (int)G.zc < dout.nz ? zb + (int)G.zc : dout.nz;
+  if (x >= dout.nx || y >= dout.ny) return;
+  const unsigned plane = (unsigned)dout.nx * (unsigned)dout.ny, N4 = plane * (unsigned)dout.nz * 4u;
+  const unsigned Ni = (unsigned)din.nx * (unsigned)din.ny * (unsigned)din.nz;
+  unsigned i = ((unsigned)zb * (unsigned)dout.ny + (unsigned)y) * (unsigned)dout.nx + (unsigned)x;
+  double c[3];
+  c[0] = rs_axis<false>(X, 0, x, 0.0);
+  c[1] = rs_axis<false>(X, 1, y, 0.0);
+  int cz0 = -1, cz1 = -1;               // the input planes held in lo / hi
+  float lo[3][4], hi[3][4];             // per component: row y0 (x0, x1), row y1 (x0, x1)
+  for (int z = zb; z < ze; ++z, i += plane) {
+    c[2] = rs_axis<false>(X, 2, z, 0.0);
+    float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+    if (rs_inside(c, din)) {
+      const double flx = floor(c[0]), fly = floor(c[1]), flz = floor(c[2]);
+      const int bx = (int)flx, by = (int)fly, bz = (int)flz;
+      int x0, x1, y0, y1, z0, z1;
+      float wx, wy, wz;
+      pp_axis_setup(bx, (float)(c[0] - flx), din.nx, x0, x1, wx);
+      pp_axis_setup(by, (float)(c[1] - fly), din.ny, y0, y1, wy);
+      pp_axis_setup(bz, (float)(c[2] - flz), din.nz, z0, z1, wz);
+      if (z0 != cz0 || z1 != cz1) {
+        const bool xlast = x0 > din.nx - 2;
+        const unsigned xs = WIDE ? (unsigned)(xlast ? din.nx - 2 : x0) : 0u;
+        const bool shift = z0 == cz1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float* comp = in + (size_t)k * Ni;
+          if (shift) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lo[k][e] = hi[k][e];
+          } else {
+            rs_row<WIDE>(comp, xlast, ((unsigned)z0 * (unsigned)din.ny + (unsigned)y0) * (unsigned)din.nx + xs, lo[k][0], lo[k][1]);
+            rs_row<WIDE>(comp, xlast, ((unsigned)z0 * (unsigned)din.ny + (unsigned)y1) * (unsigned)din.nx + xs, lo[k][2], lo[k][3]);
+          }
+          rs_row<WIDE>(comp, xlast, ((unsigned)z1 * (unsigned)din.ny + (unsigned)y0) * (unsigned)din.nx + xs, hi[k][0], hi[k][1]);
+          rs_row<WIDE>(comp, xlast, ((unsigned)z1 * (unsigned)din.ny + (unsigned)y1) * (unsigned)din.nx + xs, hi[k][2], hi[k][3]);
+        }
+        cz0 = z0;
+        cz1 = z1;
+      }
+      r0 = rs_lerp(lo[0][0], lo[0][1], lo[0][2], lo[0][3], hi[0][0], hi[0][1], hi[0][2], hi[0][3], wx, wy, wz);
+      r1 = rs_lerp(lo[1][0], lo[1][1], lo[1][2], lo[1][3], hi[1][0], hi[1][1], hi[1][2], hi[1][3], wx, wy, wz);
+      r2 = rs_lerp(lo[2][0], lo[2][1], lo[2][2], lo[2][3], hi[2][0], hi[2][1], hi[2][2], hi[2][3], wx, wy, wz);
+    }
+    rs_st(out, i * 4u, r0);
+    rs_st(out, N4 + i * 4u, r1);
+    rs_st(out, 2u * N4 + i * 4u, r2);
+  }
+}
+
 unsigned grid_for(size_t work) {
   size_t blocks = (work + NT - 1) / NT;
   if (blocks > 65535u * 8u) blocks = 65535u * 8u;
@@ -393,9 +600,22 @@ void fill_xform(const pp_geom* gin, const pp_geom* gout, const double* A, const 
     X->o_in[k] = gin->origin[k];
   }
   X->has_affine = (A != nullptr);
+  X->diag = !A && pp_geom_identity_dir(gin) && pp_geom_identity_dir(gout);
   static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   memcpy(X->A, A ? A : I3, sizeof(X->A));
   for (int k = 0; k < 3; ++k) X->t[k] = (A && t) ? t[k] : 0.0;
+}
+
+bool rs_generic_forced() { return getenv("PP_RESAMPLE_GENERIC") != nullptr; }
+rs_axes rs_axes_of(const pp_xform& X) {
+  rs_axes a;
+  for (int k = 0; k < 3; ++k) {
+    a.s_out[k] = X.i2p_out[k * 3 + k];
+    a.o_out[k] = X.o_out[k];
+    a.o_in[k] = X.o_in[k];
+    a.p_in[k] = X.p2i_in[k * 3 + k];
+  }
+  return a;
 }
 
 template <typename T>
@@ -423,6 +643,20 @@ int resample_any(pp_ctx* ctx, const T* in, const pp_geom* gin, const pp_geom* go
     dv = (T)c;
   } else {
     dv = (T)default_value;
+  }
+  if (X.diag && interp != PP_INTERP_BSPLINE && rs_small(din, sizeof(T)) && rs_small(dout, field ? 12 : sizeof(T)) && !rs_generic_forced()) {
+    const rs_axes XA = rs_axes_of(X);
+#define PP_RSA(I, F, W) hipLaunchKernelGGL((k_resample_axis<T, I, F, W>), grid, block, 0, ctx->stream, in, din, field, out, dout, XA, dv)
+    if (interp == PP_INTERP_NEAREST) {
+      if (field) PP_RSA(PP_INTERP_NEAREST, true, true); else PP_RSA(PP_INTERP_NEAREST, false, true);
+    } else if (din.nx >= 2) {
+      if (field) PP_RSA(PP_INTERP_LINEAR, true, true); else PP_RSA(PP_INTERP_LINEAR, false, true);
+    } else {
+      if (field) PP_RSA(PP_INTERP_LINEAR, true, false); else PP_RSA(PP_INTERP_LINEAR, false, false);
+    }
+#undef PP_RSA
+    PP_LAUNCH_CHECK(ctx, name);
+    return PP_OK;
   }
 #define PP_RS(I, F) hipLaunchKernelGGL((k_resample<T, I, F>), grid, block, 0, ctx->stream, in, din, field, out, dout, X, dv)
   if (interp == PP_INTERP_NEAREST) {
@@ -538,6 +772,17 @@ int pp_resample_field_f32(pp_ctx* ctx, const float* in, const pp_geom* gin, cons
   fill_xform(gin, gout, nullptr, nullptr, &X);
   const pp_dims din{gin->size[0], gin->size[1], gin->size[2]};
   const pp_dims dout{gout->size[0], gout->size[1], gout->size[2]};
+  if (X.diag && rs_small(din, 4) && rs_small(dout, 12) && !rs_generic_forced()) {
+    const rs_grid G = rs_grid_for(dout);
+    if (din.nx >= 2)
+      hipLaunchKernelGGL(k_resample_field_march<true>, dim3(G.gx, G.gy, G.gz), dim3(RS_TX, RS_TY), 0, ctx->stream, in, din, out, dout,
+                         rs_axes_of(X), G);
+    else
+      hipLaunchKernelGGL(k_resample_field_march<false>, dim3(G.gx, G.gy, G.gz), dim3(RS_TX, RS_TY), 0, ctx->stream, in, din, out, dout,
+                         rs_axes_of(X), G);
+    PP_LAUNCH_CHECK(ctx, "k_resample_field_march");
+    return PP_OK;
+  }
   const pp_grid3 g3 = grid3_for(dout.nx, dout.ny, dout.nz);
   hipLaunchKernelGGL(k_resample_field, g3.grid, g3.block, 0, ctx->stream, in, din, out, dout, X);
   PP_LAUNCH_CHECK(ctx, "k_resample_field");

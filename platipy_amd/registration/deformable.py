@@ -193,6 +193,9 @@ class HipDemonsFilter:
 _IDENTITY = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
 
 
+_CT_PROBE_VOXELS = 1 << 20
+
+
 def _rotate_field(field, direction, transpose=False):
     """R (or R^T) applied to the three components of a planar field tensor [3, Z, Y, X]."""
     R = torch.tensor(direction, dtype=field.dtype, device=field.device).reshape(3, 3)
@@ -338,7 +341,13 @@ def fast_symmetric_forces_demons_registration(
         # behind the whole registration it would idle the GPU until the host has come back and launched the final resample.
         mt = moving_image.tensor
         if mt.dtype == torch.float32 and mt.is_contiguous():
-            lowest = runtime.context(mt.device).minmax(mt, mt.numel())[0]
+            # only "is any voxel <= -1000" matters: a CT's first planes are air, so the first 2^20 voxels usually answer it
+            # (a 4 MB read); the whole volume is read only when they do not
+            c = runtime.context(mt.device)
+            head = min(mt.numel(), _CT_PROBE_VOXELS)
+            lowest = c.minmax(mt, head)[0]
+            if lowest > -1000 and head < mt.numel():
+                lowest = c.minmax(mt, mt.numel())[0]
         else:
             lowest = float(mt.min())
         default_value = -1000 if lowest <= -1000 else 0

@@ -259,6 +259,59 @@ def test_resample_field_and_compose(backend):
     np.testing.assert_allclose(backend.host(d_tot), want2, rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("shape", [(23, 30, 70), (37, 9, 129), (6, 5, 1), (40, 21, 2)])
+def test_marching_gathers_equal_the_general_kernels(backend, shape, monkeypatch):
+    """Round 5: on axis-aligned grids below 2^32 bytes, resample (linear / nearest, fp32 / u8, with and without a field) runs
+    with one fp64 multiply per axis and 32-bit offsets, and the field up-sampling marches z with its corner pairs kept in
+    registers from plane to plane.  The terms they drop are products with exact zeros, so every result is bit-identical to
+    the general kernels (PP_RESAMPLE_GENERIC=1) -- inside, on the buffer border, outside, single-column and two-column
+    volumes, tiles and z chunks that overhang the volume, up- and down-sampling along z."""
+    spacing, origin = (0.9, 1.3, 2.1), (-11.5, 4.25, 100.0)
+    rng = np.random.default_rng(77)
+    img = (phantom(shape, seed=3) + 50.0 * rng.standard_normal(shape)).astype(np.float32)
+    lab = (rng.integers(0, 5, shape)).astype(np.uint8)
+    f = (random_dvf(shape, spacing, seed=5, max_mm=9.0) + rng.normal(size=(3,) + shape)).astype(np.float32)
+    it = random_dvf(shape, spacing, seed=6, max_mm=4.0)
+    g = geom_of(shape, spacing, origin)
+    other_shape = (max(1, shape[0] * 2 - 1), max(1, shape[1] + 3), max(1, shape[2] // 2 + 1))
+    other = geom_of(other_shape, (0.47, 1.21, 4.0), (-12.0, 3.0, 99.0))
+    res = {}
+    for mode in ("", "1"):
+        if mode:
+            monkeypatch.setenv("PP_RESAMPLE_GENERIC", mode)
+        else:
+            monkeypatch.delenv("PP_RESAMPLE_GENERIC", raising=False)
+        ctx, r = backend.ctx, []
+        for interp in (_lib.INTERP_LINEAR, _lib.INTERP_NEAREST):
+            out = backend.empty(shape)
+            ctx.resample(backend.dev(img), g, g, out, field=backend.dev(f), interp=interp, default_value=-1000.0)
+            r.append(backend.host(out).copy())
+            out = backend.empty(other_shape)
+            ctx.resample(backend.dev(img), g, other, out, interp=interp, default_value=-3.0)
+            r.append(backend.host(out).copy())
+            out = backend.empty(shape, np.uint8)
+            ctx.resample(backend.dev(lab), g, g, out, field=backend.dev(f), interp=interp, default_value=7, u8=True)
+            r.append(backend.host(out).copy())
+            out = backend.empty(other_shape, np.uint8)
+            ctx.resample(backend.dev(lab), g, other, out, interp=interp, default_value=0, u8=True)
+            r.append(backend.host(out).copy())
+        out = backend.empty((3,) + other_shape)
+        ctx.resample_field(backend.dev(f), g, other, out)
+        r.append(backend.host(out).copy())
+        fine_shape = (shape[0] * 3 + 2, shape[1] * 2, shape[2] + 1)       # x3 along z: most steps reuse both planes
+        fine = geom_of(fine_shape, (0.9 * shape[2] / (shape[2] + 1), 0.66, 0.7), (-11.9, 4.0, 99.0))
+        out = backend.empty((3,) + fine_shape)
+        ctx.resample_field(backend.dev(f), g, fine, out)
+        r.append(backend.host(out).copy())
+        tot = backend.dev(f)
+        ctx.compose_field(tot, backend.dev(it), g)
+        r.append(backend.host(tot).copy())
+        res[mode] = r
+    for a, b in zip(res[""], res["1"]):
+        np.testing.assert_array_equal(a, b)
+    assert any((a != a.flat[0]).any() for a in res[""])
+
+
 def _demons_params(ctx, iterations, spacing, variant, max_rms=0.02):
     p = ctx.default_demons_params()
     p.iterations = iterations
@@ -797,12 +850,15 @@ def test_demons_history_is_what_an_iteration_observer_reads(backend, variant):
     assert sh.halted and len(hh) == sh.elapsed_iterations == 3 and hh == hist[:3]
 
 
-def test_recursive_gaussian_single_sweep_equals_two_sweeps(backend, monkeypatch):
+@pytest.mark.parametrize("shape", [(150, 71, 24), (12, 40, 150), (9, 33, 77)])
+def test_recursive_gaussian_single_sweep_equals_two_sweeps(backend, monkeypatch, shape):
     """The single-sweep recursive Gaussian (segments of 32 voxels in registers, the anti-causal recursion warmed up over the
     following segment) against the exact two-sweep walk on lines longer than several segments, ragged in length: the
     warm-up error is < 1e-12 of the signal, so the fp32 results are equal except where a value sits within that distance
-    of a rounding boundary (<= 1 ulp, a vanishing fraction); and both equal the oracle."""
-    shape, spacing, origin = (150, 71, 24), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)     # z lines of 150, y lines of 71
+    of a rounding boundary (<= 1 ulp, a vanishing fraction); and both equal the oracle.  The second and third shapes have x
+    rows of 150 and 77 voxels: rows that are not whole 16-byte quads (the x kernel's 4-byte-aligned quad mover with
+    element-wise row ends), several segments long."""
+    spacing, origin = (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)     # first shape: z lines of 150, y lines of 71
     f = (random_dvf(shape, spacing, seed=61, max_mm=5.0) + 0.5 * np.random.default_rng(62).normal(size=(3,) + shape)).astype(np.float32)
     sigma = [1.5, 1.5, 1.5]
     out = {}

@@ -101,6 +101,15 @@ int main(int argc, char** argv) {
   run("resample f32 linear through field", 20, [&] { return resample(ctx, A, &g, &g, nullptr, nullptr, D, 2, -1000.0, B); });
   run("resample u8 nearest through field", 14, [&] { return resample_u8(ctx, L, &g, &g, nullptr, nullptr, D, 1, 0.0, L2); });
   run("resample f32 linear identity", 8, [&] { return resample(ctx, A, &g, &g, nullptr, nullptr, nullptr, 2, 0.0, B); });
+  {
+    auto resample_field = sym<int (*)(pp_ctx*, const float*, const pp_geom*, const pp_geom*, float*)>(h, "pp_resample_field_f32");
+    pp_geom gc = g;
+    gc.size[0] = nx / 4; gc.size[1] = ny / 4; gc.size[2] = nz / 4;
+    for (int i = 0; i < 3; ++i) { gc.spacing[i] = 4.0; gc.origin[i] = 1.5; }
+    // (the coarse field: the first nx/4 * ny/4 * nz/4 * 3 floats of D2, any values)
+    run("resample_field x4 up-sampling (12 B written)", 12, [&] { return resample_field(ctx, D2, &gc, &g, D); });
+    hipLaunchKernelGGL(k_fill_smooth, dim3(4096), dim3(256), 0, st, D, nx, ny, nz, 4.0f);
+  }
   run("compose_field", 36, [&] { return compose(ctx, D, D2, &g); });
   run("recursive_gaussian_field sigma 1.5", 72, [&] { return rgauss(ctx, D, &g, s15); });
   run("weight_map_local sigma 2", 40, [&] { return wlocal(ctx, A, B, size, sp, 2.0, 1e-5, D); });
