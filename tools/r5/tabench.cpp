@@ -7,6 +7,8 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
 struct f2u { float x, y; } __attribute__((packed, aligned(4)));
+struct f3u { float x, y, z; } __attribute__((packed, aligned(4)));
+struct f4u { float x, y, z, w; } __attribute__((packed, aligned(4)));
 
 // MODE 0: 8-byte pair at 4-byte alignment, consecutive lanes one element apart (the warp's gather on a coherent field)
 // MODE 1: 4-byte element, consecutive lanes (coalesced)
@@ -39,9 +41,31 @@ __global__ void __launch_bounds__(256) k(const float* __restrict__ a, float* __r
       } else if (MODE == 5) {
         const f2u v = *reinterpret_cast<const f2u*>(a + ((row + lane * 521u + 1u) & mask));
         acc += v.x + v.y;
-      } else {
+      } else if (MODE == 6) {
         const float4 v = *reinterpret_cast<const float4*>(a + ((row + 4u * lane) & ~3u));
         acc += v.x + v.y + v.z + v.w;
+      } else {
+        // kernel B's shape: lane l samples x = 2 l and 2 l + 1; `jog` = the displacement's integer part changes once in the wave
+        const unsigned jog = (MODE >= 10 && MODE != 13) ? (lane >= 37u ? 1u : 0u) : 0u;
+        const unsigned e = row + 2u * lane + 1u + jog;
+        if (MODE == 7 || MODE == 10) {          // two pairs per lane (A's and B's corners): today's form
+          const f2u v = *reinterpret_cast<const f2u*>(a + e);
+          const f2u w = *reinterpret_cast<const f2u*>(a + e + 1u);
+          acc += v.x + v.y + w.x + w.y;
+        } else if (MODE == 8 || MODE == 11) {   // one 16-byte load at 4-byte alignment covers both
+          const f4u v = *reinterpret_cast<const f4u*>(a + e);
+          acc += v.x + v.y + v.z + v.w;
+        } else if (MODE == 9 || MODE == 12) {   // the quad, plus a pair for one lane in 8 (row-incoherent lanes)
+          const f4u v = *reinterpret_cast<const f4u*>(a + e);
+          acc += v.x + v.y + v.z + v.w;
+          if ((lane & 7u) == 3u) {
+            const f2u w = *reinterpret_cast<const f2u*>(a + ((e + 4099u) & mask));
+            acc += w.x + w.y;
+          }
+        } else {                                // 13: 12 bytes
+          const f3u v = *reinterpret_cast<const f3u*>(a + e);
+          acc += v.x + v.y + v.z;
+        }
       }
     }
     base = (base + 64u * 131u) & mask;
@@ -80,5 +104,13 @@ int main(int argc, char** argv) {
   run<4>("element, lanes scattered", a, out, mask);
   run<5>("pair, 4-byte aligned, lanes scattered", a, out, mask);
   run<6>("quad, 16-byte aligned, consecutive lanes", a, out, mask);
+  printf("kernel B's shape (lane l: x = 2 l, 2 l + 1); per lane-iteration, i.e. per 1 or 2 instructions:\n");
+  run<7>("B: two pairs (today)", a, out, mask);
+  run<8>("B: one 16-byte load, 4-byte aligned", a, out, mask);
+  run<9>("B: 16-byte load + a pair for one lane in 8", a, out, mask);
+  run<13>("B: one 12-byte load", a, out, mask);
+  run<10>("B, one jog in the wave: two pairs (today)", a, out, mask);
+  run<11>("B, one jog: one 16-byte load", a, out, mask);
+  run<12>("B, one jog: 16-byte load + a pair for one lane in 8", a, out, mask);
   return 0;
 }
