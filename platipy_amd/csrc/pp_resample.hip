@@ -34,6 +34,42 @@ pp_grid3 grid3_for(int nxv, int ny, int nz) {
   return g;
 }
 
+// The same blocks handed out XCD-aware.  Hardware sends block b of a launch to XCD b % 8, so with the plain (x, y, z) grid
+// the rows y and y + 1 of a plane -- whose gathers read the same rows of the source -- run on different XCDs, every XCD
+// walks every plane, and each L2 fetches what its neighbours also fetch (measured: the composition fetched 84 B / voxel
+// from HBM / MALL for 24 compulsory, the warp through a field 25 for 16; banded 27.6 and 16.1 -- tools/r5/reg_pmc.sh).  The
+// time follows only where the field is rough enough for the fetch to matter (sbench's composition 1.40 -> 1.01 ms; inside
+// config 2's registration, whose finest-level field is smooth, the composition stays at 0.89 ms: it is bound by its
+// twelve gather instructions per voxel, ~30 clocks each once lanes are not exactly consecutive).  Banded: a 1-D launch of 8 x per x nz blocks;
+// block b works on plane (b / 8) / per and, within it, on tile (b % 8) x per + (b / 8) % per of the plane's gx x gy tiles --
+// each XCD owns a band of rows of every plane, planes still go by in order (two planes of DRAM pages at a time).
+struct pp_band {
+  unsigned gx, gy, per, tiles;   // per == 0: plain 3-D grid
+};
+pp_band band_for(const pp_grid3& g, dim3* launch, bool wanted = true) {
+  pp_band b{g.grid.x, g.grid.y, 0u, g.grid.x * g.grid.y};
+  const char* e = getenv("PP_RS_BAND");
+  const bool on = wanted && !(e && atoi(e) == 0);
+  if (on && b.tiles >= 64u && (size_t)((b.tiles + 7u) / 8u) * 8u * g.grid.z < ((size_t)1 << 31)) {
+    b.per = (b.tiles + 7u) / 8u;
+    *launch = dim3(8u * b.per * g.grid.z, 1, 1);
+  } else {
+    *launch = g.grid;
+  }
+  return b;
+}
+__device__ __forceinline__ bool pp_band_block(const pp_band& B, unsigned& bx, unsigned& by, unsigned& bz) {
+  if (B.per == 0u) {
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+    return true;
+  }
+  const unsigned b = blockIdx.x, q = b >> 3, t = (b & 7u) * B.per + q % B.per;
+  bz = q / B.per;
+  bx = t % B.gx;
+  by = t / B.gx;
+  return t < B.tiles;
+}
+
 // ---------------------------------------------------------------------------------------
 // same-grid warp
 
@@ -43,11 +79,13 @@ pp_grid3 grid3_for(int nxv, int ny, int nz) {
 template <int VEC>
 __global__ void __launch_bounds__(NT) k_warp_same_grid_sl(const float* __restrict__ moving, const float* __restrict__ field,
                                                           float* __restrict__ out, pp_dims d, pp_warp_scale sc, float edge,
-                                                          const int* __restrict__ halt) {
+                                                          const int* __restrict__ halt, pp_band B) {
   if (halt && *halt) return;
   const int nxv = d.nx / VEC;
   const size_t N = (size_t)d.nx * d.ny * d.nz;
-  const int xv = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z;
+  unsigned bx_, by_, bz_;
+  if (!pp_band_block(B, bx_, by_, bz_)) return;
+  const int xv = bx_ * blockDim.x + threadIdx.x, y = by_ * blockDim.y + threadIdx.y, z = bz_;
   if (xv < nxv && y < d.ny) {
     const int x0 = xv * VEC;
     const size_t i = ((size_t)z * d.ny + y) * d.nx + x0;
@@ -123,9 +161,11 @@ __global__ void __launch_bounds__(NT) k_warp_same_grid(const float* __restrict__
 // total(x) += iter(x + total(x)), zero outside (deformable.py:154).  In place on `total`:
 // every thread reads only its own voxel of `total`.
 __global__ void __launch_bounds__(NT) k_compose_same_grid(float* __restrict__ total, const float* __restrict__ iter,
-                                                          pp_dims d, pp_warp_scale sc) {
+                                                          pp_dims d, pp_warp_scale sc, pp_band B) {
   const size_t N = (size_t)d.nx * d.ny * d.nz;
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z;
+  unsigned bx_, by_, bz_;
+  if (!pp_band_block(B, bx_, by_, bz_)) return;
+  const int x = bx_ * blockDim.x + threadIdx.x, y = by_ * blockDim.y + threadIdx.y, z = bz_;
   if (x < d.nx && y < d.ny) {
     const size_t i = ((size_t)z * d.ny + y) * d.nx + x;
     const float tx = total[i], ty = total[N + i], tz = total[2 * N + i];
@@ -478,8 +518,10 @@ __device__ __forceinline__ bool rs_inside(const double c[3], const pp_dims& n) {
 // k_resample on axis-aligned grids (same launch geometry: grid3_for)
 template <typename T, int INTERP, bool HASFIELD, bool WIDE>
 __global__ void __launch_bounds__(NT) k_resample_axis(const T* __restrict__ in, pp_dims din, const float* __restrict__ field,
-                                                      T* __restrict__ out, pp_dims dout, rs_axes X, T default_value) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z;
+                                                      T* __restrict__ out, pp_dims dout, rs_axes X, T default_value, pp_band B) {
+  unsigned bx_, by_, bz_;
+  if (!pp_band_block(B, bx_, by_, bz_)) return;
+  const int x = bx_ * blockDim.x + threadIdx.x, y = by_ * blockDim.y + threadIdx.y, z = bz_;
   if (x >= dout.nx || y >= dout.ny) return;
   const unsigned N4 = (unsigned)dout.nx * (unsigned)dout.ny * (unsigned)dout.nz * 4u;
   const unsigned i = ((unsigned)z * (unsigned)dout.ny + (unsigned)y) * (unsigned)dout.nx + (unsigned)x;
@@ -646,7 +688,11 @@ int resample_any(pp_ctx* ctx, const T* in, const pp_geom* gin, const pp_geom* go
   }
   if (X.diag && interp != PP_INTERP_BSPLINE && rs_small(din, sizeof(T)) && rs_small(dout, field ? 12 : sizeof(T)) && !rs_generic_forced()) {
     const rs_axes XA = rs_axes_of(X);
-#define PP_RSA(I, F, W) hipLaunchKernelGGL((k_resample_axis<T, I, F, W>), grid, block, 0, ctx->stream, in, din, field, out, dout, XA, dv)
+    dim3 launch;
+    // (banded only where it measured faster or equal: linear through a field.  Labels through a field and resamples without
+    // a field fetch nothing twice to begin with and ran 8 - 17 % slower banded.)
+    const pp_band B = band_for(g3, &launch, field != nullptr && interp == PP_INTERP_LINEAR && sizeof(T) == 4);
+#define PP_RSA(I, F, W) hipLaunchKernelGGL((k_resample_axis<T, I, F, W>), launch, block, 0, ctx->stream, in, din, field, out, dout, XA, dv, B)
     if (interp == PP_INTERP_NEAREST) {
       if (field) PP_RSA(PP_INTERP_NEAREST, true, true); else PP_RSA(PP_INTERP_NEAREST, false, true);
     } else if (din.nx >= 2) {
@@ -701,14 +747,18 @@ int pp_warp_same_grid(pp_ctx* ctx, const float* moving, const float* field, cons
                   d.ny < (1 << 22) && d.nz < (1 << 22) && getenv("PP_WARP_LEGACY") == nullptr;
   if (vec4) {
     const pp_grid3 g3 = grid3_for(d.nx / 4, d.ny, d.nz);
+    dim3 launch;
+    const pp_band B = band_for(g3, &launch);
     if (sl)
-      hipLaunchKernelGGL((k_warp_same_grid_sl<4>), g3.grid, g3.block, 0, ctx->stream, moving, field, out, d, sc, edge_value, halt_flag);
+      hipLaunchKernelGGL((k_warp_same_grid_sl<4>), launch, g3.block, 0, ctx->stream, moving, field, out, d, sc, edge_value, halt_flag, B);
     else
       hipLaunchKernelGGL((k_warp_same_grid<4>), g3.grid, g3.block, 0, ctx->stream, moving, field, out, d, sc, edge_value, halt_flag);
   } else {
     const pp_grid3 g3 = grid3_for(d.nx, d.ny, d.nz);
+    dim3 launch;
+    const pp_band B = band_for(g3, &launch);
     if (sl)
-      hipLaunchKernelGGL((k_warp_same_grid_sl<1>), g3.grid, g3.block, 0, ctx->stream, moving, field, out, d, sc, edge_value, halt_flag);
+      hipLaunchKernelGGL((k_warp_same_grid_sl<1>), launch, g3.block, 0, ctx->stream, moving, field, out, d, sc, edge_value, halt_flag, B);
     else
       hipLaunchKernelGGL((k_warp_same_grid<1>), g3.grid, g3.block, 0, ctx->stream, moving, field, out, d, sc, edge_value, halt_flag);
   }
@@ -823,7 +873,9 @@ int pp_compose_field_f32(pp_ctx* ctx, float* total, const float* iter, const pp_
   // flight together ran 1.43 ms against this kernel's 1.14 ms at 512 x 512 x 256 -- one voxel per thread keeps more gathers
   // of more wavefronts in flight.)
   const pp_grid3 g3 = grid3_for(d.nx, d.ny, d.nz);
-  hipLaunchKernelGGL(k_compose_same_grid, g3.grid, g3.block, 0, ctx->stream, total, iter, d, sc);
+  dim3 launch;
+  const pp_band B = band_for(g3, &launch);
+  hipLaunchKernelGGL(k_compose_same_grid, launch, g3.block, 0, ctx->stream, total, iter, d, sc, B);
   PP_LAUNCH_CHECK(ctx, "k_compose_same_grid");
   return PP_OK;
 }

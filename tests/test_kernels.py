@@ -312,6 +312,49 @@ def test_marching_gathers_equal_the_general_kernels(backend, shape, monkeypatch)
     assert any((a != a.flat[0]).any() for a in res[""])
 
 
+@pytest.mark.parametrize("shape", [(3, 260, 9), (2, 65, 300)])
+def test_banded_launch_visits_every_voxel_once(backend, shape, monkeypatch):
+    """Round 5: the gathers through a field (warp, axis-aligned resample, composition) are launched as a 1-D grid whose
+    block b works on plane (b / 8) / per, tile (b % 8) x per + (b / 8) % per, so that each XCD owns a band of rows of every
+    plane (PP_RS_BAND=0: the plain 3-D grid).  Same results, on grids whose tile count is not a multiple of 8."""
+    spacing, origin = (1.1, 0.8, 2.0), (3.0, -2.0, 1.0)
+    rng = np.random.default_rng(5)
+    img = (phantom(shape, seed=8) + 20.0 * rng.standard_normal(shape)).astype(np.float32)
+    lab = rng.integers(0, 4, shape).astype(np.uint8)
+    f = random_dvf(shape, spacing, seed=9, max_mm=3.0).astype(np.float32)
+    it = random_dvf(shape, spacing, seed=10, max_mm=2.0)
+    g = geom_of(shape, spacing, origin)
+    res = {}
+    for mode in ("", "0"):
+        if mode:
+            monkeypatch.setenv("PP_RS_BAND", mode)
+        else:
+            monkeypatch.delenv("PP_RS_BAND", raising=False)
+        ctx, r = backend.ctx, []
+        out = backend.empty(shape)
+        out[...] = -5.0
+        ctx.warp(backend.dev(img), backend.dev(f), g, -1000.0, out)
+        r.append(backend.host(out).copy())
+        out = backend.empty(shape)
+        out[...] = -5.0
+        ctx.resample(backend.dev(img), g, g, out, field=backend.dev(f), interp=_lib.INTERP_LINEAR, default_value=-1000.0)
+        r.append(backend.host(out).copy())
+        out = backend.empty(shape, np.uint8)
+        out[...] = 9
+        ctx.resample(backend.dev(lab), g, g, out, field=backend.dev(f), interp=_lib.INTERP_NEAREST, default_value=7, u8=True)
+        r.append(backend.host(out).copy())
+        tot = backend.dev(f)
+        ctx.compose_field(tot, backend.dev(it), g)
+        r.append(backend.host(tot).copy())
+        res[mode] = r
+    for a, b in zip(res[""], res["0"]):
+        np.testing.assert_array_equal(a, b)
+    assert (res[""][0] != -5.0).all() and (res[""][1] != -5.0).all() and (res[""][2] != 9).all()
+    fvol = O.Vol(f.astype(np.float64), spacing, origin)
+    want = O.resample(O.Vol(lab, spacing, origin), O.Vol(lab, spacing, origin), field_vol=fvol, interp=_lib.INTERP_NEAREST, default_value=7).arr
+    np.testing.assert_array_equal(res[""][2], want)
+
+
 def _demons_params(ctx, iterations, spacing, variant, max_rms=0.02):
     p = ctx.default_demons_params()
     p.iterations = iterations
