@@ -563,7 +563,7 @@ rs_grid rs_grid_for(const pp_dims& d) {
   g.gx = (unsigned)((d.nx + RS_TX - 1) / RS_TX);
   g.gy = (unsigned)((d.ny + RS_TY - 1) / RS_TY);
   g.zc = 32;
-  static const char* e = getenv("PP_RS_ZCHUNK");
+  const char* e = getenv("PP_RS_ZCHUNK");
   if (e && atoi(e) > 0) g.zc = (unsigned)atoi(e);
   while (g.zc > 1 && (size_t)g.gx * g.gy * ((d.nz + g.zc - 1) / g.zc) < 4096) g.zc >>= 1;
   g.gz = (unsigned)((d.nz + g.zc - 1) / g.zc);
