@@ -22,11 +22,15 @@ constexpr int NT = 256;
 
 // Launch geometry of the per-voxel kernels: thread (x, y) of a (bx, 256 / bx) block, grid (x blocks, y blocks, z) -- no
 // 64-bit division per voxel to recover (x, y, z) from a linear index.  bx = 64 / 128 / 256 lanes along x by row length.
+// (Round 5: it was 256 for every row longer than 128 -- a third of the lanes idle at 341.)
 struct pp_grid3 {
   dim3 grid, block;
 };
-pp_grid3 grid3_for(int nxv, int ny, int nz) {
-  const unsigned bx = nxv <= 64 ? 64u : (nxv <= 128 ? 128u : 256u);
+pp_grid3 grid3_for(int nxv, int ny, int nz, unsigned bx_max = 256u) {
+  // the widest of 64 / 128 / 256 lanes along x that pads the row least (341 voxels: 128 -> 384 lanes, not 256 -> 512)
+  unsigned bx = 64u;
+  for (unsigned c = 128u; c <= 256u && c <= bx_max; c *= 2u)
+    if ((unsigned)((nxv + c - 1) / c) * c <= (unsigned)((nxv + bx - 1) / bx) * bx) bx = c;
   const unsigned by = NT / bx;
   pp_grid3 g;
   g.block = dim3(bx, by, 1);
@@ -872,7 +876,11 @@ int pp_compose_field_f32(pp_ctx* ctx, float* total, const float* iter, const pp_
   // (measured, round 3: four voxels per thread with 16-byte accesses of `total` and the twelve corner loads of a voxel pair in
   // flight together ran 1.43 ms against this kernel's 1.14 ms at 512 x 512 x 256 -- one voxel per thread keeps more gathers
   // of more wavefronts in flight.)
-  const pp_grid3 g3 = grid3_for(d.nx, d.ny, d.nz);
+  // 64 x 4 blocks: a block's four rows share their upper / lower corner rows in L1 (sbench 0.99 -> 0.96 ms, config 2's
+  // registration 15.69 -> 15.53 ms against 256 x 1; PP_COMPOSE_BLOCK=128|256 for the other shapes)
+  unsigned bxm = 64u;
+  if (const char* e = getenv("PP_COMPOSE_BLOCK")) bxm = (unsigned)atoi(e) >= 64u ? (unsigned)atoi(e) : 64u;
+  const pp_grid3 g3 = grid3_for(d.nx, d.ny, d.nz, bxm);
   dim3 launch;
   const pp_band B = band_for(g3, &launch);
   hipLaunchKernelGGL(k_compose_same_grid, launch, g3.block, 0, ctx->stream, total, iter, d, sc, B);
