@@ -890,6 +890,9 @@ __global__ void __launch_bounds__(NT, PP_MV_WAVES) k_metric_values_lanes(const f
     // left the wavefront before the block takes its ticket.
     __hip_atomic_store(mine + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if defined(__HIP_DEVICE_COMPILE__)
+#if !defined(__gfx950__) && !defined(PP_ALLOW_FENCE_FREE_HANDOVER)
+#error "the fence-free row hand-over above is a property of gfx950's L2 / memory-scope behaviour: re-derive it (or put the release / acquire fences back) before building for another target"
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   }
