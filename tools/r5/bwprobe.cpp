@@ -26,6 +26,31 @@ __global__ void __launch_bounds__(256) k_write(float4* __restrict__ b, size_t n)
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = make_float4(1.0f, 2.0f, 3.0f, 4.0f);
 }
 
+// kernel B's store pattern: 512 blocks of 512 threads, a block owns a 64 x 16 tile of a 512 x 512 plane and marches 128
+// planes; per plane it writes its tile of four arrays (D'x, D'y, D'z, M o D').  W = 2: a thread owns two x-neighbours and
+// issues four 8-byte stores (today); W = 4: the lanes of a pair have exchanged halves, each issues two 16-byte stores (even
+// lanes arrays 0 and 1, odd lanes arrays 2 and 3).
+template <int W>
+__global__ void __launch_bounds__(512) k_store_march(float* __restrict__ base, size_t array_floats, int nz) {
+  const int tile = blockIdx.x & 255, chunk = blockIdx.x >> 8;            // 8 x 32 tiles, 2 chunks
+  const int tx = tile & 7, ty = tile >> 3;
+  const int lane2 = threadIdx.x & 31, row = threadIdx.x >> 5;              // 32 threads x 2 voxels = 64 columns, 16 rows
+  const size_t plane = 512 * 512;
+  for (int z = chunk * (nz / 2); z < (chunk + 1) * (nz / 2); ++z) {
+    const size_t rowoff = (size_t)z * plane + (size_t)(ty * 16 + row) * 512 + tx * 64;
+    if (W == 2) {
+      const float2 v = make_float2((float)z, 1.0f);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) *reinterpret_cast<float2*>(base + a * array_floats + rowoff + 2 * lane2) = v;
+    } else {
+      const float4 v = make_float4((float)z, 1.0f, 2.0f, 3.0f);
+      const int pair = lane2 >> 1, odd = lane2 & 1;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) *reinterpret_cast<float4*>(base + (size_t)(2 * odd + a) * array_floats + rowoff + 4 * pair) = v;
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const size_t mb = argc > 1 ? (size_t)atoi(argv[1]) : 1024;   // MB per array
   const size_t n = mb * 1024 * 1024 / 16;
@@ -48,6 +73,26 @@ int main(int argc, char** argv) {
     run("copy (1 read + 1 write)", (double)n * 32, [&] { hipLaunchKernelGGL(k_copy, dim3(blocks), dim3(256), 0, 0, a, b, n); });
     run("copy, non-temporal store", (double)n * 32, [&] { hipLaunchKernelGGL(k_copy_nt, dim3(blocks), dim3(256), 0, 0, a, b, n); });
     run("triad (2 reads + 1 write)", (double)n * 48, [&] { hipLaunchKernelGGL(k_triad, dim3(blocks), dim3(256), 0, 0, a, b, c, n); });
+  }
+  {
+    const int nz = 256;
+    const size_t af = (size_t)512 * 512 * nz;
+    float* big;
+    CK(hipMalloc(&big, 4 * af * sizeof(float)));
+    CK(hipMemset(big, 0, 4 * af * sizeof(float)));
+    for (int rep = 0; rep < 2; ++rep)
+      for (int w : {2, 4}) {
+        auto launch = [&] {
+          if (w == 2) hipLaunchKernelGGL(k_store_march<2>, dim3(512), dim3(512), 0, 0, big, af, nz);
+          else hipLaunchKernelGGL(k_store_march<4>, dim3(512), dim3(512), 0, 0, big, af, nz);
+        };
+        launch(); CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int r = 0; r < 10; ++r) launch();
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+        printf("marching stores of kernel B's shape, %2d-byte stores: %8.3f ms  %7.0f GB/s (16 B/voxel written)\n", 4 * w, ms, 4.0 * af * 4 / (ms * 1e-3) / 1e9);
+      }
   }
   return 0;
 }
