@@ -201,6 +201,7 @@ struct pp_xform {
   double p2i_in[9], o_in[3];
   int has_affine;
   int diag;   // host side: both grids axis-aligned, no linear transform (the marching kernels' case)
+  int axis;   // host side: both grids axis-aligned (k_resample_axis, with or without a linear transform)
 };
 
 // itk::ImageBase::TransformIndexToPhysicalPoint -> MatrixOffsetTransformBase::TransformPoint ->
@@ -500,7 +501,38 @@ __device__ __forceinline__ float rs_sample(const T* __restrict__ im, const rs_co
 // origin_in, times 1 / spacing_in -- the terms pp_map_point adds besides these are products with exact zeros.
 struct rs_axes {
   double s_out[3], o_out[3], o_in[3], p_in[3];
+  double A[9], t[3];   // the linear transform between the two (k_resample_axis<..., AFFINE = true> only)
 };
+// The same with a linear transform q = A p + t between the two axis-aligned grids (the pipelines' affine propagation of
+// images and labels): the index -> physical and physical -> index products are still diagonal, the 3 x 3 in the middle
+// is evaluated as pp_map_point writes it.
+template <bool HASFIELD>
+__device__ __forceinline__ void rs_affine(const rs_axes& X, int x, int y, int z, double ddx, double ddy, double ddz, double c[3]) {
+#pragma clang fp contract(off)
+  double p[3], q[3];
+  p[0] = X.s_out[0] * (double)x;
+  p[0] = p[0] + X.o_out[0];
+  p[1] = X.s_out[1] * (double)y;
+  p[1] = p[1] + X.o_out[1];
+  p[2] = X.s_out[2] * (double)z;
+  p[2] = p[2] + X.o_out[2];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    double s = X.A[r * 3 + 0] * p[0] + X.A[r * 3 + 1] * p[1];
+    s = s + X.A[r * 3 + 2] * p[2];
+    q[r] = s + X.t[r];
+  }
+  if (HASFIELD) {
+    q[0] = q[0] + ddx;
+    q[1] = q[1] + ddy;
+    q[2] = q[2] + ddz;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double v = q[r] - X.o_in[r];
+    c[r] = X.p_in[r] * v;
+  }
+}
 template <bool HASFIELD>
 __device__ __forceinline__ double rs_axis(const rs_axes& X, int r, int idx, double dd) {
 #pragma clang fp contract(off)
@@ -520,7 +552,7 @@ __device__ __forceinline__ bool rs_inside(const double c[3], const pp_dims& n) {
 }
 
 // k_resample on axis-aligned grids (same launch geometry: grid3_for)
-template <typename T, int INTERP, bool HASFIELD, bool WIDE>
+template <typename T, int INTERP, bool HASFIELD, bool WIDE, bool AFFINE>
 __global__ void __launch_bounds__(NT) k_resample_axis(const T* __restrict__ in, pp_dims din, const float* __restrict__ field,
                                                       T* __restrict__ out, pp_dims dout, rs_axes X, T default_value, pp_band B) {
   unsigned bx_, by_, bz_;
@@ -536,9 +568,13 @@ __global__ void __launch_bounds__(NT) k_resample_axis(const T* __restrict__ in, 
     ddz = (double)rs_ld(field, 2u * N4 + i * 4u);
   }
   double c[3];
-  c[0] = rs_axis<HASFIELD>(X, 0, x, ddx);
-  c[1] = rs_axis<HASFIELD>(X, 1, y, ddy);
-  c[2] = rs_axis<HASFIELD>(X, 2, z, ddz);
+  if (AFFINE) {
+    rs_affine<HASFIELD>(X, x, y, z, ddx, ddy, ddz, c);
+  } else {
+    c[0] = rs_axis<HASFIELD>(X, 0, x, ddx);
+    c[1] = rs_axis<HASFIELD>(X, 1, y, ddy);
+    c[2] = rs_axis<HASFIELD>(X, 2, z, ddz);
+  }
   T res = default_value;
   if (rs_inside(c, din)) {
     if (INTERP == PP_INTERP_NEAREST) {
@@ -646,7 +682,8 @@ void fill_xform(const pp_geom* gin, const pp_geom* gout, const double* A, const 
     X->o_in[k] = gin->origin[k];
   }
   X->has_affine = (A != nullptr);
-  X->diag = !A && pp_geom_identity_dir(gin) && pp_geom_identity_dir(gout);
+  X->axis = pp_geom_identity_dir(gin) && pp_geom_identity_dir(gout);
+  X->diag = !A && X->axis;
   static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   memcpy(X->A, A ? A : I3, sizeof(X->A));
   for (int k = 0; k < 3; ++k) X->t[k] = (A && t) ? t[k] : 0.0;
@@ -660,7 +697,9 @@ rs_axes rs_axes_of(const pp_xform& X) {
     a.o_out[k] = X.o_out[k];
     a.o_in[k] = X.o_in[k];
     a.p_in[k] = X.p2i_in[k * 3 + k];
+    a.t[k] = X.t[k];
   }
+  for (int k = 0; k < 9; ++k) a.A[k] = X.A[k];
   return a;
 }
 
@@ -690,13 +729,14 @@ int resample_any(pp_ctx* ctx, const T* in, const pp_geom* gin, const pp_geom* go
   } else {
     dv = (T)default_value;
   }
-  if (X.diag && interp != PP_INTERP_BSPLINE && rs_small(din, sizeof(T)) && rs_small(dout, field ? 12 : sizeof(T)) && !rs_generic_forced()) {
+  if (X.axis && interp != PP_INTERP_BSPLINE && rs_small(din, sizeof(T)) && rs_small(dout, field ? 12 : sizeof(T)) && !rs_generic_forced()) {
     const rs_axes XA = rs_axes_of(X);
     dim3 launch;
     // (banded only where it measured faster or equal: linear through a field.  Labels through a field and resamples without
     // a field fetch nothing twice to begin with and ran 8 - 17 % slower banded.)
     const pp_band B = band_for(g3, &launch, field != nullptr && interp == PP_INTERP_LINEAR && sizeof(T) == 4);
-#define PP_RSA(I, F, W) hipLaunchKernelGGL((k_resample_axis<T, I, F, W>), launch, block, 0, ctx->stream, in, din, field, out, dout, XA, dv, B)
+#define PP_RSA2(I, F, W, AF) hipLaunchKernelGGL((k_resample_axis<T, I, F, W, AF>), launch, block, 0, ctx->stream, in, din, field, out, dout, XA, dv, B)
+#define PP_RSA(I, F, W) do { if (X.has_affine) PP_RSA2(I, F, W, true); else PP_RSA2(I, F, W, false); } while (0)
     if (interp == PP_INTERP_NEAREST) {
       if (field) PP_RSA(PP_INTERP_NEAREST, true, true); else PP_RSA(PP_INTERP_NEAREST, false, true);
     } else if (din.nx >= 2) {
@@ -704,6 +744,7 @@ int resample_any(pp_ctx* ctx, const T* in, const pp_geom* gin, const pp_geom* go
     } else {
       if (field) PP_RSA(PP_INTERP_LINEAR, true, false); else PP_RSA(PP_INTERP_LINEAR, false, false);
     }
+#undef PP_RSA2
 #undef PP_RSA
     PP_LAUNCH_CHECK(ctx, name);
     return PP_OK;

@@ -263,7 +263,8 @@ def test_resample_field_and_compose(backend):
 def test_marching_gathers_equal_the_general_kernels(backend, shape, monkeypatch):
     """Round 5: on axis-aligned grids below 2^32 bytes, resample (linear / nearest, fp32 / u8, with and without a field) runs
     with one fp64 multiply per axis and 32-bit offsets, and the field up-sampling marches z with its corner pairs kept in
-    registers from plane to plane.  The terms they drop are products with exact zeros, so every result is bit-identical to
+    registers from plane to plane; with a linear transform between the grids only the 3 x 3 in the middle stays.  The terms
+    they drop are products with exact zeros, so every result is bit-identical to
     the general kernels (PP_RESAMPLE_GENERIC=1) -- inside, on the buffer border, outside, single-column and two-column
     volumes, tiles and z chunks that overhang the volume, up- and down-sampling along z."""
     spacing, origin = (0.9, 1.3, 2.1), (-11.5, 4.25, 100.0)
@@ -294,6 +295,20 @@ def test_marching_gathers_equal_the_general_kernels(backend, shape, monkeypatch)
             r.append(backend.host(out).copy())
             out = backend.empty(other_shape, np.uint8)
             ctx.resample(backend.dev(lab), g, other, out, interp=interp, default_value=0, u8=True)
+            r.append(backend.host(out).copy())
+        # the same with a linear transform between the two grids (the pipelines' affine propagation)
+        ang = 0.07
+        A = np.array([[np.cos(ang), -np.sin(ang), 0.01], [np.sin(ang), np.cos(ang), -0.02], [0.015, 0.0, 1.03]])
+        t = np.array([0.8, -1.1, 0.6])
+        for interp in (_lib.INTERP_LINEAR, _lib.INTERP_NEAREST):
+            out = backend.empty(other_shape)
+            ctx.resample(backend.dev(img), g, other, out, affine_A=A.ravel(), affine_t=t, interp=interp, default_value=-1000.0)
+            r.append(backend.host(out).copy())
+            out = backend.empty(shape)
+            ctx.resample(backend.dev(img), g, g, out, affine_A=A.ravel(), affine_t=t, field=backend.dev(f), interp=interp, default_value=-2.0)
+            r.append(backend.host(out).copy())
+            out = backend.empty(other_shape, np.uint8)
+            ctx.resample(backend.dev(lab), g, other, out, affine_A=A.ravel(), affine_t=t, interp=interp, default_value=9, u8=True)
             r.append(backend.host(out).copy())
         out = backend.empty((3,) + other_shape)
         ctx.resample_field(backend.dev(f), g, other, out)

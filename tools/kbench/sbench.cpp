@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -100,6 +101,11 @@ int main(int argc, char** argv) {
   run("warp (same grid, linear)", 20, [&] { return warp(ctx, A, D, &g, -1000.0f, B); });
   run("resample f32 linear through field", 20, [&] { return resample(ctx, A, &g, &g, nullptr, nullptr, D, 2, -1000.0, B); });
   run("resample u8 nearest through field", 14, [&] { return resample_u8(ctx, L, &g, &g, nullptr, nullptr, D, 1, 0.0, L2); });
+  {
+    const double ang = 0.05, Aa[9] = {cos(ang), -sin(ang), 0.0, sin(ang), cos(ang), 0.0, 0.0, 0.0, 1.02}, ta[3] = {3.0, -2.0, 1.5};
+    run("resample f32 linear through an affine", 8, [&] { return resample(ctx, A, &g, &g, Aa, ta, nullptr, 2, -1000.0, B); });
+    run("resample u8 nearest through an affine", 2, [&] { return resample_u8(ctx, L, &g, &g, Aa, ta, nullptr, 1, 0.0, L2); });
+  }
   run("resample f32 linear identity", 8, [&] { return resample(ctx, A, &g, &g, nullptr, nullptr, nullptr, 2, 0.0, B); });
   {
     auto resample_field = sym<int (*)(pp_ctx*, const float*, const pp_geom*, const pp_geom*, float*)>(h, "pp_resample_field_f32");
