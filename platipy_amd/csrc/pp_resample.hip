@@ -2,16 +2,22 @@
 //
 // Replaces itk::WarpImageFilter inside the demons loop, sitk.Resample / ResampleImageFilter
 // (reference: registration/utils.py:176-190, :257-267; registration/deformable.py:130,137,140,
-// 154,185,281-301) and itk::DisplacementFieldTransform.  All kernels are HBM/L2-bound gathers:
-// lanes run along x so the displacement planes, the output and -- for smooth fields -- the
-// eight gathered neighbours are row-coalesced; one thread handles 4 consecutive voxels.
+// 154,185,281-301) and itk::DisplacementFieldTransform.  All kernels are gathers: lanes run along x
+// so the displacement planes, the output and -- for smooth fields -- the gathered neighbours are
+// row-coalesced.  What bounds them is the number of gather instructions (an 8-byte corner pair costs
+// ~15 clocks per wavefront and CU on consecutive lanes, ~30 otherwise: profiles/round5_tabench.txt) and,
+// for the fp64 coordinate path, instruction issue -- not HBM bytes.
 //
 // Two coordinate paths:
 //  * same-grid (hot loop, compose): continuous index = idx + D / spacing, formed as an integer
 //    base plus an fp32 fraction so no precision is lost to the magnitude of idx;
 //  * general (pyramids, linear transforms, propagation of masks): the ITK sequence
 //    index -> physical -> transform -> physical -> continuous index, evaluated in fp64 with
-//    contraction off, so nearest-neighbour decisions match the fp64 restatement bit for bit.
+//    contraction off, so nearest-neighbour decisions match the fp64 restatement bit for bit.  On
+//    axis-aligned grids (every pipeline grid) k_resample_axis / k_resample_field_march evaluate the
+//    same sequence without its exact-zero terms (round 5, below).
+// Launch geometry: grid3_for (block width by least row padding) and, for the gathers through a field,
+// the XCD-banded order of band_for.
 #include "pp_internal.h"
 #include "pp_kernels.h"
 #include "pp_warp_sample.h"
