@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 1
+#define PP_ABI_VERSION 2
 
 typedef enum {
   PP_OK = 0,
@@ -347,6 +347,7 @@ enum { PP_MODEL_TRANSLATION = 0, PP_MODEL_VERSOR_RIGID = 1, PP_MODEL_SIMILARITY 
        PP_MODEL_AFFINE = 4, PP_MODEL_EULER = 5, PP_MODEL_SCALE_VERSOR = 6,
        PP_MODEL_SCALE_SKEW_VERSOR = 7 };                 /* sitk parameter layouts; 3/6/7/3/12/6/9/15 parameters */
 enum { PP_OPT_GD = 0, PP_OPT_GD_LINE_SEARCH = 1 };
+enum { PP_LINREG_RETURN_BEST = 1 };
 enum { PP_LINREG_STOP_ITERATIONS = 0, PP_LINREG_STOP_CONVERGED = 1, PP_LINREG_STOP_NO_OVERLAP = 2 };
 typedef struct pp_linreg_level {
   int model;              /* PP_MODEL_*: q = A(params) (p - center) + center + t(params)            */
@@ -356,20 +357,21 @@ typedef struct pp_linreg_level {
   int vsize[3];           /* virtual (shrunk fixed) domain                                            */
   int stride;             /* REGULAR sampling: every stride-th voxel of it                            */
   int speculation;        /* golden-section tree levels probed per launch, 1..4 (1 = sequential)      */
-  int reserved;
+  int flags;              /* PP_LINREG_RETURN_BEST or 0 (ITK / SimpleITK default: the level's last point) */
   double v_i2p[9], v_origin[3]; /* virtual index -> physical: p = v_i2p idx + v_origin               */
   double f_p2i[9], f_origin[3]; /* fixed  physical -> index:  idx = f_p2i (p - f_origin)             */
   double m_p2i[9], m_origin[3]; /* moving physical -> index                                           */
   double init_matrix[9], init_offset[3]; /* the centring transform composed in front: q = M p + o    */
   double center[3];       /* fixed centre of rotation of the optimised transform                      */
-  double v_min_spacing;   /* smallest virtual spacing (learning-rate estimate)                        */
+  double v_min_spacing;   /* m_MaximumStepSizeInPhysicalUnits of the learning-rate estimate: the smallest virtual
+                             spacing OF THE FIRST LEVEL (ITK assigns the default once per optimiser)     */
 } pp_linreg_level;
 typedef struct pp_linreg_stats {
   int iterations;         /* optimiser iterations taken            */
   int evaluations;        /* metric evaluations (probes included)  */
   int stop;               /* PP_LINREG_STOP_*                      */
   int reserved;
-  double value;           /* metric at the returned parameters     */
+  double value;           /* optimiser's GetMetricValue(): the last evaluation (with RETURN_BEST: at the returned point) */
   double learning_rate;   /* last learning rate                    */
 } pp_linreg_stats;
 int pp_linear_num_parameters(int model);

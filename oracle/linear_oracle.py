@@ -249,3 +249,329 @@ def itk_regular_jitter(generator, vsize, stride, vspacing, vdirection=None):
     d = np.eye(3) if vdirection is None else np.asarray(vdirection, dtype=np.float64).reshape(3, 3)
     p2i = np.linalg.inv(d * sp[None, :])
     return phys @ p2i.T
+
+
+# =================================================================================================================================
+# The registration as a whole (round 6): sitk.ImageRegistrationMethod.Execute as platipy/imaging/registration/linear.py:129-238
+# configures it, restated in fp64 numpy from the ITK 5.3 classes it instantiates -- ImageRegistrationMethodv4 (level loop),
+# MeanSquaresImageToImageMetricv4 (physical-space formulation, analytic transform Jacobians),
+# RegistrationParameterScalesFromPhysicalShift, GradientDescentOptimizerv4 / GradientDescentLineSearchOptimizerv4,
+# WindowConvergenceMonitoringFunction, the transforms' UpdateTransformParameters.  TEST INFRASTRUCTURE, PARITY UNPINNED (ITK from
+# memory); it shares no code with platipy_amd/registration/linear.py or csrc/pp_linear.hip: the product works in index space with
+# central differences of the index map, batches its line-search probes and runs its metric in fp32 kernels; this file works in
+# physical space with analytic Jacobians, probes sequentially and accumulates in fp64.
+
+
+def _quat_mul(a, b):
+    """Hamilton product of (v, w) quaternions, vector form: (wa vb + wb va + va x vb, wa wb - va . vb)."""
+    va, wa, vb, wb = np.asarray(a[:3]), a[3], np.asarray(b[:3]), b[3]
+    return np.concatenate([wa * vb + wb * va + np.cross(va, vb), [wa * wb - va @ vb]])
+
+
+class OracleTransform:
+    """The optimised transform T(x) = M(p) (x - c) + c + t(p) with ITK's parameter layouts, its analytic Jacobian and its
+    UpdateTransformParameters.  kinds: translation (t), rigid (versor 3, t 3), similarity (versor 3, t 3, scale), affine (matrix
+    row-major 9, t 3)."""
+
+    def __init__(self, kind, center=(0.0, 0.0, 0.0)):
+        self.kind = kind
+        self.c = np.asarray(center, dtype=np.float64)
+        self.p = {"translation": np.zeros(3), "rigid": np.zeros(6), "similarity": np.array([0, 0, 0, 0, 0, 0, 1.0]),
+                  "affine": np.concatenate([np.eye(3).ravel(), np.zeros(3)])}[kind].astype(np.float64)
+
+    @staticmethod
+    def _rot(v):
+        """itk::Versor -> matrix: R x = x + 2 w (v x x) + 2 v x (v x x), w = sqrt(1 - |v|^2)."""
+        v = np.asarray(v, dtype=np.float64)
+        w = np.sqrt(max(0.0, 1.0 - v @ v))
+        K = np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+        return np.eye(3) + 2.0 * w * K + 2.0 * K @ K
+
+    def matrix_translation(self, p=None):
+        p = self.p if p is None else p
+        if self.kind == "translation":
+            return np.eye(3), p[0:3]
+        if self.kind == "rigid":
+            return self._rot(p[0:3]), p[3:6]
+        if self.kind == "similarity":
+            return p[6] * self._rot(p[0:3]), p[3:6]
+        return p[0:9].reshape(3, 3), p[9:12]
+
+    def apply(self, x, p=None):
+        M, t = self.matrix_translation(p)
+        return (x - self.c) @ M.T + self.c + t
+
+    def jacobian(self, x):
+        """d T(x) / d p  -> [n, 3, n_params] (ComputeJacobianWithRespectToParameters)."""
+        d = x - self.c
+        n = len(x)
+        if self.kind == "translation":
+            return np.broadcast_to(np.eye(3), (n, 3, 3)).copy()
+        if self.kind == "affine":
+            J = np.zeros((n, 3, 12))
+            for r in range(3):
+                J[:, r, 3 * r:3 * r + 3] = d
+                J[:, r, 9 + r] = 1.0
+            return J
+        v = self.p[0:3]
+        w = np.sqrt(max(1e-300, 1.0 - v @ v))
+        s = self.p[6] if self.kind == "similarity" else 1.0
+        J = np.zeros((n, 3, len(self.p)))
+        vxd = np.cross(v, d)
+        for i in range(3):
+            e = np.zeros(3)
+            e[i] = 1.0
+            exd = np.cross(e, d)
+            J[:, :, i] = s * (2.0 * (-v[i] / w) * vxd + 2.0 * w * exd + 2.0 * (np.cross(e, vxd) + np.cross(v, exd)))
+        J[:, 0, 3] = J[:, 1, 4] = J[:, 2, 5] = 1.0
+        if self.kind == "similarity":
+            J[:, :, 6] = d @ self._rot(v).T
+        return J
+
+    def updated(self, update):
+        """UpdateTransformParameters(update, 1) -> new parameter vector (self.p untouched)."""
+        update = np.asarray(update, dtype=np.float64)
+        new = self.p + update
+        if self.kind in ("rigid", "similarity"):
+            v = self.p[0:3]
+            cur = np.concatenate([v, [np.sqrt(max(0.0, 1.0 - v @ v))]])
+            angle = float(np.linalg.norm(update[0:3]))
+            if angle > 0.0:
+                grad_rot = np.concatenate([update[0:3] / angle * np.sin(angle / 2.0), [np.cos(angle / 2.0)]])
+            else:
+                grad_rot = np.array([0.0, 0.0, 0.0, 1.0])
+            q = _quat_mul(cur, grad_rot)
+            new[0:3] = q[0:3] if q[3] >= 0.0 else -q[0:3]
+        return new
+
+
+def _window_convergence_itk(energies, window=10):
+    """WindowConvergenceMonitoringFunction::GetConvergenceValue (see the note in the product's _window_convergence; written here
+    from the filter's per-point accumulation rather than in closed form)."""
+    if len(energies) < window:
+        return np.inf
+    e = np.asarray(energies[-window:], dtype=np.float64)
+    total = np.abs(e).sum()
+    if total == 0.0:
+        return 0.0
+    delta, omega = np.zeros(2), np.zeros(2)
+    for i in range(window):
+        u = i / (window - 1.0)
+        if abs(u - 1.0) <= 1e-4:
+            u = 1.0 - 1e-4
+        bw = np.array([1.0 - u, u])                  # order-1 B-spline weights of the two control points
+        w2 = (bw * bw).sum()
+        for k in range(2):
+            phi = bw[k] * (e[i] / total) / w2
+            delta[k] += bw[k] * bw[k] * phi
+            omega[k] += bw[k] * bw[k]
+    lattice = delta / omega
+    return -(lattice[1] - lattice[0])
+
+
+def _shrunk_virtual_domain(size, spacing, origin, direction, factor):
+    """itk::ShrinkImageFilter::GenerateOutputInformation: size floor(n / f) (>= 1), spacing * f, origin moved so that the centre
+    of the domain stays where it is."""
+    n = np.asarray(size, dtype=np.float64)
+    f = np.broadcast_to(np.asarray(factor, dtype=np.float64), (3,))
+    out_size = np.maximum(1, np.floor(n / f)).astype(np.int64)
+    sp_in = np.asarray(spacing, dtype=np.float64)
+    sp_out = sp_in * f
+    D = np.asarray(direction, dtype=np.float64).reshape(3, 3)
+    centre_in = D @ (sp_in * (n - 1.0) / 2.0)
+    centre_out = D @ (sp_out * (out_size - 1.0) / 2.0)
+    return out_size, sp_out, np.asarray(origin, dtype=np.float64) + centre_in - centre_out, D
+
+
+class _PhysicalMeanSquares:
+    """MeanSquaresImageToImageMetricv4 over one level's sample point set, in PHYSICAL space."""
+
+    def __init__(self, fixed, moving, points, init_matrix, init_offset, gradient_image):
+        self.f_arr, self.m_arr = np.asarray(fixed.arr, dtype=np.float32), np.asarray(moving.arr, dtype=np.float32)
+        self.f_p2i, self.f_o = self._p2i(fixed), np.asarray(fixed.origin, dtype=np.float64)
+        self.m_p2i, self.m_o = self._p2i(moving), np.asarray(moving.origin, dtype=np.float64)
+        self.m_i2p_T = np.linalg.inv(self.m_p2i).T
+        self.points = points
+        self.Ai, self.oi = init_matrix, init_offset
+        self.gimg = gradient_image              # [3, Z, Y, X] physical gradient (filtered), or None: the interpolant's own
+        ok, self.fval, _ = _sample(self.f_arr, (points - self.f_o) @ self.f_p2i.T)
+        self.f_ok = ok
+        self.evaluations = 0
+
+    @staticmethod
+    def _p2i(vol):
+        D = np.asarray(vol.direction, dtype=np.float64).reshape(3, 3)
+        return np.linalg.inv(D * np.asarray(vol.spacing, dtype=np.float64)[None, :])
+
+    def _moving(self, tfm, p):
+        y = tfm.apply(self.points, p) @ self.Ai.T + self.oi
+        cm = (y - self.m_o) @ self.m_p2i.T
+        ok, mval, g_idx = _sample(self.m_arr, cm)
+        return ok & self.f_ok, mval, g_idx, cm
+
+    def value(self, tfm, p=None):
+        self.evaluations += 1
+        ok, mval, _, _ = self._moving(tfm, p)
+        n = int(ok.sum())
+        if n == 0:
+            return np.inf
+        d = np.where(ok, self.fval - mval, 0.0)
+        return float((d * d).sum() / n)
+
+    def value_and_derivative(self, tfm):
+        """-> (value, derivative) with ITK's sign: the optimiser ADDS learning_rate * derivative / scales."""
+        self.evaluations += 1
+        ok, mval, g_idx, cm = self._moving(tfm, None)
+        n = int(ok.sum())
+        if n == 0:
+            return np.inf, np.zeros(len(tfm.p))
+        if self.gimg is not None:
+            g_phys = np.stack([_sample(self.gimg[r], cm)[1] for r in range(3)], axis=1)
+        else:
+            g_phys = g_idx @ self.m_p2i              # d m / d y = (d idx / d y)^T d m / d idx
+        d = np.where(ok, self.fval - mval, 0.0)
+        J = np.einsum("rc,ncp->nrp", self.Ai, tfm.jacobian(self.points))    # composite: initial's position Jacobian x optimised's
+        per_sample = np.einsum("nr,nrp->np", np.where(ok[:, None], g_phys, 0.0), J)
+        return float((d * d).sum() / n), (2.0 * d[:, None] * per_sample).sum(0) / n
+
+
+def _corner_points(vsize, vspacing, vorigin, vdir):
+    n = np.asarray(vsize, dtype=np.float64) - 1.0
+    idx = np.array([[i, j, k] for k in (0.0, n[2]) for j in (0.0, n[1]) for i in (0.0, n[0])])
+    return vorigin[None, :] + (idx * vspacing[None, :]) @ vdir.T
+
+
+def _max_shift(tfm, corners, Ai, delta):
+    """ScalesFromShiftBase::ComputeMaximumVoxelShift for the physical-shift estimator: largest displacement of a corner of the
+    virtual domain, through the composite moving transform, when the parameters are UPDATED by delta."""
+    old = tfm.apply(corners) @ Ai.T
+    new = tfm.apply(corners, tfm.updated(delta)) @ Ai.T
+    return float(np.sqrt(((new - old) ** 2).sum(1)).max())
+
+
+def _estimate_scales(tfm, corners, Ai, variation=0.01):
+    n = len(tfm.p)
+    shifts = np.zeros(n)
+    for i in range(n):
+        d = np.zeros(n)
+        d[i] = variation
+        shifts[i] = _max_shift(tfm, corners, Ai, d)
+    eps = np.finfo(np.float64).eps
+    nonzero = shifts[shifts > eps]
+    if nonzero.size == 0:
+        return np.ones(n)
+    smallest = nonzero.min()
+    scales = np.where(shifts <= eps, smallest * smallest, shifts * shifts)
+    return scales / (variation * variation)
+
+
+def _estimate_step_scale(tfm, corners, Ai, step, variation=0.01):
+    biggest = float(np.abs(step).max())
+    if biggest <= np.finfo(np.float64).eps:
+        return 0.0
+    factor = variation / biggest
+    return _max_shift(tfm, corners, Ai, step * factor) / factor
+
+
+def _golden_section_itk(value_at, a, b, c, state, metric_b=None, epsilon=0.01, max_iterations=20):
+    """GradientDescentLineSearchOptimizerv4::GoldenSectionSearch, the recursion as ITK writes it (one probe at a time)."""
+    if state["iterations"] > max_iterations:
+        return (c + a) / 2.0
+    state["iterations"] += 1
+    resphi = 2.0 - (1.0 + np.sqrt(5.0)) / 2.0
+    x = b + resphi * (c - b) if (c - b) > (b - a) else b - resphi * (b - a)
+    if abs(c - a) < epsilon * (abs(b) + abs(x)):
+        return (c + a) / 2.0
+    if metric_b is None:
+        metric_b = value_at(b)
+    metric_x = value_at(x)
+    if metric_x < metric_b:
+        if (c - b) > (b - a):
+            return _golden_section_itk(value_at, b, x, c, state, metric_x, epsilon, max_iterations)
+        return _golden_section_itk(value_at, a, x, b, state, metric_x, epsilon, max_iterations)
+    if (c - b) > (b - a):
+        return _golden_section_itk(value_at, a, b, x, state, metric_b, epsilon, max_iterations)
+    return _golden_section_itk(value_at, x, b, c, state, metric_b, epsilon, max_iterations)
+
+
+def registration(fixed, moving, reg_method="similarity", optimiser="gradient_descent", shrink_factors=(8, 2, 1), smooth_sigmas=(4, 2, 0),
+                 sampling_rate=0.25, number_of_iterations=50, seed=42, itk_sampling=True, return_best=False):
+    """fixed, moving: oracle.Vol (float32 [Z, Y, X] + geometry).  -> dict(parameters, levels=[dict(values, parameters per
+    iteration, learning_rates, scales, stop)], init_matrix, init_offset, evaluations).  mean_squares only (the pipelines' metric).
+    itk_sampling=False: samples on the lattice and the interpolant's gradient (the product's opt-out), for A/B tests."""
+    from oracle import oracle as O
+
+    kind = {"translation": "translation", "rigid": "rigid", "similarity": "similarity", "affine": "affine"}[reg_method.lower()]
+    fD = np.asarray(fixed.direction, dtype=np.float64).reshape(3, 3)
+    mD = np.asarray(moving.direction, dtype=np.float64).reshape(3, 3)
+
+    def centre(vol, D):
+        n = np.asarray(vol.size, dtype=np.float64)
+        return np.asarray(vol.origin) + D @ (np.asarray(vol.spacing) * (n - 1.0) / 2.0)
+
+    # CenteredTransformInitializer(fixed, moving, Euler3DTransform(), GEOMETRY): identity rotation, translation between the centres
+    Ai, oi = np.eye(3), centre(moving, mD) - centre(fixed, fD)
+    tfm = OracleTransform(kind)
+    generator = MersenneTwister(seed) if itk_sampling else None
+    levels, max_step, evaluations = [], None, 0
+    for shrink, sigma in zip(shrink_factors, smooth_sigmas):
+        f_l = O.discrete_gaussian(fixed, sigma * sigma) if sigma > 0 else fixed
+        m_l = O.discrete_gaussian(moving, sigma * sigma) if sigma > 0 else moving
+        vsize, vspacing, vorigin, vdir = _shrunk_virtual_domain(fixed.size, fixed.spacing, fixed.origin, fixed.direction, shrink)
+        stride = int(np.ceil(1.0 / sampling_rate)) if sampling_rate < 1.0 else 1
+        nv = int(vsize[0] * vsize[1] * vsize[2])
+        lin = np.arange(0, nv, stride, dtype=np.int64)
+        idx = np.stack([lin % vsize[0], (lin // vsize[0]) % vsize[1], lin // (vsize[0] * vsize[1])], axis=1).astype(np.float64)
+        points = vorigin[None, :] + (idx * vspacing[None, :]) @ vdir.T
+        if generator is not None:       # SetMetricSamplePoints: each physical coordinate + N(0, 1) * spacing / 3, raster order
+            points = points + generator.normal_variates(3 * len(points)).reshape(len(points), 3) * (vspacing / 3.0)[None, :]
+        gimg = O.gradient_recursive_gaussian(m_l).astype(np.float64) if itk_sampling else None
+        metric = _PhysicalMeanSquares(f_l, m_l, points, Ai, oi, gimg)
+        corners = _corner_points(vsize, vspacing, vorigin, vdir)
+        # ---- StartOptimization ----
+        scales = _estimate_scales(tfm, corners, Ai)
+        if max_step is None:            # "if the user hasn't set this, assign the default" -- once per optimiser object
+            max_step = float(vspacing.min())
+        energies, rec = [], {"values": [], "parameters": [], "learning_rates": [], "scales": scales.tolist(), "stop": "iterations"}
+        learning_rate, best_value, best_p = 1.0, np.inf, tfm.p.copy()
+        for it in range(number_of_iterations):
+            value, derivative = metric.value_and_derivative(tfm)
+            if not np.isfinite(value):
+                if it == 0:
+                    raise RuntimeError("no valid sample points")
+                rec["stop"] = "no overlap"
+                tfm.p = previous
+                break
+            rec["values"].append(value)
+            rec["parameters"].append(tfm.p.copy())
+            if value < best_value:
+                best_value, best_p = value, tfm.p.copy()
+            energies.append(value)
+            if _window_convergence_itk(energies) <= 1e-6:
+                rec["stop"] = "converged"
+                break
+            gradient = derivative / scales                                  # ModifyGradientByScales
+            if it == 0:                                                     # EstimateLearningRate (Once)
+                step_scale = _estimate_step_scale(tfm, corners, Ai, gradient)
+                learning_rate = max_step / step_scale if step_scale > np.finfo(np.float64).eps else 1.0
+            if optimiser == "gradient_descent_line_search":
+                def value_at(rate):
+                    return metric.value(tfm, tfm.updated(rate * gradient))
+
+                learning_rate = _golden_section_itk(value_at, 0.0 * learning_rate, learning_rate, 5.0 * learning_rate, {"iterations": 0})
+            rec["learning_rates"].append(learning_rate)
+            previous = tfm.p.copy()
+            tfm.p = tfm.updated(learning_rate * gradient)                  # UpdateTransformParameters(m_Gradient)
+        if return_best and metric.value(tfm) > best_value:
+            tfm.p = best_p
+        rec["final"] = tfm.p.copy()
+        evaluations += metric.evaluations
+        levels.append(rec)
+    return {"parameters": tfm.p.copy(), "levels": levels, "init_matrix": Ai, "init_offset": oi, "evaluations": evaluations,
+            "matrix_offset": _total_matrix_offset(tfm, Ai, oi)}
+
+
+def _total_matrix_offset(tfm, Ai, oi):
+    """CompositeTransform([initial, optimised]) as q = A p + off."""
+    M, t = tfm.matrix_translation()
+    return Ai @ M, Ai @ (t + tfm.c - M @ tfm.c) + oi

@@ -18,7 +18,7 @@ INTERP_NEAREST = 1
 INTERP_LINEAR = 2
 INTERP_BSPLINE = 3
 DEMONS_AUTO, DEMONS_STAGED, DEMONS_FUSED = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 HISTORY_CAPACITY = 4096     # PP_DEMONS_HISTORY_CAPACITY: iterations of one Execute whose metric / RMS change the device ring keeps
 
 
@@ -38,7 +38,7 @@ MI_MATTES, MI_JOINT = 0, 1
 
 class LinregLevel(C.Structure):     # pp_linreg_level
     _fields_ = [("model", C.c_int), ("metric", C.c_int), ("optimizer", C.c_int), ("iterations", C.c_int), ("vsize", C.c_int * 3),
-                ("stride", C.c_int), ("speculation", C.c_int), ("reserved", C.c_int),
+                ("stride", C.c_int), ("speculation", C.c_int), ("flags", C.c_int),
                 ("v_i2p", C.c_double * 9), ("v_origin", C.c_double * 3), ("f_p2i", C.c_double * 9), ("f_origin", C.c_double * 3),
                 ("m_p2i", C.c_double * 9), ("m_origin", C.c_double * 3), ("init_matrix", C.c_double * 9),
                 ("init_offset", C.c_double * 3), ("center", C.c_double * 3), ("v_min_spacing", C.c_double)]
@@ -52,6 +52,7 @@ class LinregStats(C.Structure):     # pp_linreg_stats
 ERR_NO_OVERLAP = -6
 MODEL_TRANSLATION, MODEL_VERSOR_RIGID, MODEL_SIMILARITY, MODEL_SCALE, MODEL_AFFINE, MODEL_EULER, MODEL_SCALE_VERSOR, MODEL_SCALE_SKEW_VERSOR = range(8)
 OPT_GD, OPT_GD_LINE_SEARCH = 0, 1
+LINREG_RETURN_BEST = 1
 
 
 class DemonsParams(C.Structure):

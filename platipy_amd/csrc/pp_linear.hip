@@ -5,7 +5,9 @@
 // with REGULAR sampling, RegistrationParameterScalesFromPhysicalShift over the 8 corners of the virtual domain
 // (SetOptimizerScalesFromPhysicalShift, linear.py:231), GradientDescentOptimizerv4 /
 // GradientDescentLineSearchOptimizerv4 (learning rate estimated once per level, golden-section search on
-// [0, 5] x learning rate, epsilon 0.01, <= 20 probes), convergence window 10 / minimum value 1e-6.
+// [0, 5] x learning rate, epsilon 0.01, <= 20 probes), convergence window 10 / minimum value 1e-6, the transform's own
+// UpdateTransformParameters for every step, probe and scale estimate (the versor family composes its rotation), and -- as
+// SimpleITK leaves returnBestParametersAndValue off -- the LAST point of the level as its result.
 //
 // The metric and its gradient are GPU kernels (pp_fusion.hip); everything here is the optimiser's host logic --
 // a few hundred flops per iteration -- kept native so that a registration is one library call per level: no
@@ -37,10 +39,43 @@ void mat_vec(const double* A, const double* x, double* y) {
   for (int k = 0; k < 3; ++k) y[k] = t[k];
 }
 
+// itk::VersorRigid3DTransform::UpdateTransformParameters (inherited by Similarity3D / ScaleVersor3D / ScaleSkewVersor3D): the
+// first three entries of the update are an axis-angle rotation (angle = their norm) composed onto the current versor on the
+// right; the remaining parameters are added by the caller.
+void versor_compose(const double* p, const double* u, double* out) {
+  const double x = p[0], y = p[1], z = p[2];
+  const double w = std::sqrt(std::fmax(0.0, 1.0 - (x * x + y * y + z * z)));
+  const double norm = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+  double gx = 0.0, gy = 0.0, gz = 0.0, gw = 1.0;
+  if (norm > 0.0) {
+    const double f = std::sin(norm / 2.0) / norm;
+    gx = u[0] * f, gy = u[1] * f, gz = u[2] * f, gw = std::cos(norm / 2.0);
+  }
+  double nx = w * gx - z * gy + y * gz + x * gw;
+  double ny = z * gx + w * gy - x * gz + y * gw;
+  double nz = -y * gx + x * gy + w * gz + z * gw;
+  const double nw = -x * gx - y * gy - z * gz + w * gw;
+  if (nw < 0.0) nx = -nx, ny = -ny, nz = -nz;   // only the right part is kept and w = +sqrt(1 - |v|^2): same rotation
+  out[0] = nx, out[1] = ny, out[2] = nz;
+}
+
+bool versor_model(int model) {
+  return model == PP_MODEL_VERSOR_RIGID || model == PP_MODEL_SIMILARITY || model == PP_MODEL_SCALE_VERSOR || model == PP_MODEL_SCALE_SKEW_VERSOR;
+}
+
+// itk::Transform::UpdateTransformParameters(update, 1): out = p (+) update
+void update_parameters(int model, int n, const double* p, const double* u, double* out) {
+  double v[3];
+  const bool versor = versor_model(model);
+  if (versor) versor_compose(p, u, v);
+  for (int i = 0; i < n; ++i) out[i] = p[i] + u[i];
+  if (versor) out[0] = v[0], out[1] = v[1], out[2] = v[2];
+}
+
 void versor_matrix(const double* v, double* R) {
   double x = v[0], y = v[1], z = v[2];
   double n2 = x * x + y * y + z * z;
-  if (n2 > 1.0) {  // keep the versor valid under additive updates
+  if (n2 > 1.0) {  // (rounding only: composed versors have unit norm)
     const double s = 1.0 / std::sqrt(n2);
     x *= s;
     y *= s;
@@ -270,7 +305,7 @@ struct level_state {
   // itk::RegistrationParameterScalesFromPhysicalShift: largest corner displacement caused by a parameter change
   double max_shift(const double* params, const double* delta) const {
     std::vector<double> p1(n);
-    for (int i = 0; i < n; ++i) p1[i] = params[i] + delta[i];
+    update_parameters(L->model, n, params, delta, p1.data());   // ScalesFromShiftBase::ComputeSampleShifts -> UpdateTransformParameters
     double A0[9], o0[3], A1[9], o1[3];
     total(params, A0, o0);
     total(p1.data(), A1, o1);
@@ -318,35 +353,36 @@ struct level_state {
   }
 };
 
-// itk::Function::WindowConvergenceMonitoringFunction: slope of a straight-line fit to the last `window` energies
-// (normalised by their total magnitude), sign flipped; "not yet" = +inf until the window is full.
+// itk::Function::WindowConvergenceMonitoringFunction::GetConvergenceValue: the last `window` energies, divided by the sum of
+// their magnitudes, at t = i / (window - 1), approximated by BSplineScatteredDataPointSetToImageFilter with spline order 1, two
+// control points and one level -- the Lee / Wolberg / Shin scattered-data update, NOT a least-squares line: with the hat weights
+// w0 = 1 - t, w1 = t of a sample, control point k = sum(w_k^3 e / (w0^2 + w1^2)) / sum(w_k^2) -- and the value is minus the
+// slope between the two control points.  The filter moves a sample on the domain's end (t = 1) inside by its B-spline epsilon
+// (1e-3 of the 0.1 spacing of its parametric grid).  "Not yet" = +inf until the window is full.  ITK 5.3 from memory.
 double window_convergence(const std::vector<double>& values, int window) {
   if ((int)values.size() < window) return INF;
   const double* e = values.data() + values.size() - window;
   double tot = 0.0;
   for (int i = 0; i < window; ++i) tot += std::fabs(e[i]);
   if (tot == 0.0) return 0.0;
-  double tbar = 0.0, ebar = 0.0;
+  double delta[2] = {0.0, 0.0}, omega[2] = {0.0, 0.0};
   for (int i = 0; i < window; ++i) {
-    tbar += (double)i / (window - 1);
-    ebar += e[i] / tot;
+    double t = (double)i / (window - 1);
+    if (std::fabs(t - 1.0) <= 1e-4) t = 1.0 - 1e-4;
+    const double w[2] = {1.0 - t, t}, w2 = w[0] * w[0] + w[1] * w[1];
+    for (int k = 0; k < 2; ++k) {
+      delta[k] += (e[i] / tot) * (w[k] * w[k] * w[k] / w2);
+      omega[k] += w[k] * w[k];
+    }
   }
-  tbar /= window;
-  ebar /= window;
-  double sxy = 0.0, sxx = 0.0;
-  for (int i = 0; i < window; ++i) {
-    const double dt = (double)i / (window - 1) - tbar;
-    sxy += dt * (e[i] / tot - ebar);
-    sxx += dt * dt;
-  }
-  return -(sxy / sxx);
+  return -(delta[1] / omega[1] - delta[0] / omega[0]);
 }
 
 // itk::GradientDescentLineSearchOptimizerv4::GoldenSectionSearch with speculative, batched probing.
 struct golden_search {
   level_state* S;
   const double* base;  // parameters at learning rate 0
-  const double* g;     // scaled gradient: params(e) = base - e g
+  const double* g;     // scaled gradient: params(e) = UpdateTransformParameters(base, -e g)
   double eps;
   int max_iter, depth;
   std::vector<double> kx, kv;  // probed learning rates and their values
@@ -389,8 +425,11 @@ struct golden_search {
     std::vector<double> plist(want.size() * (size_t)n), vals(want.size());
     for (size_t off = 0; off < want.size(); off += 16) {
       const int k = (int)std::min<size_t>(16, want.size() - off);
-      for (int c = 0; c < k; ++c)
-        for (int i = 0; i < n; ++i) plist[(size_t)c * n + i] = base[i] - want[off + c] * g[i];
+      std::vector<double> step(n);
+      for (int c = 0; c < k; ++c) {
+        for (int i = 0; i < n; ++i) step[i] = -want[off + c] * g[i];
+        update_parameters(S->L->model, n, base, step.data(), plist.data() + (size_t)c * n);
+      }
       const int rc = S->values(k, plist.data(), vals.data() + off);
       if (rc) return rc;
     }
@@ -461,9 +500,10 @@ extern "C" int pp_linear_optimize_f32(pp_ctx* ctx, const float* fixed, const int
   const int depth = level->speculation < 1 ? 1 : (level->speculation > 4 ? 4 : level->speculation);
   pp_fsamp_scope fixed_samples_scope(ctx);   // the fixed image is constant for this call: its lattice samples are evaluated once
 
-  std::vector<double> p(params, params + n), best(p), scales(n), grad(n), g(n), hist;
+  const bool return_best = (level->flags & PP_LINREG_RETURN_BEST) != 0;
+  std::vector<double> p(params, params + n), best(p), prev(p), scales(n), grad(n), g(n), step(n), hist;
   S.scales(p.data(), scales.data());
-  double learning_rate = 1.0, best_value = INF;
+  double learning_rate = 1.0, best_value = INF, last_value = INF;
   int stop = PP_LINREG_STOP_ITERATIONS, done = 0;
   for (int it = 0; it < level->iterations; ++it) {
     double value = 0.0;
@@ -472,9 +512,13 @@ extern "C" int pp_linear_optimize_f32(pp_ctx* ctx, const float* fixed, const int
     if (rc) return rc;
     if (!overlap) {
       if (it == 0) return pp_fail(ctx, PP_ERR_NO_OVERLAP, "linear registration: no valid sample points (images do not overlap)");
-      stop = PP_LINREG_STOP_NO_OVERLAP;  // stepped off the overlap: keep the best point
+      // stepped off the overlap (ITK's metric would warn, return its maximum and a zero derivative, and the optimiser would sit
+      // there): the level ends at the last point that had samples
+      stop = PP_LINREG_STOP_NO_OVERLAP;
+      p = prev;
       break;
     }
+    last_value = value;
     if (value < best_value) {
       best_value = value;
       best = p;
@@ -487,11 +531,11 @@ extern "C" int pp_linear_optimize_f32(pp_ctx* ctx, const float* fixed, const int
       break;
     }
     for (int i = 0; i < n; ++i) g[i] = grad[i] / scales[i];  // ModifyGradientByScales
-    if (it == 0) {                                         // estimateLearningRate = Once
+    if (it == 0) {                                         // estimateLearningRate = Once (per StartOptimization, i.e. per level)
       std::vector<double> neg(n);
       for (int i = 0; i < n; ++i) neg[i] = -g[i];
       const double ss = S.step_scale(p.data(), neg.data());
-      if (ss > 1e-300) learning_rate = level->v_min_spacing / ss;
+      learning_rate = ss > std::numeric_limits<double>::epsilon() ? level->v_min_spacing / ss : 1.0;
     }
     if (level->optimizer == PP_OPT_GD_LINE_SEARCH) {
       golden_search gs{&S, p.data(), g.data(), 0.01, 20, depth, {}, {}};
@@ -500,16 +544,18 @@ extern "C" int pp_linear_optimize_f32(pp_ctx* ctx, const float* fixed, const int
       if (rc) return rc;
       if (lr > 0) learning_rate = lr;
     }
-    for (int i = 0; i < n; ++i) p[i] -= learning_rate * g[i];
+    prev = p;
+    for (int i = 0; i < n; ++i) step[i] = -learning_rate * g[i];
+    update_parameters(level->model, n, prev.data(), step.data(), p.data());   // m_Metric->UpdateTransformParameters(m_Gradient)
   }
-  double last = INF;
-  {
+  double last = last_value;       // GetMetricValue(): the value of the last evaluation, one step behind the returned point
+  if (return_best) {              // SetOptimizerAsGradientDescent(..., returnBestParametersAndValue=True): best point evaluated
     const int rc = S.values(1, p.data(), &last);
     if (rc) return rc;
-  }
-  if (last > best_value) {
-    p = best;
-    last = best_value;
+    if (last > best_value) {
+      p = best;
+      last = best_value;
+    }
   }
   for (int i = 0; i < n; ++i) params[i] = p[i];
   if (stats) {

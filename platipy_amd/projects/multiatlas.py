@@ -201,13 +201,26 @@ def _hand_over(obj, stream, _seen=None):
                 _hand_over(getattr(obj, name), stream, _seen)
 
 
+# How chains that share a GPU are scheduled against each other (runtime.Turnstile).  STAGGER: one chain at a time through its
+# throughput-bound phase (finest demons level + the full-resolution resamples behind it), the others' latency-bound phases
+# underneath.  ENTRY_SLOTS: how many chains may be in their linear stage at once (0: no bound) -- chains started together are
+# thereby admitted one after the other and reach the turnstile one throughput-bound phase apart instead of all at once.
+STAGGER = True
+ENTRY_SLOTS = 1
+
+
 def _map_atlases(fn, ids, streams_per_gpu, device):
     """Run fn(atlas_id) for this rank's atlases, `streams_per_gpu` at a time.  Each worker thread runs under its own
     long-lived HIP stream, hence its own pp_ctx (runtime.context follows torch's current stream), so one atlas's
-    small coarse-level kernels overlap another's; ctypes calls release the GIL."""
+    small coarse-level kernels overlap another's; ctypes calls release the GIL.  The chains are staggered (STAGGER,
+    ENTRY_SLOTS above): results are those of the sequential run bit for bit, only the order of the device work changes."""
     if streams_per_gpu <= 1 or len(ids) <= 1 or device.type != "cuda":
         return {i: fn(i) for i in ids}
     import queue
+    import threading
+
+    turnstile = runtime.Turnstile() if STAGGER else None
+    slots = threading.Semaphore(ENTRY_SLOTS) if (STAGGER and ENTRY_SLOTS > 0) else None
 
     main = torch.cuda.current_stream(device)
     ready = torch.cuda.Event()
@@ -219,6 +232,7 @@ def _map_atlases(fn, ids, streams_per_gpu, device):
     def work(i):
         torch.cuda.set_device(device)
         s = free.get()
+        runtime.set_turnstile(turnstile, slots)
         try:
             s.wait_event(ready)
             with torch.cuda.stream(s):
@@ -227,6 +241,7 @@ def _map_atlases(fn, ids, streams_per_gpu, device):
                 done.record(s)
             return out, done
         finally:
+            runtime.set_turnstile(None)
             free.put(s)
 
     with ThreadPoolExecutor(max_workers=min(streams_per_gpu, len(ids))) as ex:
@@ -351,7 +366,8 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
             atlas_reg_image = convert_mask_to_reg_structure(orig[guide_structure_name], expansion=2)
         else:
             target_reg_image, atlas_reg_image = img_crop, orig["CT Image"]
-        _, initial_tfm = linear_registration(target_reg_image, atlas_reg_image, **lin_set)
+        with runtime.entry_slot():
+            _, initial_tfm = linear_registration(target_reg_image, atlas_reg_image, **lin_set)
         cur = {"Transform": initial_tfm,
                "CT Image": apply_transform(orig["CT Image"], img_crop, initial_tfm, -1000, sitkLinear)}
         for s in atlas_structure_list:

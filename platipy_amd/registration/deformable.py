@@ -14,6 +14,7 @@ Deviations, all deliberate and visible:
     one direction, so this is the same computation -- and the field is rotated back to physical (LPS)
     components at the end.  (ITK's behaviour for this case could not be checked: parity unpinned.)
 """
+import contextlib
 import weakref
 
 import numpy as np
@@ -235,9 +236,16 @@ def _zero_field(reference):
 
 def multiscale_demons(registration_algorithm, fixed_image, moving_image, initial_transform=None,
                       initial_displacement_field=None, isotropic_resample=None, resolution_staging=None,
-                      smoothing_sigmas=None, iteration_staging=None, interp_order=sitkLinear):
+                      smoothing_sigmas=None, iteration_staging=None, interp_order=sitkLinear, _exclusive=None):
     """Run `registration_algorithm` coarse-to-fine (reference deformable.py:31-187).  Any object with
-    SetNumberOfIterations / Execute(fixed, moving) -> vector Image / GetStandardDeviations works."""
+    SetNumberOfIterations / Execute(fixed, moving) -> vector Image / GetStandardDeviations works.
+    `_exclusive`: a contextlib.ExitStack of the caller's that receives runtime.exclusive() when the first throughput-bound
+    level begins (several atlas chains on one GPU: runtime.Turnstile), so that the caller's own full-resolution work after this
+    function stays inside the same section; without one the section ends with this function."""
+    if _exclusive is None:
+        with contextlib.ExitStack() as stack:
+            return multiscale_demons(registration_algorithm, fixed_image, moving_image, initial_transform, initial_displacement_field,
+                                     isotropic_resample, resolution_staging, smoothing_sigmas, iteration_staging, interp_order, stack)
     fixed_image, moving_image = as_image(fixed_image), as_image(moving_image)
     if fixed_image.direction != _IDENTITY:
         # a direct call with oriented images (fast_symmetric_forces_demons_registration converts before it calls): the loop
@@ -248,7 +256,7 @@ def multiscale_demons(registration_algorithm, fixed_image, moving_image, initial
         true_direction = fixed_image.direction
         f_l, m_l, d_l = _local_frame(fixed_image, moving_image, initial_displacement_field)
         out = multiscale_demons(registration_algorithm, f_l, m_l, None, d_l, isotropic_resample, resolution_staging,
-                                smoothing_sigmas, iteration_staging, interp_order)
+                                smoothing_sigmas, iteration_staging, interp_order, _exclusive)
         return Image(_rotate_field(out.tensor, true_direction), out.spacing, out.origin, true_direction, True)
     ctx = runtime.context(fixed_image.device)
     fixed_images, moving_images = [], []
@@ -273,8 +281,12 @@ def multiscale_demons(registration_algorithm, fixed_image, moving_image, initial
     else:
         dvf_total = resample_field(as_image(initial_displacement_field), fixed_image)
 
+    in_section = False
     for i in range(len(fixed_images)):
         f_image, m_image = fixed_images[i], moving_images[i]
+        if not in_section and f_image.tensor.numel() >= runtime.HEAVY_VOXELS:
+            _exclusive.enter_context(runtime.exclusive(f_image.device))      # (a no-op outside the multi-atlas worker threads)
+            in_section = True
         if dvf_total is None:
             dvf_total = _zero_field(f_image)       # (not 800 MB of zeros at full resolution resampled onto the coarsest grid)
         else:
@@ -352,14 +364,15 @@ def fast_symmetric_forces_demons_registration(
             lowest = float(mt.min())
         default_value = -1000 if lowest <= -1000 else 0
 
-    deformation_field = multiscale_demons(
-        registration_algorithm=registration_method, fixed_image=fixed_image, moving_image=moving_image,
-        resolution_staging=resolution_staging, smoothing_sigmas=smoothing_sigmas, iteration_staging=iteration_staging,
-        isotropic_resample=isotropic_resample, initial_displacement_field=initial_displacement_field,
-        interp_order=interp_order)
+    with contextlib.ExitStack() as section:      # (runtime.exclusive from the first throughput-bound level to the final warp)
+        deformation_field = multiscale_demons(
+            registration_algorithm=registration_method, fixed_image=fixed_image, moving_image=moving_image,
+            resolution_staging=resolution_staging, smoothing_sigmas=smoothing_sigmas, iteration_staging=iteration_staging,
+            isotropic_resample=isotropic_resample, initial_displacement_field=initial_displacement_field,
+            interp_order=interp_order, _exclusive=section)
 
-    output_transform = DisplacementFieldTransform(deformation_field)
-    registered_image = resample_image(moving_image, fixed_image, output_transform, interp_order, default_value)
+        output_transform = DisplacementFieldTransform(deformation_field)
+        registered_image = resample_image(moving_image, fixed_image, output_transform, interp_order, default_value)
     registered_image = registered_image.like(cast_tensor(registered_image.tensor, moving_image_type))
     if true_direction != identity:
         phys = _rotate_field(deformation_field.tensor, true_direction)

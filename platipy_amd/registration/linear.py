@@ -7,18 +7,23 @@ physical-shift parameter scales, learning-rate estimation, gradient descent with
 convergence test, optional golden-section line search, L-BFGS-B -- is host arithmetic on <= 12
 parameters, as it is in ITK.
 
-Deliberate, visible deviations from ITK (SURVEY 7 "hard parts": bit parity of the optimiser
-trajectory is not a goal for this stage; it is judged by final metric / transform / Dice):
-  * REGULAR sampling takes every ceil(1/rate)-th voxel of the shrunk fixed grid like ITK; ITK's seeded sub-voxel
-    jitter of the sample points is OFF by default and switched on by `itk_sampling=True` (ItkRegularJitter below:
-    the Mersenne-Twister stream of SetMetricSamplingPercentage(rate, seed=42), pp_linear_set_sample_jitter);
-  * the moving-image gradient is the analytic gradient of the trilinear interpolant, not ITK's
-    Gaussian-derivative-filtered gradient image (with or without the flag);
-  * versor parameters are updated additively and re-normalised;
-  * each level returns the best parameters it visited (ITK's returnBestParametersAndValue=True; SimpleITK's
-    default is False).  ITK re-estimates the learning rate at the start of every level so that the first step
-    moves the volume corners by one voxel; when the previous level already converged that first step overshoots,
-    and keeping the best visited point makes the result insensitive to it;
+ITK semantics kept (round 6: they are the DEFAULTS; each was an opt-in or a deviation before):
+  * REGULAR sampling takes every ceil(1/rate)-th voxel of the shrunk fixed grid and moves each sample point by ITK's seeded
+    sub-voxel jitter (ItkRegularJitter below: the Mersenne-Twister stream of SetMetricSamplingPercentage(rate, seed=42),
+    pp_linear_set_sample_jitter); `itk_sampling=False` turns the jitter off (samples on the lattice);
+  * the moving-image gradient is ITK's filtered gradient image (GradientRecursiveGaussianImageFilter, sigma = the moving
+    image's largest spacing, linearly interpolated at the mapped point: ImageToImageMetricv4's default); with
+    `itk_sampling=False` it is the analytic gradient of the trilinear interpolant;
+  * every step, line-search probe and scale estimate goes through the transform's UpdateTransformParameters: the versor family
+    (rigid, similarity, scale-versor, scale-skew-versor) COMPOSES an axis-angle rotation onto its versor, all other
+    parameters are added (transform._versor_update);
+  * each level ends at its LAST point (SimpleITK leaves returnBestParametersAndValue off); `return_best_parameters=True` is
+    SetOptimizerAs...(returnBestParametersAndValue=True);
+  * the learning rate is estimated once per level from m_MaximumStepSizeInPhysicalUnits, which ITK assigns ONCE per optimiser
+    -- the smallest virtual spacing of the FIRST level -- and the convergence value is ITK's two-control-point B-spline
+    approximation of the energy window, not a least-squares slope (_window_convergence).
+Remaining deliberate deviations:
+  * a step that leaves the overlap ends the level at the previous point (ITK's metric would warn and return its maximum);
   * all four metrics of the reference run on the GPU: "mean_squares", "correlation", "mattes_mi" (50 bins, fixed
     zero-order / moving cubic-B-spline Parzen windows as itk::MattesMutualInformationImageToImageMetricv4; joint
     histogram in 64-bit fixed point, so results do not depend on scheduling) and "joint_hist_mi" (20 bins, joint PDF
@@ -31,6 +36,7 @@ trajectory is not a goal for this stage; it is judged by final metric / transfor
     instead of running for days (the reference itself says "use is not currently recommended").
 """
 import os
+import threading
 
 import numpy as np
 import torch
@@ -278,7 +284,7 @@ class _MeanSquares:
     # -- itk::RegistrationParameterScalesFromPhysicalShift over the 8 corners ------------
     def max_shift(self, model, params, delta):
         A0, o0 = self.total(model, params)
-        A1, o1 = self.total(model, np.asarray(params) + delta)
+        A1, o1 = self.total(model, model.update(params, delta))     # ScalesFromShiftBase::ComputeSampleShifts -> UpdateTransformParameters
         d = (self.corners @ (A1 - A0).T) + (o1 - o0)[None, :]
         return float(np.sqrt((d ** 2).sum(1)).max())
 
@@ -303,8 +309,12 @@ class _MeanSquares:
 
 
 def _window_convergence(values, window):
-    """itk::Function::WindowConvergenceMonitoringFunction: slope of a straight-line fit to the last `window`
-    energies, normalised by their total magnitude; returns a large number until the window is full."""
+    """itk::Function::WindowConvergenceMonitoringFunction::GetConvergenceValue: the last `window` energies, divided by the
+    sum of their magnitudes, at t = i / (window - 1), approximated by BSplineScatteredDataPointSetToImageFilter (spline order
+    1, two control points, one level).  That filter is the Lee / Wolberg / Shin scattered-data update, not a least-squares
+    fit: with the hat weights w0 = 1 - t, w1 = t of a sample, control point k = sum(w_k^3 e / (w0^2 + w1^2)) / sum(w_k^2);
+    the convergence value is minus the slope between the two control points.  A sample on the end of the parametric domain
+    is moved inside by the filter's epsilon (1e-3 of its 0.1 grid spacing).  +inf until the window is full."""
     if len(values) < window:
         return float("inf")
     e = np.asarray(values[-window:], dtype=np.float64)
@@ -312,9 +322,11 @@ def _window_convergence(values, window):
     if tot == 0.0:
         return 0.0
     e = e / tot
-    t = np.linspace(0.0, 1.0, window)
-    slope = np.polyfit(t, e, 1)[0]
-    return -float(slope)
+    t = np.arange(window, dtype=np.float64) / (window - 1)
+    t = np.where(np.abs(t - 1.0) <= 1e-4, 1.0 - 1e-4, t)
+    w = np.stack([1.0 - t, t])
+    lattice = (e[None, :] * w ** 3 / (w ** 2).sum(0)[None, :]).sum(1) / (w ** 2).sum(1)
+    return -float(lattice[1] - lattice[0])
 
 
 # The gradient-descent optimisers run inside the library (pp_linear.hip: one call per level, no interpreter between
@@ -325,9 +337,9 @@ _NATIVE_MODEL = {TranslationTransform: 0, VersorRigid3DTransform: 1, Similarity3
                  FullAffineTransform: 4, Euler3DTransform: 5, ScaleVersor3DTransform: 6, ScaleSkewVersor3DTransform: 7}
 
 
-def _optimise_level_native(ctx, ms, model, params, opt, number_of_iterations, verbose):
+def _optimise_level_native(ctx, ms, model, params, opt, number_of_iterations, verbose, max_step, return_best, record):
     """pp_linear_optimize_f32 on the level described by `ms`."""
-    from .._lib import ERR_NO_OVERLAP, LinregLevel, PlatipyAmdError
+    from .._lib import ERR_NO_OVERLAP, LINREG_RETURN_BEST, LinregLevel, PlatipyAmdError
 
     lv = LinregLevel()
     lv.model = _NATIVE_MODEL[type(model)]
@@ -346,10 +358,11 @@ def _optimise_level_native(ctx, ms, model, params, opt, number_of_iterations, ve
     lv.init_matrix[:] = np.asarray(ms.Ai, dtype=np.float64).ravel().tolist()
     lv.init_offset[:] = np.asarray(ms.oi, dtype=np.float64).tolist()
     lv.center[:] = np.asarray(model.center, dtype=np.float64).tolist()
-    lv.v_min_spacing = ms.min_spacing
+    lv.v_min_spacing = float(max_step)
+    lv.flags = LINREG_RETURN_BEST if return_best else 0
     try:
         out, stats, history = ctx.linear_optimize(ms.ft, ms.fixed.GetSize(), ms.mt, ms.moving.GetSize(), lv, params, ms.fmask, ms.mmask,
-                                                  history=number_of_iterations if verbose else 0)
+                                                  history=number_of_iterations if (verbose or record is not None) else 0)
     except PlatipyAmdError as e:
         if getattr(e, "code", 0) == ERR_NO_OVERLAP:
             raise RuntimeError("linear_registration: no valid sample points (images do not overlap)") from e
@@ -358,6 +371,9 @@ def _optimise_level_native(ctx, ms, model, params, opt, number_of_iterations, ve
     if verbose:
         for it, value in enumerate(history):
             print("{0:3} = {1:10.5f}".format(it, value))
+    if record is not None:
+        record.append({"values": list(history), "iterations": int(stats.iterations), "stop": int(stats.stop),
+                       "learning_rate": float(stats.learning_rate), "parameters": [float(v) for v in out]})
     return np.asarray(out, dtype=np.float64)
 
 
@@ -481,19 +497,23 @@ def linear_registration(
     exhaustive_steps=None,
     exhaustive_step_length=1.0,
     exhaustive_max_evaluations=None,
-    itk_sampling=False,
+    itk_sampling=True,
     sampling_seed=42,
+    return_best_parameters=False,
 ):
     """Initial linear registration between two images (reference registration/linear.py:50-260).
 
     Returns (registered_image, CompositeTransform([initial_centering_transform, optimised_transform])).
 
-    `itk_sampling=True` (extension, default off) switches the two declared metric deviations off: (i) the REGULAR sample points
-    carry ITK's seeded sub-voxel jitter -- registration.SetMetricSamplingPercentage(sampling_rate, seed=42), linear.py:151 --
-    drawn from one Mersenne-Twister stream over the levels (`sampling_seed`, the reference's 42); (ii) the moving-image gradient
-    is the linear interpolation of ITK's filtered gradient image (GradientRecursiveGaussianImageFilter with sigma = the moving
-    image's largest spacing, NormalizeAcrossScale, once per level: ImageToImageMetricv4's default) instead of the derivative
-    of the intensity interpolant.  For every metric and optimiser.
+    `itk_sampling` (default True = the reference's semantics; False is the opt-out that samples on the lattice): (i) the REGULAR
+    sample points carry ITK's seeded sub-voxel jitter -- registration.SetMetricSamplingPercentage(sampling_rate, seed=42),
+    linear.py:151 -- drawn from one Mersenne-Twister stream over the levels (`sampling_seed`, the reference's 42); (ii) the
+    moving-image gradient is the linear interpolation of ITK's filtered gradient image (GradientRecursiveGaussianImageFilter
+    with sigma = the moving image's largest spacing, NormalizeAcrossScale, once per level: ImageToImageMetricv4's default)
+    instead of the derivative of the intensity interpolant.  For every metric and optimiser.  `return_best_parameters` is
+    SetOptimizerAsGradientDescent[LineSearch](..., returnBestParametersAndValue): SimpleITK's default False returns each
+    level's last point.  After the call `linear_registration.last_levels` holds, per level, the optimiser's record
+    (metric value per iteration, iterations taken, stop reason, learning rate, parameters) of the gradient-descent optimisers.
 
     The last three arguments are extensions for optimiser="exhaustive" (the reference hard-codes numberOfSteps = [10] * 6 at
     linear.py:221, 21^6 = 85.8 M evaluations on a six-parameter model, and says itself that "use is not currently
@@ -534,14 +554,16 @@ def linear_registration(
     fixed_mask = as_image(fixed_structure) if fixed_structure is not None else None
     moving_mask = as_image(moving_structure) if moving_structure is not None else None
     params = np.asarray(model.GetParameters(), dtype=np.float64)
+    record = []
     if not itk_sampling:
         params = _optimise_levels(ctx, None, **_level_args(locals()))
     else:
         try:
-            params = _optimise_levels(ctx, ItkRegularJitter(sampling_seed), **_level_args(locals()))
+            params = _optimise_levels(ctx, _JitterSource(sampling_seed, fixed_image.device), **_level_args(locals()))
         finally:
             ctx.set_sample_jitter(None)
             ctx.set_moving_gradient(None)
+    linear_registration.last_levels = record
 
     model.SetParameters(params)
     output_transform = model
@@ -584,6 +606,47 @@ class ItkRegularJitter:
         return np.ascontiguousarray((phys @ p2i.T).astype(np.float32))
 
 
+_JITTER_CACHE = {}      # (device, seed, levels so far) -> device tensor; a handful of entries, oldest dropped first
+_JITTER_CACHE_MAX = 16
+_JITTER_LOCK = threading.Lock()
+
+
+def release_cached_jitter():
+    """Called by runtime.release_all()."""
+    with _JITTER_LOCK:
+        _JITTER_CACHE.clear()
+
+
+class _JitterSource:
+    """ItkRegularJitter's levels as DEVICE tensors, remembered across registrations: the stream depends only on the seed and on
+    the sequence of (virtual size, stride, spacing, direction) of the levels drawn so far, and a multi-atlas run registers every
+    atlas onto the same target grid with the same seed -- 1.5 M Mersenne-Twister draws per registration otherwise."""
+
+    def __init__(self, seed, device):
+        self.seed, self.device, self.history, self._gen, self._drawn = int(seed), device, (), None, 0
+
+    def level(self, vsize, stride, vspacing, vdir):
+        here = (tuple(int(v) for v in vsize), int(stride), tuple(float(v) for v in vspacing), tuple(float(v) for v in np.ravel(vdir)))
+        self.history = self.history + (here,)
+        key = (str(self.device), self.seed, self.history)
+        with _JITTER_LOCK:
+            hit = _JITTER_CACHE.get(key)
+        if hit is not None:
+            return hit
+        if self._gen is None:
+            self._gen = ItkRegularJitter(self.seed)
+        while self._drawn < len(self.history) - 1:      # levels served from the cache: their variates still have to be consumed
+            self._gen.level(*self.history[self._drawn][:3], np.asarray(self.history[self._drawn][3]).reshape(3, 3))
+            self._drawn += 1
+        t = torch.from_numpy(self._gen.level(vsize, stride, vspacing, vdir)).to(self.device)
+        self._drawn += 1
+        with _JITTER_LOCK:
+            while len(_JITTER_CACHE) >= _JITTER_CACHE_MAX:
+                _JITTER_CACHE.pop(next(iter(_JITTER_CACHE)))
+            _JITTER_CACHE[key] = t
+        return t
+
+
 def itk_moving_gradient(ctx, moving):
     """ImageToImageMetricv4's default moving-image gradient source, in moving-INDEX units [3, Z, Y, X] float32:
     itk::GradientRecursiveGaussianImageFilter(sigma = largest spacing, NormalizeAcrossScale, UseImageDirection) -- per component
@@ -614,14 +677,16 @@ def itk_moving_gradient(ctx, moving):
 def _level_args(scope):
     keys = ("fixed_image", "moving_image", "fixed_mask", "moving_mask", "initial_transform", "model", "params", "metric", "opt",
             "shrink_factors", "smooth_sigmas", "sampling_rate", "number_of_iterations", "verbose", "exhaustive_steps",
-            "exhaustive_step_length", "exhaustive_max_evaluations")
+            "exhaustive_step_length", "exhaustive_max_evaluations", "return_best_parameters", "record")
     return {k: scope[k] for k in keys}
 
 
 def _optimise_levels(ctx, jitter, fixed_image, moving_image, fixed_mask, moving_mask, initial_transform, model, params, metric, opt,
                      shrink_factors, smooth_sigmas, sampling_rate, number_of_iterations, verbose, exhaustive_steps,
-                     exhaustive_step_length, exhaustive_max_evaluations):
+                     exhaustive_step_length, exhaustive_max_evaluations, return_best_parameters=False, record=None):
     """The resolution levels of linear_registration (ImageRegistrationMethodv4's level loop) -> optimised parameters."""
+    max_step = None     # GradientDescentOptimizerBasev4::m_MaximumStepSizeInPhysicalUnits: assigned at the first StartOptimization
+    gradient_of = {}    # id(level's moving tensor) -> its filtered gradient image (levels without smoothing share the image)
     for level, (shrink, sigma) in enumerate(zip(shrink_factors, smooth_sigmas)):
         # ImageRegistrationMethodv4::InitializeRegistrationAtEachLevel: smooth both (physical sigma), shrink the virtual domain
         f_l = discrete_gaussian(fixed_image, sigma * sigma) if sigma > 0 else fixed_image
@@ -629,9 +694,17 @@ def _optimise_levels(ctx, jitter, fixed_image, moving_image, fixed_mask, moving_
         vsize, vspacing, vorigin, vdir = _shrink_geometry(fixed_image, shrink)
         ms = _MeanSquares(ctx, f_l, m_l, vsize, vspacing, vorigin, vdir, initial_transform, sampling_rate, fixed_mask, moving_mask,
                           metric=metric)
+        if max_step is None:
+            max_step = ms.min_spacing
         if jitter is not None:      # this level's perturbed sample points, for every metric kernel until the next level replaces them
-            ctx.set_sample_jitter(torch.from_numpy(jitter.level(ms.vsize, ms.stride, vspacing, vdir)).to(fixed_image.device))
-            ctx.set_moving_gradient(itk_moving_gradient(ctx, m_l))      # ... and this level's filtered gradient image
+            ctx.set_sample_jitter(jitter.level(ms.vsize, ms.stride, vspacing, vdir))
+            # ... and this level's filtered gradient image (ITK filters per level; levels that share the moving image -- no
+            # smoothing sigma -- share the result, which is the same numbers)
+            key = id(m_l.tensor)
+            if key not in gradient_of:
+                gradient_of.clear()
+                gradient_of[key] = (m_l.tensor, itk_moving_gradient(ctx, m_l))     # (the image is kept: its id stays its own)
+            ctx.set_moving_gradient(gradient_of[key][1])
 
         if opt == "lbfgsb":
             from scipy.optimize import fmin_l_bfgs_b
@@ -658,46 +731,54 @@ def _optimise_levels(ctx, jitter, fixed_image, moving_image, fixed_mask, moving_
             continue
 
         if NATIVE_OPTIMISER and type(model) in _NATIVE_MODEL and ms.bins is None:
-            params = _optimise_level_native(ctx, ms, model, params, opt, number_of_iterations, verbose)
+            params = _optimise_level_native(ctx, ms, model, params, opt, number_of_iterations, verbose, max_step, return_best_parameters,
+                                            record)
             continue
 
         scales = ms.scales(model, params)
         learning_rate = 1.0
         history = []
         best_value, best_params = float("inf"), params.copy()
+        previous, stop = params.copy(), 0
         for it in range(number_of_iterations):
             try:
                 value, grad = ms.value_and_gradient(model, params)
             except RuntimeError:
                 if it == 0:
                     raise
-                break                                           # stepped off the overlap: keep the best point
+                params, stop = previous, 2                      # stepped off the overlap: the level ends at the last point with samples
+                break
             if value < best_value:
                 best_value, best_params = value, params.copy()
             history.append(value)
             if verbose:
                 print("{0:3} = {1:10.5f}".format(it, value))
             if _window_convergence(history, 10) <= 1e-6:
+                stop = 1
                 break
             g = grad / scales                                   # ModifyGradientByScales
-            if it == 0:                                         # estimateLearningRate = Once
+            if it == 0:                                         # estimateLearningRate = Once (per StartOptimization: per level)
                 ss = ms.step_scale(model, params, -g)
-                if ss > 1e-300:
-                    learning_rate = ms.min_spacing / ss
+                learning_rate = max_step / ss if ss > np.finfo(np.float64).eps else 1.0
             if opt == "gradient_descent_line_search":
                 base = params.copy()
 
                 def trial(es):
-                    return ms.values(model, [base - e * g for e in es])
+                    return ms.values(model, [model.update(base, -e * g) for e in es])
 
                 lr = _golden_section(trial, 0.0, learning_rate, 5.0 * learning_rate)
                 learning_rate = lr if lr > 0 else learning_rate
-            params = params - learning_rate * g
-        try:
-            last = ms.value(model, params)
-        except RuntimeError:
-            last = float("inf")
-        if last > best_value:
-            params = best_params
+            previous = params
+            params = model.update(params, -learning_rate * g)   # m_Metric->UpdateTransformParameters(m_Gradient)
+        if return_best_parameters:
+            try:
+                last = ms.value(model, params)
+            except RuntimeError:
+                last = float("inf")
+            if last > best_value:
+                params = best_params
+        if record is not None:
+            record.append({"values": list(history), "iterations": len(history), "stop": stop, "learning_rate": float(learning_rate),
+                           "parameters": [float(v) for v in params]})
 
     return params

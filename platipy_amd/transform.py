@@ -88,10 +88,36 @@ class CompositeTransform(Transform):
 # registration/linear.py:166-181).  All are MatrixOffsetTransformBase: q = A (p - c) + c + t.
 
 
+def _versor_update(p, update):
+    """itk::VersorRigid3DTransform::UpdateTransformParameters (inherited by Similarity3D, ScaleVersor3D and ScaleSkewVersor3D):
+    the first three entries of `update` are an AXIS-ANGLE rotation -- axis update[:3], angle |update[:3]| radians -- composed
+    onto the current rotation on the right (new = current * gradientRotation, Hamilton product); every other parameter is
+    added.  A zero update leaves the versor as it is."""
+    p = np.asarray(p, dtype=np.float64)
+    update = np.asarray(update, dtype=np.float64)
+    out = p + update
+    x, y, z = p[0], p[1], p[2]
+    w = np.sqrt(max(0.0, 1.0 - (x * x + y * y + z * z)))
+    norm = float(np.sqrt(update[0] * update[0] + update[1] * update[1] + update[2] * update[2]))
+    if norm > 0.0:
+        f = np.sin(norm / 2.0) / norm
+        gx, gy, gz, gw = update[0] * f, update[1] * f, update[2] * f, np.cos(norm / 2.0)
+    else:
+        gx, gy, gz, gw = 0.0, 0.0, 0.0, 1.0
+    nx = w * gx - z * gy + y * gz + x * gw
+    ny = z * gx + w * gy - x * gz + y * gw
+    nz = -y * gx + x * gy + w * gz + z * gw
+    nw = -x * gx - y * gy - z * gz + w * gw
+    if nw < 0.0:      # (itk::Versor keeps w >= 0 implicitly: only the right part is stored and w = +sqrt(1 - |v|^2))
+        nx, ny, nz = -nx, -ny, -nz
+    out[0], out[1], out[2] = nx, ny, nz
+    return out
+
+
 def _versor_matrix(v):
     x, y, z = (float(a) for a in v)
     n2 = x * x + y * y + z * z
-    if n2 > 1.0:  # keep the versor valid under additive updates
+    if n2 > 1.0:  # (rounding only: composed versors have unit norm)
         s = 1.0 / np.sqrt(n2)
         x, y, z = x * s, y * s, z * s
         n2 = 1.0
@@ -127,6 +153,11 @@ class _Parametrised(AffineTransform):
     def GetNumberOfParameters(self):
         return self.n_params
 
+    def update(self, params, update):
+        """itk::Transform::UpdateTransformParameters(update, factor = 1) on a parameter vector: params + update, except
+        where a transform class overrides it (the versor family composes its rotation, _versor_update)."""
+        return np.asarray(params, dtype=np.float64) + np.asarray(update, dtype=np.float64)
+
     def SetCenter(self, c):
         self.center = np.asarray(c, dtype=np.float64).reshape(3)
 
@@ -151,6 +182,8 @@ class VersorRigid3DTransform(_Parametrised):
     def decode(self, p):
         return _versor_matrix(p[:3]), np.asarray(p[3:6], dtype=np.float64).copy()
 
+    update = staticmethod(_versor_update)
+
 
 class Similarity3DTransform(_Parametrised):
     """parameters: versor (x, y, z), translation (3), isotropic scale"""
@@ -161,6 +194,8 @@ class Similarity3DTransform(_Parametrised):
 
     def decode(self, p):
         return float(p[6]) * _versor_matrix(p[:3]), np.asarray(p[3:6], dtype=np.float64).copy()
+
+    update = staticmethod(_versor_update)
 
 
 class ScaleVersor3DTransform(_Parametrised):
@@ -178,6 +213,8 @@ class ScaleVersor3DTransform(_Parametrised):
         A[1, 1] += float(p[7]) - 1.0
         A[2, 2] += float(p[8]) - 1.0
         return A, np.asarray(p[3:6], dtype=np.float64).copy()
+
+    update = staticmethod(_versor_update)
 
 
 class ScaleSkewVersor3DTransform(_Parametrised):
@@ -205,6 +242,8 @@ class ScaleSkewVersor3DTransform(_Parametrised):
         A[1, 0] += float(p[11]); A[1, 2] += float(p[12])
         A[2, 0] += float(p[13]); A[2, 1] += float(p[14])
         return A, np.asarray(p[3:6], dtype=np.float64).copy()
+
+    update = staticmethod(_versor_update)
 
 
 class ScaleTransform(_Parametrised):

@@ -1,6 +1,7 @@
-"""linear_registration: the metric kernel against a numpy restatement and finite differences, then the
-whole optimisation by what it achieves (metric, recovered transform, Dice) -- SURVEY 7: bit parity of ITK's
-optimiser trajectory is not a goal for this stage."""
+"""linear_registration: the metric kernels against a numpy restatement and finite differences, then the
+whole optimisation by what it achieves (metric, recovered transform, Dice).  The trajectory itself -- metric value per
+iteration, iterations per level, parameters -- is held against the independent fp64 restatement of ITK's registration method in
+tests/test_linear_oracle.py (round 6)."""
 import numpy as np
 import pytest
 
@@ -246,9 +247,14 @@ def test_linear_registration_recovers_known_transform(host_api, method, optimise
     shape, spacing, origin = (24, 40, 48), (1.5, 1.5, 2.5), (-30.0, -20.0, 10.0)
     fix, mov, (R, t, c) = _rigid_pair(pa, shape, spacing, origin)
     before = float(((fix - mov) ** 2).mean())
+    # Plain gradient descent with ITK's once-per-level learning rate (the first step of a level moves the volume corners by one
+    # voxel of the FIRST level, whatever the gradient's size) leaves the optimum again at every level that starts converged on
+    # this noise-free pair -- ITK's behaviour, tests/test_linear_oracle.py -- so that case asks for ITK's
+    # returnBestParametersAndValue; the line searches bracket their step and need no such help.
+    extra = {"return_best_parameters": True} if optimiser == "gradient_descent" else {}
     img, tfm = pa.registration.linear_registration(
         pa.image_from_array(fix, spacing, origin), pa.image_from_array(mov, spacing, origin), reg_method=method,
-        optimiser=optimiser, shrink_factors=[4, 2, 1], smooth_sigmas=[2, 1, 0], sampling_rate=0.5, number_of_iterations=40)
+        optimiser=optimiser, shrink_factors=[4, 2, 1], smooth_sigmas=[2, 1, 0], sampling_rate=0.5, number_of_iterations=40, **extra)
     assert isinstance(tfm, pa.CompositeTransform) and len(tfm.transforms) == 2
     after = float(((fix - img.numpy()) ** 2).mean())
     if method == "translation":
@@ -264,8 +270,9 @@ def test_linear_registration_recovers_known_transform(host_api, method, optimise
     got = corners @ A.T + off
     want = (corners - c) @ R.T + c + t
     # 12-parameter gradient descent converges slowly along the shear/scale directions: the volume corners land
-    # within 3 mm after 3 x 40 iterations; the 6/7-parameter models within 1 mm
-    assert np.abs(got - want).max() < (3.0 if method == "affine" else 1.0), np.abs(got - want).max()
+    # within 3 mm after 3 x 40 iterations; the 6/7-parameter models within 1.5 mm (each level's LAST point, as SimpleITK
+    # returns it: 1.2 mm here; the best visited point would be within 1 mm)
+    assert np.abs(got - want).max() < (3.0 if method == "affine" else 1.5), np.abs(got - want).max()
 
 
 def test_linear_registration_correlation_metric(host_api):
@@ -482,8 +489,10 @@ def test_exhaustive_optimiser_walks_the_grid(host_api):
     A, off = tfm.matrix_offset()
     np.testing.assert_allclose(A, np.eye(3), atol=1e-12)
     np.testing.assert_allclose(off, [1.0, -2.0, 0.0], atol=1e-9)
+    # (samples on the lattice: the grid's rotation steps are +-1 x the physical-shift scale, i.e. half turns that leave a few
+    # background samples in the overlap with a difference of exactly 0 -- only the exact shift on lattice samples ties with that)
     _, tfm6 = pa.registration.linear_registration(f, m, reg_method="rigid", optimiser="exhaustive", shrink_factors=[2], smooth_sigmas=[0],
-                                                  sampling_rate=1.0, exhaustive_steps=[1, 1, 1, 2, 2, 2])     # 27 * 125 grid points
+                                                  sampling_rate=1.0, exhaustive_steps=[1, 1, 1, 2, 2, 2], itk_sampling=False)     # 27 * 125 grid points
     assert np.linalg.norm(np.asarray(tfm6.matrix_offset()[1]) - [1.0, -2.0, 0.0]) < 1.5
 
 
@@ -630,9 +639,10 @@ def test_metric_kernels_with_sample_jitter_match_the_oracle(backend):
 
 
 def test_linear_registration_with_itk_sampling(host_api):
-    """itk_sampling=True: the registration still recovers the known rigid motion (sub-voxel jitter of the sample points does
-    not change where the optimum is), its result differs from the lattice run's (the flag does something), it is
-    reproducible (seeded), and the context's jitter is gone afterwards."""
+    """itk_sampling=True (the default since round 6): the registration recovers the known rigid motion (sub-voxel jitter of the
+    sample points does not change where the optimum is), its result differs from the lattice run's (itk_sampling=False does
+    something), it is reproducible (seeded, and the jitter arrays are cached across calls), and the context's jitter is gone
+    afterwards."""
     pa = host_api
     from platipy_amd import runtime
 
@@ -641,8 +651,8 @@ def test_linear_registration_with_itk_sampling(host_api):
     kw = dict(reg_method="rigid", optimiser="gradient_descent_line_search", shrink_factors=[4, 2], smooth_sigmas=[2, 1],
               sampling_rate=0.5, number_of_iterations=30)
     fi, mi = pa.image_from_array(fix, spacing, origin), pa.image_from_array(mov, spacing, origin)
-    _, t0 = pa.registration.linear_registration(fi, mi, **kw)
-    img, t1 = pa.registration.linear_registration(fi, mi, itk_sampling=True, **kw)
+    _, t0 = pa.registration.linear_registration(fi, mi, itk_sampling=False, **kw)
+    img, t1 = pa.registration.linear_registration(fi, mi, **kw)
     _, t2 = pa.registration.linear_registration(fi, mi, itk_sampling=True, **kw)
     assert getattr(runtime.context(fi.device), "_sample_jitter", None) is None
     A0, o0 = t0.matrix_offset()

@@ -1,0 +1,172 @@
+"""linear_registration against an INDEPENDENT fp64 restatement of what the reference's call configures.
+
+platipy/imaging/registration/linear.py:133-238 hands the optimisation to sitk.ImageRegistrationMethod: ITK's
+ImageRegistrationMethodv4 level loop, MeanSquaresImageToImageMetricv4 on seeded REGULAR samples, parameter scales from
+physical shift, GradientDescentOptimizerv4 / GradientDescentLineSearchOptimizerv4, window convergence monitoring.
+oracle/linear_oracle.py::registration restates that chain in fp64 numpy -- physical-space metric, analytic transform Jacobians,
+sequential golden section, ITK's versor composition -- and shares no code with platipy_amd/registration/linear.py (index-space
+maps, central differences of the index map, batched speculative probes) or csrc/pp_linear.hip.  The product is held to it at
+the level of the TRAJECTORY: iterations per level, stop reason, metric value at every iteration, each level's parameters, where
+the final map sends the volume's corners, and the count of voxels by which a mask propagated through the two results differs.
+
+The oracle is parity-unpinned (ITK 5.3 from memory: DESIGN section 3, recollections 9 and 13-15); these tests show that the
+product and an independent reading of ITK agree, not that either equals SimpleITK.
+
+`emu` runs (CPU suite): the host logic (Python optimiser loop) on the oracle's own index-space metric stand-in
+(tests/helpers.py::install_emu_runtime); `gpu` runs: the product as shipped -- fp32 metric kernels, native optimiser."""
+import numpy as np
+import pytest
+
+from oracle import linear_oracle as LO
+from oracle import oracle as O
+from tests.helpers import phantom, record_stats
+from tests.test_linear import _rigid_pair
+
+SHAPE, SPACING, ORIGIN = (24, 40, 48), (1.5, 1.5, 2.5), (-30.0, -20.0, 10.0)
+
+
+def _corners():
+    n = np.array(SHAPE[::-1], dtype=np.float64) - 1
+    return np.array([[i, j, k] for i in (0, n[0]) for j in (0, n[1]) for k in (0, n[2])]) * np.array(SPACING) + np.array(ORIGIN)
+
+
+def _compare(pa, fix, mov, method, optimiser, kw, label):
+    fi, mi = pa.image_from_array(fix, SPACING, ORIGIN), pa.image_from_array(mov, SPACING, ORIGIN)
+    _, tfm = pa.registration.linear_registration(fi, mi, reg_method=method, optimiser=optimiser, **kw)
+    got_levels = [dict(l) for l in pa.registration.linear_registration.last_levels]
+    want = LO.registration(O.Vol(fix, SPACING, ORIGIN), O.Vol(mov, SPACING, ORIGIN), method, optimiser, kw["shrink_factors"], kw["smooth_sigmas"],
+                           kw["sampling_rate"], kw["number_of_iterations"], seed=42, itk_sampling=kw.get("itk_sampling", True))
+    stats = {"method": method, "optimiser": optimiser, "levels": []}
+    assert len(got_levels) == len(want["levels"])
+    for g, w in zip(got_levels, want["levels"]):
+        n = min(len(g["values"]), len(w["values"]))
+        gv, wv = np.asarray(g["values"][:n]), np.asarray(w["values"][:n])
+        rel = np.abs(gv - wv) / np.maximum(np.abs(wv), 1e-12)
+        stats["levels"].append({"iterations_product": int(g["iterations"]), "iterations_oracle": len(w["values"]),
+                                "stop_product": int(g["stop"]), "stop_oracle": w["stop"], "value_rel_err_max": float(rel.max()),
+                                "value_rel_err_first5": float(rel[:5].max()), "param_abs_err_max": float(np.abs(np.asarray(g["parameters"]) - w["final"]).max()),
+                                "first_value": float(wv[0]), "last_value": float(wv[-1])})
+    A, off = tfm.matrix_offset()
+    Aw, ow = want["matrix_offset"]
+    c = _corners()
+    stats["corner_mm"] = float(np.sqrt((((c @ np.asarray(A).T + off) - (c @ Aw.T + ow)) ** 2).sum(1)).max())
+    # a mask through the two results (nearest neighbour, the pipelines' propagation)
+    zz, yy, xx = np.meshgrid(*[np.arange(v) for v in SHAPE], indexing="ij")
+    mask = (((xx - 22) / 11.0) ** 2 + ((yy - 21) / 9.0) ** 2 + ((zz - 12) / 6.0) ** 2 < 1).astype(np.uint8)
+    prop = pa.registration.apply_transform(pa.image_from_array(mask, SPACING, ORIGIN), fi, tfm, 0, pa.sitkNearestNeighbor).numpy()
+    wprop = O.resample(O.Vol(mask, SPACING, ORIGIN), O.Vol(mask, SPACING, ORIGIN), affine=(Aw, ow), interp=O.INTERP_NEAREST).arr
+    stats["mask_voxels"], stats["mask_voxels_differing"] = int(mask.sum()), int((prop != wprop).sum())
+    record_stats("linear_oracle_" + label, stats)
+    print(label, stats)
+    return stats, got_levels, want
+
+
+def _assert_same_trajectory(stats, first5=2e-4):
+    """Per level: iteration count and stop reason equal; the metric value of every iteration within 1e-2 relative, and within
+    `first5` over the first level's first five iterations (fp32 kernels against fp64).  A line search COMPARES probe values:
+    where two probes tie to rounding the two implementations may take different branches of the golden section, which moves
+    that iteration's learning rate by one bracket step (measured: 1e-3 in the value, absorbed by the following iterations) --
+    hence the looser bound after the start.  The final maps send the volume's corners to within 0.05 mm of each other, and a
+    mask propagated through each differs in at most 0.2 % of its voxels (3 of 2451 measured at worst)."""
+    for k, lv in enumerate(stats["levels"]):
+        assert lv["iterations_product"] == lv["iterations_oracle"], stats
+        assert {0: "iterations", 1: "converged", 2: "no overlap"}[lv["stop_product"]] == lv["stop_oracle"], stats
+        assert lv["value_rel_err_max"] <= 1e-2, stats
+        if k == 0:
+            assert lv["value_rel_err_first5"] <= first5, stats
+    assert stats["corner_mm"] <= 0.05, stats
+    assert stats["mask_voxels_differing"] <= 0.002 * stats["mask_voxels"], stats
+
+
+CASES = [("rigid", "gradient_descent_line_search"), ("similarity", "gradient_descent_line_search"), ("affine", "gradient_descent_line_search"),
+         ("translation", "gradient_descent_line_search"), ("rigid", "gradient_descent"), ("similarity", "gradient_descent"),
+         ("affine", "gradient_descent")]
+
+
+@pytest.mark.parametrize("method,optimiser", CASES)
+def test_linear_registration_follows_the_itk_oracle(host_api, method, optimiser):
+    """Two levels without smoothing (the pipelines' sigmas are 0), ITK sampling on (the default); bounds: _assert_same_trajectory."""
+    pa = host_api
+    fix, mov, _ = _rigid_pair(pa, SHAPE, SPACING, ORIGIN)
+    gd = optimiser == "gradient_descent"
+    kw = dict(shrink_factors=[4, 2], smooth_sigmas=[0, 0], sampling_rate=0.5, number_of_iterations=8 if gd else 15)
+    stats, got, want = _compare(pa, fix, mov, method, optimiser, kw, f"{method}_{optimiser}")
+    _assert_same_trajectory(stats)
+    assert stats["levels"][0]["last_value"] < 0.7 * stats["levels"][0]["first_value"]       # it did register
+
+
+def test_linear_registration_pipeline_settings_follow_the_itk_oracle(host_api):
+    """The pipelines' own call (multiatlas/run.py:64-74): affine, line search, mean squares, three levels, sampling 0.75 -- on
+    a smaller grid with shrink factors [8, 4, 2]; and a smoothed level (sigma 2 mm: DiscreteGaussian of both images)."""
+    pa = host_api
+    fix, mov, _ = _rigid_pair(pa, SHAPE, SPACING, ORIGIN, angle=0.05, shift=(2.0, -3.0, 1.0), scale=1.04)
+    kw = dict(shrink_factors=[8, 4, 2], smooth_sigmas=[0, 0, 0], sampling_rate=0.75, number_of_iterations=12)
+    stats, _, _ = _compare(pa, fix, mov, "affine", "gradient_descent_line_search", kw, "pipeline_affine")
+    _assert_same_trajectory(stats)
+    kw = dict(shrink_factors=[4, 1], smooth_sigmas=[2, 0], sampling_rate=0.25, number_of_iterations=10)
+    stats, _, _ = _compare(pa, fix, mov, "similarity", "gradient_descent_line_search", kw, "smoothed_similarity")
+    _assert_same_trajectory(stats, first5=5e-4)
+
+
+def test_iteration_by_iteration_parameters(host_api):
+    """Each level returns its LAST point, so number_of_iterations = k exposes the parameters after k steps: product and oracle
+    agree step by step (rigid: versor composition; affine: plain addition)."""
+    pa = host_api
+    fix, mov, _ = _rigid_pair(pa, SHAPE, SPACING, ORIGIN)
+    fi, mi = pa.image_from_array(fix, SPACING, ORIGIN), pa.image_from_array(mov, SPACING, ORIGIN)
+    worst = {}
+    for method in ("rigid", "affine"):
+        for k in (1, 2, 3, 6):
+            kw = dict(reg_method=method, optimiser="gradient_descent_line_search", shrink_factors=[2], smooth_sigmas=[0], sampling_rate=0.5,
+                      number_of_iterations=k)
+            _, tfm = pa.registration.linear_registration(fi, mi, **kw)
+            got = np.asarray(tfm.transforms[1].GetParameters())
+            want = LO.registration(O.Vol(fix, SPACING, ORIGIN), O.Vol(mov, SPACING, ORIGIN), method, kw["optimiser"], [2], [0], 0.5, k)["parameters"]
+            scale = np.maximum(np.abs(want), 1e-3 if method == "rigid" else 1e-2)
+            worst[(method, k)] = float((np.abs(got - want) / scale).max())
+    print("relative parameter error after k steps:", worst)
+    assert max(worst.values()) <= 5e-3, worst
+    assert worst[("rigid", 1)] <= 2e-4 and worst[("affine", 1)] <= 2e-4, worst
+
+
+def test_versor_update_is_a_composition_and_the_window_value_is_itk_s():
+    """The two pieces of host arithmetic the oracle restates differently from the product, against closed forms: composing a
+    rotation of angle a about an axis onto a versor = the product of the rotation matrices (not the sum of the versors), and the
+    convergence value of a straight line of energies is its slope up to the scattered-data approximation's known bias."""
+    from platipy_amd.registration.linear import _window_convergence
+    from platipy_amd.transform import VersorRigid3DTransform, _versor_matrix, _versor_update
+
+    v = np.array([0.10, -0.05, 0.20, 1.0, 2.0, 3.0])
+    u = np.array([0.02, 0.03, -0.01, 0.5, -0.5, 0.25])
+    new = _versor_update(v, u)
+    angle = np.linalg.norm(u[:3])
+    axis = u[:3] / angle
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    Rg = np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * K @ K            # Rodrigues
+    np.testing.assert_allclose(_versor_matrix(new[:3]), _versor_matrix(v[:3]) @ Rg, atol=1e-12)
+    np.testing.assert_allclose(new[3:], v[3:] + u[3:])
+    t = LO.OracleTransform("rigid")
+    t.p = v.copy()
+    np.testing.assert_allclose(t.updated(u), new, atol=1e-14)                      # product and oracle: two formulations, one result
+    np.testing.assert_allclose(VersorRigid3DTransform().update(v, np.zeros(6)), v, atol=1e-15)
+    # analytic Jacobian of the oracle against central differences
+    x = np.array([[10.0, -20.0, 30.0], [1.0, 2.0, 3.0]])
+    for kind, p in (("rigid", v), ("similarity", np.append(v, 1.1))):
+        t = LO.OracleTransform(kind, center=(1.0, 2.0, 3.0))
+        t.p = p.copy()
+        J = t.jacobian(x)
+        for i in range(len(p)):
+            h = 1e-6
+            pp, pm = p.copy(), p.copy()
+            pp[i] += h
+            pm[i] -= h
+            np.testing.assert_allclose(J[:, :, i], (t.apply(x, pp) - t.apply(x, pm)) / (2 * h), atol=1e-6)
+    # window convergence: constant energies -> 0; decreasing line -> positive; the two restatements agree
+    # (a constant window reads -3e-6, not 0: the filter's end-point epsilon breaks the symmetry of the two control points)
+    assert abs(_window_convergence([5.0] * 10, 10)) < 1e-5
+    e = list(np.linspace(10.0, 9.0, 10))
+    assert _window_convergence(e, 10) > 0 and _window_convergence(e[::-1], 10) < 0
+    assert _window_convergence(e, 10) == pytest.approx(LO._window_convergence_itk(e), rel=1e-12)
+    assert _window_convergence(e[:9], 10) == float("inf")
+    # the least-squares slope of the normalised line is (10 - 9) / 95 = 0.010526; the two-control-point approximation reads lower
+    assert 0.5 * (1.0 / 95.0) < _window_convergence(e, 10) < 1.0 / 95.0

@@ -101,5 +101,49 @@ for case in range(max(4, n_cases // 2)):
     bad += 0 if ok else 1
     print(line + f" pyramid level max {e1:.1e}  recursive Gaussian max {e2:.1e}  weight map rel {e3:.1e}  distance map max {e4:.1e}"
           f"  contour {same_c}  morphology {same_m}  probability->mask {same_p}{'' if ok else '  <-- OUT OF TOLERANCE'}")
+# ---- third sweep (round 6): WHOLE registrations with the pipelines' settings -- isotropic levels of random voxel size, sigma 0,
+# many iterations with the RMS halt live, final resample onto the (anisotropic) fixed grid -- and the structure-guided stage on
+# distance-map images (multiatlas/run.py:75-84, cardiac/run.py:129-152); tolerance = tests/test_pipeline_parity.py's
+from tests.test_pipeline_parity import ellipsoid, err_stats  # noqa: E402
+
+for case in range(max(3, n_cases // 3)):
+    shape = tuple(int(v) for v in rng.integers(40, 90, size=3))
+    spacing = (float(rng.uniform(0.8, 1.3)),) * 2 + (float(rng.uniform(1.5, 3.0)),)
+    origin = tuple(float(v) for v in rng.uniform(-100, 100, size=3))
+    fine = float(rng.uniform(1.4, 2.2))
+    guided = case % 3 == 2
+    kw = dict(isotropic_resample=True, resolution_staging=[4 * fine, 2 * fine, fine], smoothing_sigmas=[0, 0, 0],
+              iteration_staging=[int(v) for v in rng.integers(30, 120, size=3)], default_value=0 if guided else None)
+    if guided:
+        c = [s / 2 for s in shape[::-1]]
+        t = ellipsoid(shape, c, [0.3 * s for s in shape[::-1]])
+        a = ellipsoid(shape, [v + float(rng.uniform(-4, 4)) for v in c], [float(rng.uniform(0.22, 0.34)) * s for s in shape[::-1]])
+        fix = pa.registration.convert_mask_to_reg_structure(pa.Image(t, spacing, origin), expansion=2).numpy()
+        mov = pa.registration.convert_mask_to_reg_structure(pa.Image(a, spacing, origin), expansion=2).numpy()
+    else:
+        fix = phantom(shape, seed=8000 + case)
+        dv = random_dvf(shape, spacing, seed=8100 + case, max_mm=float(rng.uniform(2.0, 6.0)))
+        mov = O.warp_image(O.Vol(phantom(shape, seed=8000 + case, noise=0), spacing, origin), dv.astype(np.float64), edge_value=-1000.0).arr
+        mov = (mov + rng.normal(0, 5, size=shape)).astype(np.float32)
+    tr, ptr = [], []
+    _, w, _ = O.fast_symmetric_forces_demons_registration(O.Vol(fix, spacing, origin), O.Vol(mov, spacing, origin), trace=tr, **kw)
+    pert = np.nextafter(mov.astype(np.float32), np.float32(np.inf))
+    _, p, _ = O.fast_symmetric_forces_demons_registration(O.Vol(fix, spacing, origin), O.Vol(pert, spacing, origin), trace=ptr, **kw)
+    _, tfm, g = pa.registration.fast_symmetric_forces_demons_registration(pa.image_from_array(fix, spacing, origin),
+                                                                          pa.image_from_array(mov, spacing, origin), **kw)
+    hip, own = err_stats(g.numpy(), w.arr), err_stats(p.arr, w.arr)
+    mask = ellipsoid(shape, [s / 2 for s in shape[::-1]], [0.25 * s for s in shape[::-1]]).cpu().numpy()
+    mh = pa.registration.apply_transform(pa.image_from_array(mask, spacing, origin), transform=tfm, default_value=0,
+                                         interpolator=pa.sitkNearestNeighbor).numpy()
+    mo = O.apply_transform(O.Vol(mask, spacing, origin), field_vol=w, default_value=0, interpolator=O.INTERP_NEAREST).arr
+    mp = O.apply_transform(O.Vol(mask, spacing, origin), field_vol=p, default_value=0, interpolator=O.INTERP_NEAREST).arr
+    ndiff, nown = int((mh != mo).sum()), int((mp != mo).sum())
+    ok = (hip["median"] <= max(5e-5, 4 * own["median"]) and hip["p99"] <= max(1e-3, 4 * own["p99"]) and hip["rms"] <= max(2e-3, 4 * own["rms"])
+          and hip["inner_max"] <= max(2e-2, 4 * own["inner_max"]) and ndiff <= max(2e-4 * mask.sum(), 4 * nown, 2))
+    bad += 0 if ok else 1
+    print(f"case {case:2d} {'guided' if guided else 'ct    '} shape {shape} levels {[t['fixed'].arr.shape[::-1] for t in tr]} iterations "
+          f"{[t['elapsed'] for t in tr]}: field median {hip['median']:.1e} (own {own['median']:.1e}) p99 {hip['p99']:.1e} ({own['p99']:.1e}) "
+          f"rms {hip['rms']:.1e} ({own['rms']:.1e}); whole-chain mask voxels differing {ndiff} (own {nown}) of {int(mask.sum())}"
+          f"{'' if ok else '  <-- OUT OF TOLERANCE'}")
 print("cases out of tolerance:", bad)
 sys.exit(1 if bad else 0)

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Which kernels of which HIP stream run when, for config 5's per-GPU shape (4 atlas chains on 4 streams).
 
-    rocprofv3 --kernel-trace --output-format csv -d OUT -o tl -- python tools/r5/streams_timeline.py run [atlases] [streams]
-    python tools/r5/streams_timeline.py analyse OUT > profiles/round5_streams_timeline.md
+    rocprofv3 --kernel-trace --output-format csv -d OUT -o tl -- python tools/streams_timeline.py run [atlases] [streams]
+    python tools/streams_timeline.py analyse OUT "title" > profiles/round6_streams_timeline.md
+
+`run` takes the schedule from the environment: TL_STAGGER=0|1 (projects.multiatlas.STAGGER), TL_SLOTS=n (ENTRY_SLOTS).
 
 `run`: one warm-up pass of bench.multi_atlas_streams_leg's workload, 0.4 s of idle, then the pass that is analysed.
 `analyse`: the dispatches after the last idle gap >= 0.25 s, per queue (= stream): busy time, kernel classes, and a timeline in
@@ -14,7 +16,7 @@ import os
 import sys
 from collections import defaultdict
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run(per_gpu, streams):
@@ -38,6 +40,13 @@ def run(per_gpu, streams):
             time.sleep(0.4)
         return real()
 
+    from platipy_amd.projects import multiatlas
+
+    if "TL_STAGGER" in os.environ:
+        multiatlas.STAGGER = os.environ["TL_STAGGER"] != "0"
+    if "TL_SLOTS" in os.environ:
+        multiatlas.ENTRY_SLOTS = int(os.environ["TL_SLOTS"])
+    print(f"TIMELINE_SCHEDULE stagger {multiatlas.STAGGER} entry slots {multiatlas.ENTRY_SLOTS}")
     bench.time.perf_counter = marked
     dt, dice, _ = bench.multi_atlas_streams_leg(ctx, (256, 512, 512), (1.0, 1.0, 1.0), dev, 0, 1, per_gpu=per_gpu, streams=streams)
     bench.time.perf_counter = real
@@ -59,7 +68,7 @@ def classify(name, threads):
 NAMES = {"F": "demons finest level", "C": "demons coarse levels", "L": "linear metric", "R": "resample/compose/IIR", "G": "FIR blurs", "o": "other"}
 
 
-def analyse(d):
+def analyse(d, title="kernel timeline of the atlas chains of one GPU (512x512x256, pipeline defaults)"):
     rows = []
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -73,7 +82,7 @@ def analyse(d):
     rows = rows[cut:]
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     span = (t1 - t0) / 1e6
-    print(f"# Round 5: kernel timeline of 4 atlas chains on 4 HIP streams (512x512x256, pipeline defaults)\n")
+    print(f"# {title}\n")
     print(f"{len(rows)} dispatches in a device span of {span:.1f} ms (rocprofv3 --kernel-trace; dispatches after the pause before the timed pass).\n")
     queues = sorted({r[2] for r in rows})
     per_q = defaultdict(lambda: defaultdict(float))
@@ -99,6 +108,31 @@ def analyse(d):
             multi_ms += (t - last) / 1e6
         depth += dlt
         last = t
+    # the finest demons level: when it ran (union over queues), and the aggregate rate its voxel-iterations went at
+    fin = sorted((s, e) for s, e, q, name, gx in rows if classify(name, gx) == "F")
+    if fin:
+        n_launch = len(fin)
+        merged, (cs, ce) = [], fin[0]
+        for s, e in fin[1:]:
+            if s <= ce:
+                ce = max(ce, e)
+            else:
+                merged.append((cs, ce))
+                cs, ce = s, e
+        merged.append((cs, ce))
+        f_union = sum(e - s for s, e in merged) / 1e6
+        f_multi = 0.0
+        evf = sorted([(s, 1) for s, e in fin] + [(e, -1) for s, e in fin])
+        depth, last = 0, evf[0][0]
+        for t, dlt in evf:
+            if depth >= 2:
+                f_multi += (t - last) / 1e6
+            depth += dlt
+            last = t
+        vox = float(os.environ.get("TL_FINEST_VOXELS", 341 * 341 * 171))
+        print(f"\nFinest demons level: {n_launch} launches = {n_launch / 2:.0f} iterations of {vox / 1e6:.1f} Mvoxel; a finest-level kernel was "
+              f"running for {f_union:.1f} ms (two or more of them at once for {f_multi:.1f} ms): aggregate {n_launch / 2 * vox / f_union / 1e6:.1f} Gvoxel/s "
+              f"over that time.")
     print(f"\nSum of kernel durations {tot:.1f} ms; device busy (>= 1 kernel running) {any_ms:.1f} ms of {span:.1f}; >= 2 kernels running {multi_ms:.1f} ms; idle {span - any_ms:.1f} ms.\n")
     binw = 5.0
     nb = int(span / binw) + 1
@@ -133,4 +167,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 4, int(sys.argv[3]) if len(sys.argv) > 3 else 4)
     else:
-        analyse(sys.argv[2])
+        analyse(*sys.argv[2:4])
