@@ -205,8 +205,8 @@ def _hand_over(obj, stream, _seen=None):
 # throughput-bound phase (finest demons level + the full-resolution resamples behind it), the others' latency-bound phases
 # underneath.  ENTRY_SLOTS: how many chains may be in their linear stage at once (0: no bound) -- chains started together are
 # thereby admitted one after the other and reach the turnstile one throughput-bound phase apart instead of all at once.
-STAGGER = True
-ENTRY_SLOTS = 1
+STAGGER = False
+ENTRY_SLOTS = 0
 
 
 def _map_atlases(fn, ids, streams_per_gpu, device):

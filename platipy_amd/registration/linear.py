@@ -651,27 +651,31 @@ def itk_moving_gradient(ctx, moving):
     """ImageToImageMetricv4's default moving-image gradient source, in moving-INDEX units [3, Z, Y, X] float32:
     itk::GradientRecursiveGaussianImageFilter(sigma = largest spacing, NormalizeAcrossScale, UseImageDirection) -- per component
     d the first-order recursive Gaussian along d, then the zero-order ones along the other axes in increasing order, divided by
-    spacing[d]; rotated to physical axes by the direction cosines; then d m / d index = (direction * spacing)^T applied to it."""
+    spacing[d]; rotated to physical axes by the direction cosines; then d m / d index = (direction * spacing)^T applied to it.
+    With identity direction cosines the division by spacing[d] and the index-unit conversion (times spacing[d]) cancel: the
+    filter chain's output IS the per-index gradient, written straight into its plane of the result."""
     src = moving.tensor if moving.tensor.dtype == torch.float32 else moving.tensor.float()
     src = src.contiguous()
     geom = moving.geom()
     sp = np.asarray(moving.spacing, dtype=np.float64)
     sigma = float(sp.max())
-    comps = []
+    out = torch.empty((3,) + tuple(src.shape), dtype=torch.float32, device=src.device)
+    scratch = [torch.empty_like(src), torch.empty_like(src)]
     for d in range(3):
-        cur = torch.empty_like(src)
-        ctx.recursive_gaussian_pass(src, cur, geom, d, sigma, order=1, normalize_across_scale=True)
-        for ax in range(3):
-            if ax != d:
-                nxt = torch.empty_like(src)
-                ctx.recursive_gaussian_pass(cur, nxt, geom, ax, sigma, order=0, normalize_across_scale=True)
-                cur = nxt
-        comps.append(cur / float(sp[d]))
-    phys = torch.stack(comps)
+        others = [ax for ax in range(3) if ax != d]
+        ctx.recursive_gaussian_pass(src, scratch[0], geom, d, sigma, order=1, normalize_across_scale=True)
+        ctx.recursive_gaussian_pass(scratch[0], scratch[1], geom, others[0], sigma, order=0, normalize_across_scale=True)
+        ctx.recursive_gaussian_pass(scratch[1], out[d], geom, others[1], sigma, order=0, normalize_across_scale=True)
     D = np.asarray(moving.direction, dtype=np.float64).reshape(3, 3)
-    to_index = (D * sp[None, :]).T @ D          # (direction * spacing)^T (direction g): physical gradient -> per-index gradient
-    T = torch.tensor(to_index, dtype=torch.float32, device=src.device)
-    return torch.einsum("rc,czyx->rzyx", T, phys).contiguous()
+    if np.array_equal(D, np.eye(3)):
+        return out
+    # oblique / flipped grids: physical gradient = D (filtered_d / spacing_d), per-index gradient = (D spacing)^T of that
+    to_index = (D * sp[None, :]).T @ D @ np.diag(1.0 / sp)
+    mixed = torch.empty_like(out)
+    for r in range(3):
+        torch.mul(out[0], float(to_index[r, 0]), out=mixed[r])
+        mixed[r].add_(out[1], alpha=float(to_index[r, 1])).add_(out[2], alpha=float(to_index[r, 2]))
+    return mixed
 
 
 def _level_args(scope):

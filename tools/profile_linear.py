@@ -22,23 +22,38 @@ orig = linear._optimise_level_native
 log = []
 
 
-def timed(ctx_, ms, model, params, opt, n_it, verbose):
+def timed(ctx_, ms, model, params, opt, n_it, verbose, *rest):
     torch.cuda.synchronize()
     e0 = ms.evaluations
     t0 = time.perf_counter()
-    out = orig(ctx_, ms, model, params, opt, n_it, verbose)
+    out = orig(ctx_, ms, model, params, opt, n_it, verbose, *rest)
     log.append((tuple(ms.vsize), ms.stride, time.perf_counter() - t0, ms.evaluations - e0))
     return out
 
 
 linear._optimise_level_native = timed
-for name, kw in (("quick", QUICK_REG_SETTINGS), ("affine", MUTLIATLAS_SETTINGS_DEFAULTS["linear_registration_settings"])):
+orig_grad = linear.itk_moving_gradient
+
+
+def timed_grad(ctx_, moving_):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = orig_grad(ctx_, moving_)
+    torch.cuda.synchronize()
+    print(f"   filtered gradient image: {(time.perf_counter() - t0) * 1e3:.2f} ms")
+    return out
+
+
+linear.itk_moving_gradient = timed_grad
+cases = [(name, dict(kw, itk_sampling=itk)) for itk in (True, False)
+         for name, kw in (("quick", QUICK_REG_SETTINGS), ("affine", MUTLIATLAS_SETTINGS_DEFAULTS["linear_registration_settings"]))]
+for name, kw in cases:
     pa.registration.linear_registration(fi, mi, **kw)
     log.clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     pa.registration.linear_registration(fi, mi, **kw)
     torch.cuda.synchronize()
-    print(name, "total", round((time.perf_counter() - t0) * 1e3, 2), "ms")
+    print(name, "itk_sampling", kw["itk_sampling"], "total", round((time.perf_counter() - t0) * 1e3, 2), "ms")
     for vsize, stride, dt, ev in log:
         print(f"   level vsize {vsize} stride {stride}: {dt * 1e3:7.2f} ms, {ev} evaluations, {dt * 1e6 / max(ev, 1):.1f} us/evaluation")
