@@ -486,6 +486,16 @@ def main():
                "reported": "median"}
     prof = ctx.profile_read()
     ctx.profile_enable(False)
+    # What an EMPTY bracket reads on this stream: kernels[*].avg_ms are event-to-event times, so each carries this much beyond
+    # the kernel's own duration (which is what rocprofv3 reports) -- that is why they can add up to more than ms_per_step.
+    pair_ms = []
+    for _ in range(64):
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        eb.record()
+        eb.synchronize()
+        pair_ms.append(ea.elapsed_time(eb))
+    event_pair_ms = sorted(pair_ms)[len(pair_ms) // 2]
 
     out = None
     if rank == 0:
@@ -553,6 +563,11 @@ def main():
             "repeats": repeats,
             # HIP events bracket every K-th launch of each kernel inside the timed region (kernels[*].launches = bracketed launches)
             "kernel_events_every": (None if args.no_kernel_events else max(1, args.kernel_events_every)),
+            "kernel_event_pair_ms": event_pair_ms,
+            "kernel_events_note": "kernels[*].avg_ms (and roofline.avg_launch_ms) are HIP event-to-event times on the launch stream: each "
+                                  "includes the bracket's own cost (kernel_event_pair_ms: an empty bracket on this stream) and the lost "
+                                  "back-to-back overlap, so they are upper bounds of the kernel durations rocprofv3 reports and may sum to "
+                                  "more than ms_per_step; roofline.frac is therefore conservative",
             "roofline": roofline,
             "roofline_iteration": {"achieved": iter_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": iter_gbps / HBM_PEAK_GBS,
                                    "compulsory_bytes_per_voxel": iter_bytes,

@@ -89,6 +89,10 @@ typedef struct {
 
 /* ---- context --------------------------------------------------------------------- */
 int pp_abi_version(void);
+/* The PP_* measurement / debugging switches are read from the process environment ONCE, when the library
+ * first needs one; launch paths never call getenv.  pp_reload_switches() takes the snapshot again -- for tests and A/B tools
+ * that flip a switch inside one process; not while another thread is inside the library.  (No reference counterpart.) */
+void pp_reload_switches(void);
 int pp_create(int device, void* hip_stream, pp_ctx** out);
 void pp_destroy(pp_ctx* ctx);
 const char* pp_last_error(const pp_ctx* ctx);

@@ -12,7 +12,17 @@ import os as _os
 # them the null stream's): with config 5's four atlas chains on four HIP streams two chains shared a queue and ran one after
 # the other -- 240 ms of a 269 ms span on that queue alone (profiles/round5_streams_timeline_before.md).  Read when the
 # runtime initialises the device, i.e. at the first CUDA call, which comes after this import; an explicit setting wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if "GPU_MAX_HW_QUEUES" not in _os.environ:
+    import sys as _sys
+
+    _torch = _sys.modules.get("torch")
+    if _torch is not None and _torch.cuda.is_available() and _torch.cuda.is_initialized():
+        import warnings as _warnings
+
+        _warnings.warn("platipy_amd was imported after the HIP runtime had initialised: GPU_MAX_HW_QUEUES=8 cannot take effect any "
+                       "more, and run_segmentation(streams_per_gpu >= 4) will share hardware queues between atlas chains (results are "
+                       "the same; config 5's per-GPU shape runs ~3 % slower).  Import platipy_amd first or export the variable.")
+    _os.environ["GPU_MAX_HW_QUEUES"] = "8"      # (process-wide: every HIP user of this process gets 8 queues per device)
 
 from .image import Image, image_from_array, array_from_image  # noqa: E402,F401
 from .transform import (  # noqa: E402,F401

@@ -157,6 +157,7 @@ _SIGNATURES = {
                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(MiBins),
                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pp_linear_num_parameters": (C.c_int, [C.c_int]),
+    "pp_reload_switches": (None, []),
     "pp_linear_optimize_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), _P, _P, C.POINTER(LinregLevel),
                                          C.POINTER(C.c_double), C.POINTER(LinregStats), C.POINTER(C.c_double), C.c_int]),
 }
@@ -181,7 +182,19 @@ def load(path=None):
         fn.argtypes = args
     if dll.pp_abi_version() != ABI_VERSION:
         raise PlatipyAmdError(f"{path}: ABI version {dll.pp_abi_version()} != {ABI_VERSION}")
+    _LOADED.append(dll)
     return dll
+
+
+_LOADED = []
+
+
+def reload_switches():
+    """pp_reload_switches() on every library this process loaded: the PP_* measurement switches are read from the environment
+    once; tests and A/B tools that flip one inside a process call this afterwards (not while kernels are being launched from
+    another thread)."""
+    for d in _LOADED:
+        d.pp_reload_switches()
 
 
 _DLL = None

@@ -1,11 +1,15 @@
 // platipy_amd/csrc/pp_api.hip -- context management and host-side helpers of the C ABI
 // (include/platipy_amd.h).
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 
 #include "pp_internal.h"
 
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -51,7 +55,9 @@ void pp_prof_begin(pp_ctx* ctx, const char* kernel_name) {
   }
   if ((int)p->seen.size() <= slot) p->seen.resize(slot + 1, 0);
   const int nth = p->seen[slot]++;
-  if (p->period > 1 && (nth % p->period) != 0) {   // not a sampled launch
+  // (the LAST launch of every group of `period` is the sampled one: launch 0 of a kernel name is atypical -- the first
+  // iteration of a block reads the moving image itself -- and would otherwise be in every read-out)
+  if (p->period > 1 && (nth % p->period) != p->period - 1) {   // not a sampled launch
     p->open_slot = -1;
     return;
   }
@@ -80,11 +86,79 @@ int pp_fail(pp_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
+// ---- the PP_* switches: one snapshot of the environment -----------------------------------------------------------------
+namespace {
+struct pp_switch_def {
+  const char* name;
+  bool numeric;   // the value must parse as an integer (else: presence is what counts)
+};
+constexpr pp_switch_def SWITCHES[] = {
+    {"PP_CC_ROWS_BLOCK", false},  {"PP_COMPOSE_BLOCK", true},  {"PP_FIR_LEGACY", false},   {"PP_FIR_MARCH_SP", true},
+    {"PP_FUSED_GEN", true},       {"PP_FUSED_MASK", true},     {"PP_FUSED_MIX", true},     {"PP_FUSED_NT", true},
+    {"PP_FUSED_OPT", true},       {"PP_FUSED_PITCH", true},    {"PP_FUSED_SUM", true},     {"PP_FUSED_SYNC", true},
+    {"PP_FUSED_TILE", true},      {"PP_FUSED_ZCHUNK", true},   {"PP_FUSED_ZCHUNK_A", true}, {"PP_FUSED_ZCHUNK_B", true},
+    {"PP_GAUSS3", true},          {"PP_METRIC_BLOCKS", true},  {"PP_METRIC_GRAD_ONE_LAUNCH", true}, {"PP_METRIC_LANES", true},
+    {"PP_NO_FIXED_SAMPLES", false}, {"PP_POISON_WS", false},   {"PP_RESAMPLE_GENERIC", false}, {"PP_RG_GRID", true},
+    {"PP_RG_SEG_V1", false},      {"PP_RG_TWO_SWEEP", false},  {"PP_RS_BAND", true},       {"PP_RS_ZCHUNK", true},
+    {"PP_WARP_LEGACY", false},
+};
+constexpr int N_SWITCHES = (int)(sizeof(SWITCHES) / sizeof(SWITCHES[0]));
+struct pp_switch_snapshot {
+  bool has[N_SWITCHES];
+  char value[N_SWITCHES][32];
+};
+std::atomic<pp_switch_snapshot*> g_switches{nullptr};
+std::mutex g_switch_lock;
+
+pp_switch_snapshot* take_snapshot() {
+  auto* s = new pp_switch_snapshot();
+  for (int i = 0; i < N_SWITCHES; ++i) {
+    const char* v = getenv(SWITCHES[i].name);     // the ONLY getenv of the library: here, under g_switch_lock
+    s->has[i] = false;
+    s->value[i][0] = 0;
+    if (!v) continue;
+    if (SWITCHES[i].numeric) {
+      char* end = nullptr;
+      (void)strtol(v, &end, 10);
+      if (end == v || *end != 0 || strlen(v) >= sizeof(s->value[i])) {
+        fprintf(stderr, "platipy_amd: %s=\"%s\" is not an integer; the switch is ignored\n", SWITCHES[i].name, v);
+        continue;
+      }
+    }
+    s->has[i] = true;
+    strncpy(s->value[i], v, sizeof(s->value[i]) - 1);
+  }
+  return s;
+}
+}  // namespace
+
+const char* pp_env(const char* name) {
+  pp_switch_snapshot* s = g_switches.load(std::memory_order_acquire);
+  if (!s) {
+    std::lock_guard<std::mutex> lock(g_switch_lock);
+    s = g_switches.load(std::memory_order_acquire);
+    if (!s) {
+      s = take_snapshot();
+      g_switches.store(s, std::memory_order_release);
+    }
+  }
+  for (int i = 0; i < N_SWITCHES; ++i)
+    if (strcmp(SWITCHES[i].name, name) == 0) return s->has[i] ? s->value[i] : nullptr;
+  return nullptr;
+}
+
+// Re-read the environment (tests and A/B tools that flip a switch inside one process).  Not for use while another thread is
+// inside the library: the previous snapshot is deliberately leaked, a launcher may still hold a pointer into it.
+extern "C" void pp_reload_switches(void) {
+  std::lock_guard<std::mutex> lock(g_switch_lock);
+  g_switches.store(take_snapshot(), std::memory_order_release);
+}
+
 int pp_reserve(pp_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) {
     // debugging aid: PP_POISON_WS=1 fills the reserved scratch with NaN bytes on every call, so a kernel that reads
     // scratch it did not write shows up as NaN / changed results (tools/stress_streams.py)
-    static const bool poison = getenv("PP_POISON_WS") != nullptr;
+    const bool poison = pp_env("PP_POISON_WS") != nullptr;
     if (poison && bytes) PP_HIP(ctx, hipMemsetAsync(ctx->ws, 0xFF, bytes, ctx->stream));
     return PP_OK;
   }
@@ -273,6 +347,7 @@ int pp_profile_read(pp_ctx* ctx, pp_profile_entry* out, int cap) {
     p->pool.push_back(s.b);
   }
   p->spans.clear();
+  std::fill(p->seen.begin(), p->seen.end(), 0);   // the sampling phase restarts with the accumulators
   return n < cap ? n : cap;
 }
 

@@ -284,7 +284,7 @@ unsigned grid_for(size_t work, unsigned cap = 16384u) {
 int cc_label(pp_ctx* ctx, const uint8_t* mask, int* L, const pp_dims& d, size_t n, int fg_only) {
   const dim3 g(grid_for(n)), b(NT);
   const size_t rows = (size_t)d.ny * d.nz;
-  if (getenv("PP_CC_ROWS_BLOCK")) {   // (the block-per-row form, for A/B runs)
+  if (pp_env("PP_CC_ROWS_BLOCK")) {   // (the block-per-row form, for A/B runs)
     hipLaunchKernelGGL(k_cc_rows, dim3((unsigned)(rows < 65535 ? rows : 65535)), b, 0, ctx->stream, mask, L, d, fg_only);
   } else {
     const size_t nbr = (rows + NT / 64 - 1) / (NT / 64);

@@ -888,8 +888,8 @@ void small_taps(const pp_taps& t, int R, pp_taps_small* s) {
 // z-chunk length: long chunks amortise the 2R (+3 image) halo planes, but the launch should fill the
 // chip a whole number of times.  `slots` = resident blocks of the slower kernel (256 CUs x blocks/CU).
 int fused_zchunk(const pp_dims& d, int slots, int TX, int TY, double* cost_out = nullptr, char kernel = 0, int tiles_override = 0) {
-  const char* e = kernel == 'A' ? getenv("PP_FUSED_ZCHUNK_A") : (kernel == 'B' ? getenv("PP_FUSED_ZCHUNK_B") : nullptr);
-  if (!e) e = getenv("PP_FUSED_ZCHUNK");
+  const char* e = kernel == 'A' ? pp_env("PP_FUSED_ZCHUNK_A") : (kernel == 'B' ? pp_env("PP_FUSED_ZCHUNK_B") : nullptr);
+  if (!e) e = pp_env("PP_FUSED_ZCHUNK");
   if (e) {
     const int v = atoi(e);
     if (v >= 1) {
@@ -923,7 +923,7 @@ int fused_zchunk(const pp_dims& d, int slots, int TX, int TY, double* cost_out =
 // block slots idle (341 x 341 x 171: 396 blocks on 512 slots, 11 % faster with 32 x 32) -- or, on a model tie,
 // clearly fewer tiles (less overhang: 85 x 85 -> 9 tiles instead of 12, 18 % faster).
 int fused_shape(const pp_dims& d, int slots0, int slots1) {
-  if (const char* e = getenv("PP_FUSED_TILE")) return atoi(e) == 1 ? 1 : 0;
+  if (const char* e = pp_env("PP_FUSED_TILE")) return atoi(e) == 1 ? 1 : 0;
   double c0 = 0.0, c1 = 0.0;
   fused_zchunk(d, slots0, tile_shape<0>::TX, tile_shape<0>::TY, &c0);
   fused_zchunk(d, slots1, tile_shape<1>::TX, tile_shape<1>::TY, &c1);
@@ -1120,7 +1120,7 @@ int launch_warp2(pp_ctx* ctx, int sh, bool sum, const float* D, const float* Us,
 bool fused_mix_ok(const pp_dims& d) {
   const int rest = d.nx % tile_shape<0>::TX;
   const bool shape_ok = d.nx >= tile_shape<0>::TX && rest != 0 && rest <= tile_shape<1>::TX;
-  if (const char* e = getenv("PP_FUSED_MIX")) return shape_ok && atoi(e) != 0;
+  if (const char* e = pp_env("PP_FUSED_MIX")) return shape_ok && atoi(e) != 0;
   return shape_ok && (size_t)d.nx * d.ny * d.nz >= ((size_t)8 << 20);
 }
 
@@ -1146,20 +1146,20 @@ void fused_grid(fused_args* f, const pp_dims& d, int occupancy, int sh, char ker
   // that is several times the 256 MB infinity cache.  Measured (tools/kbench/run12.sh): 79 MB volumes +1.5 % slower with
   // nt stores, 113 MB -1.5 %, 180 MB -2 %, 268 MB -2.7 %.
   f->streaming = (size_t)d.nx * d.ny * d.nz * sizeof(float) > ((size_t)100 << 20);
-  if (const char* e = getenv("PP_FUSED_NT")) f->streaming = atoi(e) != 0;
+  if (const char* e = pp_env("PP_FUSED_NT")) f->streaming = atoi(e) != 0;
   f->px = px > 0 ? px : d.nx;
   // MASK instances: pairs must exist (even pitch), offsets must fit the buffer-resource trick -- and the volume must be large
   // enough to be throughput-bound: on the small pyramid levels every lane loading on every step costs more than exact waits
   // give (128 x 128 x 64 and 64 x 64 x 32: +7 %, profiles/round4_kbench_mask.txt; 512 x 512 x 256: -2.6 %; equal at 340 x 340 x 170).
   f->masked = (f->px % 2 == 0) && 3 * (size_t)f->px * d.ny * d.nz * sizeof(float) < ((size_t)1 << 31) &&
               (size_t)d.nx * d.ny * d.nz >= ((size_t)8 << 20);
-  if (const char* e = getenv("PP_FUSED_MASK"))   // (0: the branchy kernels; 1: MASK wherever the shape allows -- A/B runs, tests)
+  if (const char* e = pp_env("PP_FUSED_MASK"))   // (0: the branchy kernels; 1: MASK wherever the shape allows -- A/B runs, tests)
     f->masked = atoi(e) != 0 && (f->px % 2 == 0) && 3 * (size_t)f->px * d.ny * d.nz * sizeof(float) < ((size_t)1 << 31);
   // soft synchronisation (PP_SOFTSYNC builds, MASK instances): only when every block of an XCD's run is resident at once --
   // 32 CUs x `occupancy` slots -- since a block waits for the MEAN progress of its group (pp_demons_fused2.h)
   f->sync = f->sync_other = nullptr;   // (set by the caller once the workspace is carved)
   f->sync_lag = (PP_SOFTSYNC > 0 && f->per_xcd <= 32 * occupancy) ? PP_SOFTSYNC : 0;
-  if (const char* e = getenv("PP_FUSED_SYNC")) f->sync_lag = (f->per_xcd <= 32 * occupancy) ? atoi(e) : 0;
+  if (const char* e = pp_env("PP_FUSED_SYNC")) f->sync_lag = (f->per_xcd <= 32 * occupancy) ? atoi(e) : 0;
 }
 
 int check_demons_args(pp_ctx* ctx, const pp_geom* g, const pp_demons_params* p) {
@@ -1317,7 +1317,7 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     if (td[a].r > rb) rb = td[a].r;
   }
   int opt = PP_FUSED_DEFAULT_OPT;
-  if (const char* e = getenv("PP_FUSED_OPT")) opt = atoi(e) == 2 ? 2 : 4;
+  if (const char* e = pp_env("PP_FUSED_OPT")) opt = atoi(e) == 2 ? 2 : 4;
   // kernel generation: 2 (pp_demons_fused2.h) unless the volume exceeds its 32-bit gather offsets / 24-bit row arithmetic,
   // rows are shorter than one strip, the 256-thread layout was asked for, or PP_FUSED_GEN=1 selects the first generation
   // (kept for A/B measurements).
@@ -1325,7 +1325,7 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
                        (size_t)d.ny * d.nz < ((size_t)1 << 24) && d.nx >= 4 && d.nx < (1 << 22) &&
                        d.ny < (1 << 22) && d.nz < (1 << 22);   // (every axis below the warp's 2^23-voxel displacement clamp)
   int gen = (gen2_ok && opt == 2) ? 2 : 1;
-  if (const char* e = getenv("PP_FUSED_GEN")) {
+  if (const char* e = pp_env("PP_FUSED_GEN")) {
     if (atoi(e) == 1) gen = 1;
   }
   // (the second generation needs > 128 registers for kernel A from radius 4 -- sigma_u = 1 voxel gives radius 2 -- and for
@@ -1334,7 +1334,7 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   // both kernels of generation 2: kernel A stores D + G_u * update and kernel B reads that one volume (three halo'd arrays
   // instead of six; the add itself is unchanged, so the fields are bit-identical).  PP_FUSED_SUM=0 keeps them apart.
   bool sum_mode = gen_a == 2 && gen_b == 2;
-  if (const char* e = getenv("PP_FUSED_SUM")) {
+  if (const char* e = pp_env("PP_FUSED_SUM")) {
     if (atoi(e) == 0) sum_mode = false;
   }
   const int opt_a = ra > 3 ? 2 : opt, opt_b = rb > 3 ? 2 : opt;   // radii 4 and 5 exist in the 512-thread layout only
@@ -1345,7 +1345,7 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   // 0.655; 171 x 171 x 85 0.073 -> 0.082 and 85 x 85 x 43 0.033 -> 0.037 (latency-bound levels: the MASK instances' unconditional
   // loads and the two copies cost more than alignment gives) -- so from 8 M voxels up; PP_FUSED_PITCH=1 / 0 forces / forbids it.
   bool pitched = gen_a == 2 && gen_b == 2 && sum_mode && p->iterations > 0 && d.nx % 4 != 0;
-  if (const char* e = getenv("PP_FUSED_PITCH")) pitched = pitched && atoi(e) != 0;
+  if (const char* e = pp_env("PP_FUSED_PITCH")) pitched = pitched && atoi(e) != 0;
   else pitched = pitched && N >= ((size_t)8 << 20);
   // (the padded pitch enlarges the component stride: the 32-bit offsets and 24-bit row products that gen2_ok checked on the
   // dense volume must also hold on the padded one -- e.g. 709 x 709 x 711 passes dense and wraps at px = 712 -- else dense rows)
@@ -1364,7 +1364,7 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
 #undef PP_OCC_A21
     sh_a = fused_shape(d, 256 * occ_a0, 256 * occ_a1);
 #define PP_OCC_A22(RR) occ_force2<RR>(2)
-    if (fused_mix_ok(d) && !getenv("PP_FUSED_TILE")) {
+    if (fused_mix_ok(d) && !pp_env("PP_FUSED_TILE")) {
       sh_a = 2;
       fused_grid(&fu, d, PP_BY_RADIUS_A2(ra, PP_OCC_A22), 2, 'A', px);
     } else {
@@ -1389,7 +1389,7 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
 #undef PP_OCC_B21
     sh_b = fused_shape(d, 256 * occ_b0, 256 * occ_b1);
 #define PP_OCC_B22(RR) occ_warp2<RR>(2)
-    if (fused_mix_ok(d) && !getenv("PP_FUSED_TILE")) {
+    if (fused_mix_ok(d) && !pp_env("PP_FUSED_TILE")) {
       sh_b = 2;
       fused_grid(&fd, d, PP_BY_RADIUS_B2(rb, PP_OCC_B22), 2, 'B', px);
     } else {

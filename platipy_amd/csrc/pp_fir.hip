@@ -502,7 +502,7 @@ template <int AXIS, bool ADD>
 int launch_axis(pp_ctx* ctx, const float* in, const float* add, float* out, const pp_dims& d, int ncomp,
                 const pp_taps& taps, const int* halt, const int* rows = nullptr, int use_y = 0, int use_z = 0) {
   const bool al16 = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | (ADD ? reinterpret_cast<uintptr_t>(add) : 0)) % 16 == 0);
-  if (!rows && !getenv("PP_FIR_LEGACY")) {
+  if (!rows && !pp_env("PP_FIR_LEGACY")) {
     const int r = taps.r;
     if (AXIS != 0) {
       const bool v4 = al16 && (d.nx % 4 == 0);
@@ -532,8 +532,8 @@ int launch_axis(pp_ctx* ctx, const float* in, const float* add, float* out, cons
   }
   const size_t cstride = (size_t)d.nx * d.ny * d.nz;
   // sparse outputs, or a radius beyond the dense register-window buckets (PP_FIR_MARCH_SP=0 keeps the one-output-per-thread kernels)
-  const char* sp_env = getenv("PP_FIR_MARCH_SP");   // (once per pass of a once-per-level filter)
-  if (!ADD && !(sp_env && atoi(sp_env) == 0) && !getenv("PP_FIR_LEGACY") && taps.r <= 32) {
+  const char* sp_env = pp_env("PP_FIR_MARCH_SP");   // (once per pass of a once-per-level filter)
+  if (!ADD && !(sp_env && atoi(sp_env) == 0) && !pp_env("PP_FIR_LEGACY") && taps.r <= 32) {
     if (AXIS != 0 && taps.r <= 24) {
       const int len = AXIS == 1 ? d.ny : d.nz, other = AXIS == 1 ? d.nz : d.ny;
       const int W = 2 * taps.r + 1;
@@ -830,7 +830,7 @@ int pp_discrete_gaussian_f32(pp_ctx* ctx, const float* in, float* out, const int
   if (taps[2].r > rmax) rmax = taps[2].r;
   bool fused = rmax <= 4 && d.nx % 4 == 0 && d.nx >= 8 && in != out && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
                N * sizeof(float) < ((size_t)1 << 31);   // (the output goes through a 2^31-byte buffer resource)
-  if (const char* e = getenv("PP_GAUSS3")) fused = fused && atoi(e) != 0;   // (0: the three separable launches, for A/B runs)
+  if (const char* e = pp_env("PP_GAUSS3")) fused = fused && atoi(e) != 0;   // (0: the three separable launches, for A/B runs)
   if (fused) {
     pp_prof_scope ps(ctx, "k_gauss3_zyx");
     switch (rmax < 1 ? 1 : rmax) {

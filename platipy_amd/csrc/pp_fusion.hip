@@ -1555,7 +1555,7 @@ __global__ void __launch_bounds__(NT) k_fixed_samples(const float* __restrict__ 
 static int pp_fixed_samples(pp_ctx* ctx, const float* fixed, const int fsize[3], const double Af[9], const double bf[3], const int vsize[3],
                             int stride, const unsigned char* fmask, const float** out) {
   *out = nullptr;
-  if (ctx->fsamp_scope <= 0 || getenv("PP_NO_FIXED_SAMPLES")) return PP_OK;
+  if (ctx->fsamp_scope <= 0 || pp_env("PP_NO_FIXED_SAMPLES")) return PP_OK;
   auto& k = ctx->fsamp_key;
   const bool same = ctx->fsamp_valid && k.fixed == fixed && k.fmask == fmask && k.stride == stride &&
                     memcmp(k.fsize, fsize, sizeof(k.fsize)) == 0 && memcmp(k.vsize, vsize, sizeof(k.vsize)) == 0 &&
@@ -1633,7 +1633,7 @@ static int metric_affine(pp_ctx* ctx, int mode, const float* fixed, const int fs
   const float* fsamp = nullptr;
   rc = pp_fixed_samples(ctx, fixed, fsize, Af, bf, vsize, stride, fixed_mask, &fsamp);
   if (rc) return rc;
-  const char* one_env = getenv("PP_METRIC_GRAD_ONE_LAUNCH");   // (0: k_metric_affine + k_sum14_final, for A/B runs and the equality test)
+  const char* one_env = pp_env("PP_METRIC_GRAD_ONE_LAUNCH");   // (0: k_metric_affine + k_sum14_final, for A/B runs and the equality test)
   if (!one_env || atoi(one_env) != 0) {
     unsigned* ticket = nullptr;
     rc = pp_ticket(ctx, &ticket);
@@ -1715,12 +1715,12 @@ int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, con
   // Candidates per thread: 16 on big lattices (HBM/L2-bound: the candidates of a sample share cache lines; the straight-line
   // form of the kernel keeps several candidates' gathers in flight), 4 for batches of up to four and on small lattices
   // (latency-bound: spread the candidates over blocks).
-  const char* lanes_env = getenv("PP_METRIC_LANES");   // (0: the candidate-loop kernels, for A/B runs and the equality test)
+  const char* lanes_env = pp_env("PP_METRIC_LANES");   // (0: the candidate-loop kernels, for A/B runs and the equality test)
   if (!lanes_env || atoi(lanes_env) != 0) {
     // Blocks: the small lattices are bound by the latency of one probe (a block's dependent gather rounds, then one ticket
     // atomic per block, ~12 ns each, serialised), the large ones by throughput.  The cap depends on the lattice only.
     unsigned nb_cap = nsamp < 20000 ? 128u : 1024u;   // (tools/r4/run16.sh: 128 x 128 x 64 lattice 24.2 / 15.4 / 11.3 / 11.9 / 13.7 ms per level at 256 .. 4096)
-    if (const char* e = getenv("PP_METRIC_BLOCKS")) nb_cap = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : nb_cap;
+    if (const char* e = pp_env("PP_METRIC_BLOCKS")) nb_cap = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : nb_cap;
     size_t spt = (nsamp + (size_t)MV_SLOTS * nb_cap - 1) / ((size_t)MV_SLOTS * nb_cap);
     spt = (spt + 3) / 4 * 4;
     PP_REQUIRE(ctx, spt < ((size_t)1 << 30), "metric values: sampling lattice too large");
@@ -1769,7 +1769,7 @@ int pp_metric_values_affine_f32(pp_ctx* ctx, int metric, const float* fixed, con
   // at 128 blocks per chunk.  (Not the ticket: a two-level ticket changed nothing.)  The cap depends on the lattice only, so
   // a candidate's partial sums do not depend on how many companions ride in the launch.  PP_METRIC_BLOCKS overrides it.
   unsigned nb_cap = (metric == 0 && small) || metric != 0 ? 128u : 512u;
-  if (const char* e = getenv("PP_METRIC_BLOCKS")) nb_cap = (unsigned)atoi(e);
+  if (const char* e = pp_env("PP_METRIC_BLOCKS")) nb_cap = (unsigned)atoi(e);
   const unsigned nb = grid_for(nsamp, nb_cap);
   const size_t row = (size_t)ch * nv;
   int rc = pp_reserve(ctx, pp_align_up((size_t)nb * nchunk * row * sizeof(double), 256));

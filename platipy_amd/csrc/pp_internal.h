@@ -56,6 +56,12 @@ struct pp_ctx {
   char err[512];
 };
 
+// The PP_* measurement / debugging switches, as the process environment held them when the library first needed
+// one -- a snapshot, taken once (or again by pp_reload_switches): launchers never call getenv, which may race with a host
+// program writing its environment from another thread.  -> the value, or NULL when the variable was unset, is not a known
+// switch, or did not parse (numeric switches must be integers; a warning goes to stderr once).
+const char* pp_env(const char* name);
+
 // HIP-event bracket around one launch (no-ops while profiling is off).
 void pp_prof_begin(pp_ctx* ctx, const char* kernel_name);
 void pp_prof_end(pp_ctx* ctx);

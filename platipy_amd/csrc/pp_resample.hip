@@ -58,7 +58,7 @@ struct pp_band {
 };
 pp_band band_for(const pp_grid3& g, dim3* launch, bool wanted = true) {
   pp_band b{g.grid.x, g.grid.y, 0u, g.grid.x * g.grid.y};
-  const char* e = getenv("PP_RS_BAND");
+  const char* e = pp_env("PP_RS_BAND");
   const bool on = wanted && !(e && atoi(e) == 0);
   if (on && b.tiles >= 64u && (size_t)((b.tiles + 7u) / 8u) * 8u * g.grid.z < ((size_t)1 << 31)) {
     b.per = (b.tiles + 7u) / 8u;
@@ -609,7 +609,7 @@ rs_grid rs_grid_for(const pp_dims& d) {
   g.gx = (unsigned)((d.nx + RS_TX - 1) / RS_TX);
   g.gy = (unsigned)((d.ny + RS_TY - 1) / RS_TY);
   g.zc = 32;
-  const char* e = getenv("PP_RS_ZCHUNK");
+  const char* e = pp_env("PP_RS_ZCHUNK");
   if (e && atoi(e) > 0) g.zc = (unsigned)atoi(e);
   while (g.zc > 1 && (size_t)g.gx * g.gy * ((d.nz + g.zc - 1) / g.zc) < 4096) g.zc >>= 1;
   g.gz = (unsigned)((d.nz + g.zc - 1) / g.zc);
@@ -695,7 +695,7 @@ void fill_xform(const pp_geom* gin, const pp_geom* gout, const double* A, const 
   for (int k = 0; k < 3; ++k) X->t[k] = (A && t) ? t[k] : 0.0;
 }
 
-bool rs_generic_forced() { return getenv("PP_RESAMPLE_GENERIC") != nullptr; }
+bool rs_generic_forced() { return pp_env("PP_RESAMPLE_GENERIC") != nullptr; }
 rs_axes rs_axes_of(const pp_xform& X) {
   rs_axes a;
   for (int k = 0; k < 3; ++k) {
@@ -795,7 +795,7 @@ int pp_warp_same_grid(pp_ctx* ctx, const float* moving, const float* field, cons
   const bool vec4 = (d.nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(field) | reinterpret_cast<uintptr_t>(out)) % 16 == 0) && (N % 4 == 0);
   // preconditions of the straight-line sample (pp_warp_sample.h)
   const bool sl = N * sizeof(float) < ((size_t)1 << 32) && (size_t)d.ny * d.nz < ((size_t)1 << 24) && d.nx >= 2 && d.nx < (1 << 22) &&
-                  d.ny < (1 << 22) && d.nz < (1 << 22) && getenv("PP_WARP_LEGACY") == nullptr;
+                  d.ny < (1 << 22) && d.nz < (1 << 22) && pp_env("PP_WARP_LEGACY") == nullptr;
   if (vec4) {
     const pp_grid3 g3 = grid3_for(d.nx / 4, d.ny, d.nz);
     dim3 launch;
@@ -926,7 +926,7 @@ int pp_compose_field_f32(pp_ctx* ctx, float* total, const float* iter, const pp_
   // 64 x 4 blocks: a block's four rows share their upper / lower corner rows in L1 (sbench 0.99 -> 0.96 ms, config 2's
   // registration 15.69 -> 15.53 ms against 256 x 1; PP_COMPOSE_BLOCK=128|256 for the other shapes)
   unsigned bxm = 64u;
-  if (const char* e = getenv("PP_COMPOSE_BLOCK")) bxm = (unsigned)atoi(e) >= 64u ? (unsigned)atoi(e) : 64u;
+  if (const char* e = pp_env("PP_COMPOSE_BLOCK")) bxm = (unsigned)atoi(e) >= 64u ? (unsigned)atoi(e) : 64u;
   const pp_grid3 g3 = grid3_for(d.nx, d.ny, d.nz, bxm);
   dim3 launch;
   const pp_band B = band_for(g3, &launch);

@@ -13,6 +13,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: longer CPU test")
 
 
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """pytest's monkeypatch, plus: the library reads its PP_* switches from the environment ONCE (pp_env), so setting or
+    deleting one here re-takes the snapshot (pp_reload_switches), and so does the undo at the end of the test."""
+    from platipy_amd import _lib
+
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv_(name, value, prepend=None):
+        setenv(name, value, prepend)
+        if name.startswith("PP_"):
+            _lib.reload_switches()
+
+    def delenv_(name, raising=True):
+        delenv(name, raising)
+        if name.startswith("PP_"):
+            _lib.reload_switches()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv_, delenv_
+    yield monkeypatch
+    monkeypatch.undo()
+    _lib.reload_switches()
+
+
 @pytest.fixture(scope="session")
 def emu_backend():
     from tests.helpers import EmuBackend

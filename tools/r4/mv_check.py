@@ -16,9 +16,9 @@ bms = [bm0 + 0.5 * rng.standard_normal(3) for _ in range(16)]
 vsize, stride = (27, 23, 19), 2
 for metric in (0, 1):
     for n in (1, 3, 4, 7, 16):
-        os.environ["PP_METRIC_LANES"] = "0"
+        os.environ["PP_METRIC_LANES"] = "0"; _lib.reload_switches()
         a = ctx.metric_values_affine(metric, dF, fs, dM, ms, Af.ravel(), bf, Ams[:n], bms[:n], vsize, stride)
-        os.environ["PP_METRIC_LANES"] = "1"
+        os.environ["PP_METRIC_LANES"] = "1"; _lib.reload_switches()
         b = ctx.metric_values_affine(metric, dF, fs, dM, ms, Af.ravel(), bf, Ams[:n], bms[:n], vsize, stride)
         b2 = ctx.metric_values_affine(metric, dF, fs, dM, ms, Af.ravel(), bf, Ams[:n], bms[:n], vsize, stride)
         err = np.abs(a - b).max() / max(np.abs(a).max(), 1e-300)

@@ -15,7 +15,7 @@ shape, spacing, origin = (16, 20, 24), (1.5, 1.5, 2.5), (-30.0, -20.0, 10.0)
 fix, mov, _ = _rigid_pair(pa, shape, spacing, origin, angle=0.06, shift=(2.0, -1.5, 1.0))
 for method in ("scaleversor", "rigid", "affine"):
     for one in ("0", "1"):
-        os.environ["PP_METRIC_GRAD_ONE_LAUNCH"] = one
+        os.environ["PP_METRIC_GRAD_ONE_LAUNCH"] = one; _lib.reload_switches()
         out = {}
         for native in (True, False):
             linear.NATIVE_OPTIMISER = native
