@@ -438,6 +438,7 @@ struct fused_args {
   int per_xcd;      // ceil(gx * gy * gz / 8)
   int streaming;    // generation 2: non-temporal output stores (volumes far beyond the infinity cache)
   int masked;       // generation 2: the MASK kernels (even rows, a whole field under 2^31 bytes; pp_demons_fused2.h)
+  int big;          // generation 2: a 3-component field spans >= 2^32 bytes -- the BIG instances (64-bit bases for the field arrays)
   // generation 2, mixed tile shapes (SH == 2): region 0 = gx x gy tiles of 64 x 16 from x = 0, region 1 = gx2 x gy2 tiles of
   // 32 x 32 from x = x2_off (the columns a 64-wide tile would overhang by half or more); gx2 == 0: one shape only
   int gx2, gy2, x2_off;
@@ -1023,6 +1024,9 @@ int launch_warp(pp_ctx* ctx, int sh, const float* D, const float* Us, const floa
 #endif
 #define PP_A2_KERNEL(SHV, SUMV, NTV, MASKV) k_fused2_force_smooth<R, SHV, (R <= PP_RING_UNROLL_MAX_R), SUMV, NTV, MASKV>
 #define PP_B2_KERNEL(SHV, SUMV, NTV, MASKV) k_fused2_add_smooth_warp<R, SHV, (R <= PP_RING_UNROLL_MAX_R), SUMV, NTV, MASKV>
+// fields of >= 2^32 bytes (fused_args::big): SUM, streaming stores, branchy instances, 64-bit bases for the field arrays
+#define PP_A2_KERNEL_BIG(SHV) k_fused2_force_smooth<R, SHV, (R <= PP_RING_UNROLL_MAX_R), true, true, false, true>
+#define PP_B2_KERNEL_BIG(SHV) k_fused2_add_smooth_warp<R, SHV, (R <= PP_RING_UNROLL_MAX_R), true, true, false, true>
 #ifndef PP_MINI_MASK
 #define PP_MINI_MASK true
 #endif
@@ -1068,11 +1072,15 @@ int launch_force2(pp_ctx* ctx, int sh, bool sum, const float* F, const float* Mw
   const dim3 grid(8u * (unsigned)fu.per_xcd), block(512);
 #define PP_GO(SHV, SUMV, NTV, MASKV) \
   hipLaunchKernelGGL((PP_A2_KERNEL(SHV, SUMV, NTV, MASKV)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, st, prev, nprev, max_rms)
+#define PP_GO_BIG(SHV) \
+  hipLaunchKernelGGL((PP_A2_KERNEL_BIG(SHV)), grid, block, 0, ctx->stream, F, Mw_in, D, Us, fu, K, partials, st, prev, nprev, max_rms)
 #ifdef PP_MINI
   (void)sh;
   PP_GO(0, true, true, PP_MINI_MASK);
 #else
-  if (!sum) {   // (PP_FUSED_SUM=0, a measurement path: cached stores only)
+  if (fu.big) {
+    if (sh == 2) PP_GO_BIG(2); else if (sh) PP_GO_BIG(1); else PP_GO_BIG(0);
+  } else if (!sum) {   // (PP_FUSED_SUM=0, a measurement path: cached stores only)
     if (sh == 2) PP_GO(2, false, false, false); else if (sh) PP_GO(1, false, false, false); else PP_GO(0, false, false, false);
   } else if (fu.masked) {
     if (fu.streaming) { if (sh == 2) PP_GO(2, true, true, true); else if (sh) PP_GO(1, true, true, true); else PP_GO(0, true, true, true); }
@@ -1084,6 +1092,7 @@ int launch_force2(pp_ctx* ctx, int sh, bool sum, const float* F, const float* Mw
   }
 #endif
 #undef PP_GO
+#undef PP_GO_BIG
   return PP_OK;
 }
 template <int R>
@@ -1092,11 +1101,14 @@ int launch_warp2(pp_ctx* ctx, int sh, bool sum, const float* D, const float* Us,
   pp_prof_scope ps(ctx, sum ? "k_fused2_add_smooth_warp" : "k_fused2_add_smooth_warp/sep");
   const dim3 grid(8u * (unsigned)fd.per_xcd), block(512);
 #define PP_GO(SHV, SUMV, NTV, MASKV) hipLaunchKernelGGL((PP_B2_KERNEL(SHV, SUMV, NTV, MASKV)), grid, block, 0, ctx->stream, D, Us, M, Dn, Mw_out, fd, sc, halt)
+#define PP_GO_BIG(SHV) hipLaunchKernelGGL((PP_B2_KERNEL_BIG(SHV)), grid, block, 0, ctx->stream, D, Us, M, Dn, Mw_out, fd, sc, halt)
 #ifdef PP_MINI
   (void)sh;
   PP_GO(0, true, true, PP_MINI_MASK);
 #else
-  if (!sum) {
+  if (fd.big) {
+    if (sh == 2) PP_GO_BIG(2); else if (sh) PP_GO_BIG(1); else PP_GO_BIG(0);
+  } else if (!sum) {
     if (sh == 2) PP_GO(2, false, false, false); else if (sh) PP_GO(1, false, false, false); else PP_GO(0, false, false, false);
   } else if (fd.masked) {
     if (fd.streaming) { if (sh == 2) PP_GO(2, true, true, true); else if (sh) PP_GO(1, true, true, true); else PP_GO(0, true, true, true); }
@@ -1108,6 +1120,7 @@ int launch_warp2(pp_ctx* ctx, int sh, bool sum, const float* D, const float* Us,
   }
 #endif
 #undef PP_GO
+#undef PP_GO_BIG
   return PP_OK;
 }
 
@@ -1151,6 +1164,7 @@ void fused_grid(fused_args* f, const pp_dims& d, int occupancy, int sh, char ker
   // MASK instances: pairs must exist (even pitch), offsets must fit the buffer-resource trick -- and the volume must be large
   // enough to be throughput-bound: on the small pyramid levels every lane loading on every step costs more than exact waits
   // give (128 x 128 x 64 and 64 x 64 x 32: +7 %, profiles/round4_kbench_mask.txt; 512 x 512 x 256: -2.6 %; equal at 340 x 340 x 170).
+  f->big = 3 * (size_t)f->px * d.ny * d.nz * sizeof(float) >= ((size_t)1 << 32);   // (the BIG instances: pp_demons_fused2.h)
   f->masked = (f->px % 2 == 0) && 3 * (size_t)f->px * d.ny * d.nz * sizeof(float) < ((size_t)1 << 31) &&
               (size_t)d.nx * d.ny * d.nz >= ((size_t)8 << 20);
   if (const char* e = pp_env("PP_FUSED_MASK"))   // (0: the branchy kernels; 1: MASK wherever the shape allows -- A/B runs, tests)
@@ -1321,7 +1335,8 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   // kernel generation: 2 (pp_demons_fused2.h) unless the volume exceeds its 32-bit gather offsets / 24-bit row arithmetic,
   // rows are shorter than one strip, the 256-thread layout was asked for, or PP_FUSED_GEN=1 selects the first generation
   // (kept for A/B measurements).
-  const bool gen2_ok = 3 * N * sizeof(float) < ((size_t)1 << 32) &&   // (a whole 3-component field under one buffer resource)
+  // (a scalar image under one buffer resource's 32-bit offsets; a 3-component field beyond that takes the BIG instances)
+  const bool gen2_ok = N * sizeof(float) < ((size_t)1 << 32) &&
                        (size_t)d.ny * d.nz < ((size_t)1 << 24) && d.nx >= 4 && d.nx < (1 << 22) &&
                        d.ny < (1 << 22) && d.nz < (1 << 22);   // (every axis below the warp's 2^23-voxel displacement clamp)
   int gen = (gen2_ok && opt == 2) ? 2 : 1;
@@ -1330,13 +1345,15 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   }
   // (the second generation needs > 128 registers for kernel A from radius 4 -- sigma_u = 1 voxel gives radius 2 -- and for
   // kernel B at radius 5, i.e. voxels under 0.55 mm: measured slower than the first generation there)
-  const int gen_a = (gen == 2 && ra <= 3) ? 2 : 1, gen_b = (gen == 2 && rb <= 4) ? 2 : 1;
+  int gen_a = (gen == 2 && ra <= 3) ? 2 : 1, gen_b = (gen == 2 && rb <= 4) ? 2 : 1;
   // both kernels of generation 2: kernel A stores D + G_u * update and kernel B reads that one volume (three halo'd arrays
   // instead of six; the add itself is unchanged, so the fields are bit-identical).  PP_FUSED_SUM=0 keeps them apart.
   bool sum_mode = gen_a == 2 && gen_b == 2;
   if (const char* e = pp_env("PP_FUSED_SUM")) {
     if (atoi(e) == 0) sum_mode = false;
   }
+  // fields of >= 2^32 bytes: generation 2 serves them through its BIG instances, which exist for the SUM pair only
+  if (3 * N * sizeof(float) >= ((size_t)1 << 32) && !sum_mode) gen_a = gen_b = 1;
   const int opt_a = ra > 3 ? 2 : opt, opt_b = rb > 3 ? 2 : opt;   // radii 4 and 5 exist in the 512-thread layout only
   fused_args fu, fd;
   int sh_a = 0, sh_b = 0;
@@ -1351,7 +1368,7 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   // dense volume must also hold on the padded one -- e.g. 709 x 709 x 711 passes dense and wraps at px = 712 -- else dense rows)
   if (pitched) {
     const size_t pxc = (size_t)(d.nx + 3) / 4 * 4;
-    if (!(3 * pxc * d.ny * d.nz * sizeof(float) < ((size_t)1 << 32) && pxc * sizeof(float) < ((size_t)1 << 24))) pitched = false;
+    if (!(pxc * d.ny * d.nz * sizeof(float) < ((size_t)1 << 32) && pxc * sizeof(float) < ((size_t)1 << 24))) pitched = false;
   }
   const int px = pitched ? (d.nx + 3) / 4 * 4 : d.nx;
   const size_t Np = (size_t)px * d.ny * d.nz;

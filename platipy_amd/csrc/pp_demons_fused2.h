@@ -745,7 +745,10 @@ struct fused2_warp_lds {
 };
 // The kernel's body for ONE tile shape (SH 0 / 1); `smem` = the block's LDS (fused2_warp_lds<R, SH, SUM>::N floats), `region`:
 // fused_tile.  The __global__ wrapper below owns the LDS and, in a mixed launch, picks the shape per block.
-template <int R, int SH, bool UNROLL, bool SUM, bool NT, bool MASK>
+// BIG: the three-component field arrays span >= 2^32 bytes (e.g. 512 x 512 x 1400): their component / plane offsets no longer fit
+// the scalar-offset operand of ONE resource per array, so those accesses rebuild a resource from a 64-bit base per component and
+// plane (the PP_SOFF = 0 form); the scalar images (< 2^32 bytes each: checked on the host) keep theirs.
+template <int R, int SH, bool UNROLL, bool SUM, bool NT, bool MASK, bool BIG = false>
 __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, const float* __restrict__ Us, const float* __restrict__ M,
                                                  float* __restrict__ Dn, float* __restrict__ Mw, const fused_args& a,
                                                  const pp_warp_scale& sc, const int* __restrict__ halt, float* const smem,
@@ -753,6 +756,8 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
   using G = strip_geom<R, SH, 0>;
   constexpr int NTH = G::NTH, TX = G::TX, TY = G::TY, W = 2 * R + 1;
   constexpr bool XS = (PP_B_XSHFL != 0) && SUM;   // x pass in registers (wavefront shuffles), y-pass buffer double-buffered
+  constexpr bool SOFF_F = (PP_SOFF != 0) && !BIG, SOFF_S = (PP_SOFF != 0);   // scalar-offset addressing of field / scalar arrays
+  static_assert(!(BIG && MASK), "the MASK instances keep whole arrays under 2^31 bytes");
   float* const s_x = smem;
   float* const s_u = smem + G::SZ_X;   // (XS: the second y-pass buffer)
   if (halt && *halt) return;
@@ -977,7 +982,7 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
       if (UNC || pair_ok) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          if constexpr (PP_SOFF != 0) pp_bst2ss<NT>(r_dn, o_st, c * N4 + po4, dn[c][0], dn[c][1]);
+          if constexpr (SOFF_F) pp_bst2ss<NT>(r_dn, o_st, c * N4 + po4, dn[c][0], dn[c][1]);
           else pp_bst2s<NT>(pp_make_rsrc(Dn + c * N + po), o_st, dn[c][0], dn[c][1]);
         }
       } else if (x + 1 < d.nx) {   // odd row length: pairs at 4-byte alignment
@@ -986,19 +991,19 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
       } else {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          if constexpr (PP_SOFF != 0) pp_bsts(r_dn, o_xy, c * N4 + po4, dn[c][0]);
+          if constexpr (SOFF_F) pp_bsts(r_dn, o_xy, c * N4 + po4, dn[c][0]);
           else pp_bst(pp_make_rsrc(Dn + c * N + po), o_xy, dn[c][0]);
         }
       }
     };
     auto store_image = [&]() {
       if (UNC || pair_ok) {
-        if constexpr (PP_SOFF != 0) pp_bst2ss<NT>(r_mw, o_st, po4, mw0, mw1);
+        if constexpr (SOFF_S) pp_bst2ss<NT>(r_mw, o_st, po4, mw0, mw1);
         else pp_bst2s<NT>(pp_make_rsrc(Mw + po), o_st, mw0, mw1);
       } else if (x + 1 < d.nx) {
         pp_gst2(reinterpret_cast<char*>(Mw + po), o_xy, mw0, mw1);
       } else {
-        if constexpr (PP_SOFF != 0) pp_bsts(r_mw, o_xy, po4, mw0);
+        if constexpr (SOFF_S) pp_bsts(r_mw, o_xy, po4, mw0);
         else pp_bst(pp_make_rsrc(Mw + po), o_xy, mw0);
       }
     };
@@ -1059,7 +1064,7 @@ __device__ __forceinline__ void fused2_warp_body(const float* __restrict__ D, co
 
 // SH 0 / 1: every tile of that shape.  SH 2: tiles of both shapes in one launch (fused_args: gx2 > 0) -- 64 x 16 wherever a
 // whole 64-wide tile fits, 32 x 32 over the remaining columns -- with the LDS of the larger carve.
-template <int R, int SH, bool UNROLL, bool SUM, bool NT, bool MASK>
+template <int R, int SH, bool UNROLL, bool SUM, bool NT, bool MASK, bool BIG = false>
 __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(const float* __restrict__ D, const float* __restrict__ Us,
                                                                             const float* __restrict__ M, float* __restrict__ Dn,
                                                                             float* __restrict__ Mw, fused_args a, pp_warp_scale sc,
@@ -1067,11 +1072,11 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_add_smooth_warp(c
   if constexpr (SH == 2) {
     constexpr int N0 = fused2_warp_lds<R, 0, SUM>::N, N1 = fused2_warp_lds<R, 1, SUM>::N;
     __shared__ __attribute__((aligned(16))) float smem[N0 > N1 ? N0 : N1];
-    if (fused_region(a) == 0) fused2_warp_body<R, 0, UNROLL, SUM, NT, MASK>(D, Us, M, Dn, Mw, a, sc, halt, smem, 0);
-    else fused2_warp_body<R, 1, UNROLL, SUM, NT, MASK>(D, Us, M, Dn, Mw, a, sc, halt, smem, 1);
+    if (fused_region(a) == 0) fused2_warp_body<R, 0, UNROLL, SUM, NT, MASK, BIG>(D, Us, M, Dn, Mw, a, sc, halt, smem, 0);
+    else fused2_warp_body<R, 1, UNROLL, SUM, NT, MASK, BIG>(D, Us, M, Dn, Mw, a, sc, halt, smem, 1);
   } else {
     __shared__ __attribute__((aligned(16))) float smem[fused2_warp_lds<R, SH, SUM>::N];
-    fused2_warp_body<R, SH, UNROLL, SUM, NT, MASK>(D, Us, M, Dn, Mw, a, sc, halt, smem, 0);
+    fused2_warp_body<R, SH, UNROLL, SUM, NT, MASK, BIG>(D, Us, M, Dn, Mw, a, sc, halt, smem, 0);
   }
 }
 
@@ -1137,7 +1142,7 @@ struct fused2_force_lds {
   static constexpr int SZ_XT = 3 * G::UH * fused2_xtile<SH>::XP;     // x-pass tile (>= G::SZ_X: the row pitch may be padded)
 };
 // The kernel's body for ONE tile shape; the three LDS objects come from the __global__ wrapper below (as for kernel B).
-template <int R, int SH, bool UNROLL, bool SUM, bool NT, bool MASK>
+template <int R, int SH, bool UNROLL, bool SUM, bool NT, bool MASK, bool BIG = false>   // (BIG: as in fused2_warp_body)
 __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, const float* __restrict__ Mw, const float* __restrict__ D,
                                                   float* __restrict__ Us, const fused_args& a, const pp_esm_consts& K,
                                                   double* __restrict__ partials, pp_dev_stats* __restrict__ st,
@@ -1146,6 +1151,8 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
   using G = fused_geom<R, 2, SH>;
   constexpr int NTH = G::NTH, TX = G::TX, TY = G::TY, W = 2 * R + 1;
   constexpr int NXI = (3 * G::XI + NTH - 1) / NTH;
+  constexpr bool SOFF_F = (PP_SOFF != 0) && !BIG, SOFF_S = (PP_SOFF != 0);
+  static_assert(!(BIG && MASK), "the MASK instances keep whole arrays under 2^31 bytes");
   float* const smem = s_u;   // (the reduction scratch of the prologue: 3 * 8 doubles)
   if (st->halt) return;   // (written by an earlier launch)
   // End of the PREVIOUS iteration, folded into this launch instead of a one-block kernel of its own (k_demons_finalize:
@@ -1299,7 +1306,7 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
     }
 #endif
     const size_t p2 = (size_t)pp_clampi(zc + 2, 0, d.nz - 1) * sz, p1 = (size_t)pp_clampi(zc + 1, 0, d.nz - 1) * sz;
-    if constexpr (PP_SOFF != 0) {
+    if constexpr (SOFF_S) {
       const unsigned s2 = (unsigned)p2 * 4u, s1 = (unsigned)p1 * 4u;
 #pragma unroll
       for (int k = 0; k < G::KU; ++k) {
@@ -1451,7 +1458,7 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
       const size_t po = (size_t)zo * sz;
 #pragma unroll
       for (int c = 0; c < (SUM ? 3 : 1); ++c) {   // two 4-byte buffer loads: no alignment case, no branch (x + 1 == nx re-reads x)
-        if constexpr (PP_SOFF != 0) {
+        if constexpr (SOFF_F) {
           const unsigned so = ((unsigned)c * (unsigned)N + (unsigned)po) * 4u;
           dsum[c].x = pp_blds(r_d, o_xy, so);
           dsum[c].y = pp_blds(r_d, o_xy1, so);
@@ -1569,7 +1576,7 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
       }
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        if constexpr (PP_SOFF != 0) {
+        if constexpr (SOFF_F) {
           const unsigned so = ((unsigned)c * (unsigned)N + (unsigned)po) * 4u;
           if (ST || pair_ok) {
             pp_bst2ss<NT>(r_us, o_xy, so, us[c][0], us[c][1]);
@@ -1625,7 +1632,7 @@ __device__ __forceinline__ void fused2_force_body(const float* __restrict__ F, c
 // SH 0 / 1 / 2 as for kernel B.  (Three LDS objects, not one carved array: the compiler may then move the image-tile reads of
 // one ESM round above the update stores of the previous one -- as slices of one array it must keep them in order, and each
 // wave pays the LDS round trip once per round.)
-template <int R, int SH, bool UNROLL, bool SUM, bool NT, bool MASK>
+template <int R, int SH, bool UNROLL, bool SUM, bool NT, bool MASK, bool BIG = false>
 __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(const float* __restrict__ F, const float* __restrict__ Mw,
                                                                          const float* __restrict__ D, float* __restrict__ Us,
                                                                          fused_args a, pp_esm_consts K,
@@ -1637,13 +1644,13 @@ __global__ void __launch_bounds__(512, PP_GEN2_WAVES) k_fused2_force_smooth(cons
     __shared__ __attribute__((aligned(16))) float2 s_mf_[(L0::SZ_IMG2 > L1::SZ_IMG2 ? L0::SZ_IMG2 : L1::SZ_IMG2) / 2];
     __shared__ __attribute__((aligned(16))) float s_u_[L0::SZ_U > L1::SZ_U ? L0::SZ_U : L1::SZ_U];
     __shared__ __attribute__((aligned(16))) float s_x_[L0::SZ_XT > L1::SZ_XT ? L0::SZ_XT : L1::SZ_XT];
-    if (fused_region(a) == 0) fused2_force_body<R, 0, UNROLL, SUM, NT, MASK>(F, Mw, D, Us, a, K, partials, st, prev, nprev, max_rms, s_mf_, s_u_, s_x_, 0);
-    else fused2_force_body<R, 1, UNROLL, SUM, NT, MASK>(F, Mw, D, Us, a, K, partials, st, prev, nprev, max_rms, s_mf_, s_u_, s_x_, 1);
+    if (fused_region(a) == 0) fused2_force_body<R, 0, UNROLL, SUM, NT, MASK, BIG>(F, Mw, D, Us, a, K, partials, st, prev, nprev, max_rms, s_mf_, s_u_, s_x_, 0);
+    else fused2_force_body<R, 1, UNROLL, SUM, NT, MASK, BIG>(F, Mw, D, Us, a, K, partials, st, prev, nprev, max_rms, s_mf_, s_u_, s_x_, 1);
   } else {
     using L = fused2_force_lds<R, SH>;
     __shared__ __attribute__((aligned(16))) float2 s_mf_[L::SZ_IMG2 / 2];
     __shared__ __attribute__((aligned(16))) float s_u_[L::SZ_U];
     __shared__ __attribute__((aligned(16))) float s_x_[L::SZ_XT];
-    fused2_force_body<R, SH, UNROLL, SUM, NT, MASK>(F, Mw, D, Us, a, K, partials, st, prev, nprev, max_rms, s_mf_, s_u_, s_x_, 0);
+    fused2_force_body<R, SH, UNROLL, SUM, NT, MASK, BIG>(F, Mw, D, Us, a, K, partials, st, prev, nprev, max_rms, s_mf_, s_u_, s_x_, 0);
   }
 }
