@@ -318,6 +318,13 @@ int pp_linear_set_sample_jitter(pp_ctx* ctx, const float* jitter, size_t nsample
  * [3][Z][Y][X] of the moving image's size `msize`, converted to moving-INDEX units (d intensity / d index); NULL restores the
  * interpolant's analytic gradient (the default).  Built by the host from pp_recursive_gaussian_pass_f32. */
 int pp_linear_set_moving_gradient(pp_ctx* ctx, const float* gradient, const int msize[3]);
+/* Optional companion of the image above for the value + gradient kernel (pp_meansq_affine_f32 / pp_corr_moments_affine_f32 and
+ * through them pp_linear_optimize_f32): the SAME gradient image packed with the moving image's intensity, [Z][Y][X][4] =
+ * (gx, gy, gz, m) per voxel, 16-byte aligned (device, caller-owned, valid until replaced).  With ITK's jittered sample points
+ * every sample has its own rows; one 16-byte element per corner is 8 gathers and ~0.25 KB of cache sectors a sample where the
+ * planar images cost 32 and ~1 KB.  Results are bit-identical.  Call after pp_linear_set_moving_gradient (which clears it);
+ * NULL removes it.  (No reference counterpart: a layout of this build.) */
+int pp_linear_set_moving_gradient_packed(pp_ctx* ctx, const float* packed);
 
 /* Mutual-information metrics (SetMetricAsMattesMutualInformation / SetMetricAsJointHistogramMutualInformation,
  * registration/linear.py:145-148) over the same sample lattice: pass 1 returns the joint intensity histogram of the valid

@@ -149,6 +149,7 @@ _SIGNATURES = {
                                               C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(C.c_double)]),
     "pp_linear_set_sample_jitter": (C.c_int, [_P, _P, C.c_size_t]),
     "pp_linear_set_moving_gradient": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
+    "pp_linear_set_moving_gradient_packed": (C.c_int, [_P, _P]),
     "pp_recursive_gaussian_pass_f32": (C.c_int, [_P, _P, _P, C.POINTER(Geom), C.c_int, C.c_double, C.c_int, C.c_int]),
     "pp_mi_histogram_f32": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, _P, _P, C.POINTER(MiBins),
@@ -486,10 +487,12 @@ class Context:
             self._chk(self.lib.pp_linear_set_sample_jitter(self.h, ptr(jitter), int(jitter.shape[0])), "pp_linear_set_sample_jitter")
         self._sample_jitter = jitter
 
-    def set_moving_gradient(self, gradient, msize=None):
+    def set_moving_gradient(self, gradient, msize=None, packed=None):
         """ITK's filtered gradient image for the gradient-bearing metric entry points (pp_linear_set_moving_gradient): a
         contiguous float32 device tensor [3, Z, Y, X] in moving-index units, kept alive by this context until replaced; None
-        restores the interpolant's analytic gradient."""
+        restores the interpolant's analytic gradient.  `packed`: optionally the same image with the intensity, float32
+        [Z, Y, X, 4] = (gx, gy, gz, m) (pp_linear_set_moving_gradient_packed)."""
+        self._moving_gradient_packed = None
         if gradient is None:
             self._chk(self.lib.pp_linear_set_moving_gradient(self.h, None, None), "pp_linear_set_moving_gradient")
         else:
@@ -498,6 +501,11 @@ class Context:
                 raise ValueError("set_moving_gradient: a float32 array [3, Z, Y, X]")
             size = msize if msize is not None else (shape[3], shape[2], shape[1])
             self._chk(self.lib.pp_linear_set_moving_gradient(self.h, ptr(gradient), _i3(size)), "pp_linear_set_moving_gradient")
+            if packed is not None:
+                if tuple(packed.shape) != shape[1:] + (4,) or str(packed.dtype).replace("torch.", "") != "float32":
+                    raise ValueError("set_moving_gradient: `packed` must be a float32 array [Z, Y, X, 4]")
+                self._chk(self.lib.pp_linear_set_moving_gradient_packed(self.h, ptr(packed)), "pp_linear_set_moving_gradient_packed")
+                self._moving_gradient_packed = packed
         self._moving_gradient = gradient
 
     def recursive_gaussian_pass(self, src, dst, geom, axis, sigma, order=0, normalize_across_scale=False):

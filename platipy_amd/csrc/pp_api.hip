@@ -98,6 +98,7 @@ constexpr pp_switch_def SWITCHES[] = {
     {"PP_FUSED_OPT", true},       {"PP_FUSED_PITCH", true},    {"PP_FUSED_SUM", true},     {"PP_FUSED_SYNC", true},
     {"PP_FUSED_TILE", true},      {"PP_FUSED_ZCHUNK", true},   {"PP_FUSED_ZCHUNK_A", true}, {"PP_FUSED_ZCHUNK_B", true},
     {"PP_GAUSS3", true},          {"PP_METRIC_BLOCKS", true},  {"PP_METRIC_GRAD_ONE_LAUNCH", true}, {"PP_METRIC_LANES", true},
+    {"PP_METRIC_GRAD_PLANAR", false},
     {"PP_NO_FIXED_SAMPLES", false}, {"PP_POISON_WS", false},   {"PP_RESAMPLE_GENERIC", false}, {"PP_RG_GRID", true},
     {"PP_RG_SEG_V1", false},      {"PP_RG_TWO_SWEEP", false},  {"PP_RS_BAND", true},       {"PP_RS_ZCHUNK", true},
     {"PP_WARP_LEGACY", false},

@@ -240,6 +240,7 @@ struct msq_args {
   int stride;
   const float* jit;   // ITK's per-sample jitter in virtual-index units, 3 floats per sample, or NULL (pp_linear_set_sample_jitter)
   const float* grad;  // ITK's filtered gradient image of the moving image, 3 volumes in moving-INDEX units, or NULL (pp_linear_set_moving_gradient)
+  const float4* grad4;  // the same image PACKED with the intensity, (gx, gy, gz, m) per voxel, or NULL (pp_linear_set_moving_gradient_packed)
 };
 
 // itk::ImageRegistrationMethodv4::SetMetricSamplePoints (REGULAR): every sample point is the lattice voxel's physical point
@@ -973,15 +974,19 @@ struct mg_corners {
   float a000, a100, a010, a110, a001, a101, a011, a111;
   float wx, wy, wz;
 };
-// GI: the moving-image gradient is sampled from ITK's filtered gradient image (msq_args::grad) instead of being derived from the
+// GI 1: the moving-image gradient is sampled from ITK's filtered gradient image (msq_args::grad) instead of being derived from the
 // eight intensity corners -- its own instance, so that the default path keeps its registers.
-template <int MODE, bool GI = false>
+// GI 2: the same from the PACKED image (msq_args::grad4: gradient and intensity of a voxel in one 16-byte element): eight gathers a
+// sample instead of thirty-two, and a quarter of the cache sectors -- with ITK's jittered sample points every sample has its
+// own rows, the planar form fetched ~0.75 KB of sectors per sample and ran at the cache-miss rate (profiles/round6_linear_pmc.md:
+// 80 % L2 misses, 138 us at the 128 x 128 x 64 lattice).  Same interpolation arithmetic, so the same bits.
+template <int MODE, int GI = 0>
 __global__ void __launch_bounds__(NT) k_metric_grad(const float* __restrict__ F, pp_dims df, const float* __restrict__ M, pp_dims dm,
                                                     const uint8_t* __restrict__ fmask, const uint8_t* __restrict__ mmask, msq_args a,
                                                     double* partials /* [grid][NACC] */, unsigned* __restrict__ ticket, void* mailbox,
                                                     unsigned long long seq, const float* __restrict__ fsamp) {
   constexpr int NACC = MODE == 0 ? 14 : 42;
-  constexpr int G = MODE == 0 ? 4 : 2;          // samples in flight per thread
+  constexpr int G = (MODE == 0 && GI != 2) ? 4 : 2;   // samples in flight per thread (packed corners are four registers each)
   constexpr int NPARTS = NT / NACC;
   __shared__ double red[(NT / 64 > NPARTS ? NT / 64 : NPARTS) * NACC];
   __shared__ int is_last;
@@ -999,6 +1004,7 @@ __global__ void __launch_bounds__(NT) k_metric_grad(const float* __restrict__ F,
     float fval[G];
     bool ok[G];
     float gimg[GI ? G : 1][3];
+    float4 q[GI == 2 ? G : 1][GI == 2 ? 8 : 1];
 #pragma unroll
     for (int j = 0; j < G; ++j) {
       const size_t eq = e0 + (size_t)j * nthr;
@@ -1047,11 +1053,41 @@ __global__ void __launch_bounds__(NT) k_metric_grad(const float* __restrict__ F,
       pp_axis_setup(bm_[0], fm[0], dm.nx, x0, x1, g[j].wx);
       pp_axis_setup(bm_[1], fm[1], dm.ny, y0, y1, g[j].wy);
       pp_axis_setup(bm_[2], fm[2], dm.nz, z0, z1, g[j].wz);
-      g[j].a000 = M[z0 * sz + y0 * sy + x0]; g[j].a100 = M[z0 * sz + y0 * sy + x1];
-      g[j].a010 = M[z0 * sz + y1 * sy + x0]; g[j].a110 = M[z0 * sz + y1 * sy + x1];
-      g[j].a001 = M[z1 * sz + y0 * sy + x0]; g[j].a101 = M[z1 * sz + y0 * sy + x1];
-      g[j].a011 = M[z1 * sz + y1 * sy + x0]; g[j].a111 = M[z1 * sz + y1 * sy + x1];
-      if constexpr (GI) msq_gradient_image(a.grad, dm, x0, x1, y0, y1, z0, z1, g[j].wx, g[j].wy, g[j].wz, gimg[j]);
+      if constexpr (GI == 2) {
+        const float4* const P = a.grad4;
+        q[j][0] = P[z0 * sz + y0 * sy + x0]; q[j][1] = P[z0 * sz + y0 * sy + x1];
+        q[j][2] = P[z0 * sz + y1 * sy + x0]; q[j][3] = P[z0 * sz + y1 * sy + x1];
+        q[j][4] = P[z1 * sz + y0 * sy + x0]; q[j][5] = P[z1 * sz + y0 * sy + x1];
+        q[j][6] = P[z1 * sz + y1 * sy + x0]; q[j][7] = P[z1 * sz + y1 * sy + x1];
+      } else {
+        g[j].a000 = M[z0 * sz + y0 * sy + x0]; g[j].a100 = M[z0 * sz + y0 * sy + x1];
+        g[j].a010 = M[z0 * sz + y1 * sy + x0]; g[j].a110 = M[z0 * sz + y1 * sy + x1];
+        g[j].a001 = M[z1 * sz + y0 * sy + x0]; g[j].a101 = M[z1 * sz + y0 * sy + x1];
+        g[j].a011 = M[z1 * sz + y1 * sy + x0]; g[j].a111 = M[z1 * sz + y1 * sy + x1];
+      }
+      if constexpr (GI == 1) msq_gradient_image(a.grad, dm, x0, x1, y0, y1, z0, z1, g[j].wx, g[j].wy, g[j].wz, gimg[j]);
+    }
+    if constexpr (GI == 2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_sched_barrier(0);   // every corner request before the first interpolation
+#endif
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        g[j].a000 = q[j][0].w; g[j].a100 = q[j][1].w; g[j].a010 = q[j][2].w; g[j].a110 = q[j][3].w;
+        g[j].a001 = q[j][4].w; g[j].a101 = q[j][5].w; g[j].a011 = q[j][6].w; g[j].a111 = q[j][7].w;
+        const float wx = g[j].wx, wy = g[j].wy, wz = g[j].wz;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {   // msq_gradient_image's lerps on the packed corners
+          const float a000 = r == 0 ? q[j][0].x : (r == 1 ? q[j][0].y : q[j][0].z), a100 = r == 0 ? q[j][1].x : (r == 1 ? q[j][1].y : q[j][1].z);
+          const float a010 = r == 0 ? q[j][2].x : (r == 1 ? q[j][2].y : q[j][2].z), a110 = r == 0 ? q[j][3].x : (r == 1 ? q[j][3].y : q[j][3].z);
+          const float a001 = r == 0 ? q[j][4].x : (r == 1 ? q[j][4].y : q[j][4].z), a101 = r == 0 ? q[j][5].x : (r == 1 ? q[j][5].y : q[j][5].z);
+          const float a011 = r == 0 ? q[j][6].x : (r == 1 ? q[j][6].y : q[j][6].z), a111 = r == 0 ? q[j][7].x : (r == 1 ? q[j][7].y : q[j][7].z);
+          const float v00 = a000 + (a100 - a000) * wx, v10 = a010 + (a110 - a010) * wx;
+          const float v01 = a001 + (a101 - a001) * wx, v11 = a011 + (a111 - a011) * wx;
+          const float v0 = v00 + (v10 - v00) * wy, v1 = v01 + (v11 - v01) * wy;
+          gimg[j][r] = v0 + (v1 - v0) * wz;
+        }
+      }
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     // every corner request before the first interpolation (see k_metric_values_lanes)
@@ -1624,6 +1660,8 @@ static int metric_affine(pp_ctx* ctx, int mode, const float* fixed, const int fs
     if (jrc) return jrc;
     const int grc = pp_gradient_for(ctx, msize, &a.grad);
     if (grc) return grc;
+    // (the packed companion is set together with the planar image, for the same moving image: pp_gradient_for has checked the size)
+    a.grad4 = (a.grad && ctx->mgrad4 && !pp_env("PP_METRIC_GRAD_PLANAR")) ? reinterpret_cast<const float4*>(ctx->mgrad4) : nullptr;
   }
   const pp_dims df{fsize[0], fsize[1], fsize[2]}, dm{msize[0], msize[1], msize[2]};
   const unsigned nb = grid_for(nsamp, 512u);   // (256 measures the same, 128 slower: profiles/round3_metric_probe_latency.txt)
@@ -1645,8 +1683,9 @@ static int metric_affine(pp_ctx* ctx, int mode, const float* fixed, const int fs
 #define PP_MG_GO(MODEV, GIV)                                                                                                              \
   hipLaunchKernelGGL((k_metric_grad<MODEV, GIV>), dim3(nb), dim3(NT), 0, ctx->stream, fixed, df, moving, dm, fixed_mask, moving_mask, a, \
                      partials, ticket, mail1, seq1, fsamp)
-    if (a.grad) { if (mode == 0) PP_MG_GO(0, true); else PP_MG_GO(1, true); }
-    else { if (mode == 0) PP_MG_GO(0, false); else PP_MG_GO(1, false); }
+    if (a.grad4) { if (mode == 0) PP_MG_GO(0, 2); else PP_MG_GO(1, 2); }
+    else if (a.grad) { if (mode == 0) PP_MG_GO(0, 1); else PP_MG_GO(1, 1); }
+    else { if (mode == 0) PP_MG_GO(0, 0); else PP_MG_GO(1, 0); }
 #undef PP_MG_GO
     PP_LAUNCH_CHECK(ctx, "k_metric_grad");
     return pp_mail_take(ctx, 0, nacc, seq1, result);
@@ -1876,7 +1915,16 @@ int pp_linear_set_moving_gradient(pp_ctx* ctx, const float* gradient, const int 
   if (!ctx) return PP_ERR_ARG;
   PP_REQUIRE(ctx, gradient == nullptr || msize != nullptr, "pp_linear_set_moving_gradient: a gradient image needs the moving image's size");
   ctx->mgrad = gradient;
+  ctx->mgrad4 = nullptr;   // (a packed companion belongs to ONE planar image: set it after this call)
   for (int k = 0; k < 3; ++k) ctx->mgrad_size[k] = gradient ? msize[k] : 0;
+  return PP_OK;
+}
+
+int pp_linear_set_moving_gradient_packed(pp_ctx* ctx, const float* packed) {
+  if (!ctx) return PP_ERR_ARG;
+  PP_REQUIRE(ctx, packed == nullptr || ctx->mgrad != nullptr, "pp_linear_set_moving_gradient_packed: set the planar gradient image first");
+  PP_REQUIRE(ctx, reinterpret_cast<uintptr_t>(packed) % 16 == 0, "pp_linear_set_moving_gradient_packed: the packed image must be 16-byte aligned");
+  ctx->mgrad4 = packed;
   return PP_OK;
 }
 

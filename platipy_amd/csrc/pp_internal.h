@@ -53,6 +53,9 @@ struct pp_ctx {
   // voxels in moving-index units, NULL = the interpolant's analytic gradient.
   const float* mgrad;
   int mgrad_size[3];
+  // ... and its packed companion (pp_linear_set_moving_gradient_packed): (gx, gy, gz, intensity) per voxel of the SAME moving image,
+  // what the value + gradient kernel gathers from when it is set (a quarter of the cache sectors per sample)
+  const float* mgrad4;
   char err[512];
 };
 

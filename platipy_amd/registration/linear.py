@@ -606,6 +606,8 @@ class ItkRegularJitter:
         return np.ascontiguousarray((phys @ p2i.T).astype(np.float32))
 
 
+PACKED_GRADIENT_MIN_SAMPLES = 200_000
+
 _JITTER_CACHE = {}      # (device, seed, levels so far) -> device tensor; a handful of entries, oldest dropped first
 _JITTER_CACHE_MAX = 16
 _JITTER_LOCK = threading.Lock()
@@ -707,8 +709,19 @@ def _optimise_levels(ctx, jitter, fixed_image, moving_image, fixed_mask, moving_
             key = id(m_l.tensor)
             if key not in gradient_of:
                 gradient_of.clear()
-                gradient_of[key] = (m_l.tensor, itk_moving_gradient(ctx, m_l))     # (the image is kept: its id stays its own)
-            ctx.set_moving_gradient(gradient_of[key][1])
+                grad = itk_moving_gradient(ctx, m_l)
+                # the value + gradient kernel of the mean-squares / correlation metrics gathers (gradient, intensity) as ONE
+                # 16-byte element per corner (pp_linear_set_moving_gradient_packed); the MI kernels read the planar image
+                # -- when some level's lattice is large enough for the layout to pay for the 2 GB copy that builds it (measured at
+                # 512 x 512 x 256: the 128 x 128 x 64 lattice's gradient launch 138 -> 60 us; lattices of 64 x 64 x 32 gain less
+                # than the ~1 ms copy)
+                packed = None
+                largest = max(int(np.prod(_shrink_geometry(fixed_image, f)[0])) for f in shrink_factors) / max(1, ms.stride)
+                if metric in ("mean_squares", "correlation") and grad.is_cuda and largest >= PACKED_GRADIENT_MIN_SAMPLES:
+                    src = m_l.tensor if m_l.tensor.dtype == torch.float32 else m_l.tensor.float()
+                    packed = torch.stack((grad[0], grad[1], grad[2], src), dim=-1)      # [Z, Y, X, 4], one copy kernel
+                gradient_of[key] = (m_l.tensor, grad, packed)     # (the image is kept: its id stays its own)
+            ctx.set_moving_gradient(gradient_of[key][1], packed=gradient_of[key][2])
 
         if opt == "lbfgsb":
             from scipy.optimize import fmin_l_bfgs_b

@@ -719,6 +719,16 @@ def test_itk_gradient_image_kernels_match_the_oracle(backend):
         gc = np.array(ctx.corr_moments_affine(*args))
         wc = L.corr_moments_affine(F, M, Af, bf, Am, bm, vsize, stride, moving_gradient=want_gi)
         np.testing.assert_allclose(gc, wc, rtol=3e-4, atol=1e-3 * np.abs(wc).max())
+        # the PACKED companion (gradient and intensity of a voxel in one 16-byte element; round 6): same corners, same lerps ->
+        # the same sums.  (A thread takes two samples at a time from the packed image and four from the planar ones, so its
+        # partial sums associate differently: equal to 1e-12 relative, not bit for bit.)
+        packed = backend.dev(np.ascontiguousarray(np.concatenate([np.moveaxis(want_gi, 0, -1), M[..., None]], axis=-1).astype(np.float32)))
+        ctx.set_moving_gradient(dev_gi, (17, 13, 12), packed=packed)
+        gp, cp = np.array(ctx.meansq_affine(*args)), np.array(ctx.corr_moments_affine(*args))
+        assert gp[1] == got[1]
+        np.testing.assert_allclose(gp, got, rtol=1e-12, atol=1e-12 * np.abs(got).max())
+        np.testing.assert_allclose(cp, gc, rtol=1e-12, atol=1e-12 * np.abs(gc).max())
+        ctx.set_moving_gradient(dev_gi, (17, 13, 12))
         with pytest.raises(_lib.PlatipyAmdError):          # a gradient image of another size than the moving image's
             ctx.meansq_affine(backend.dev(F), (18, 14, 10), backend.dev(F), (18, 14, 10), Af.ravel(), bf, Am.ravel(), bm, vsize, stride)
     finally:
