@@ -13,7 +13,6 @@ import sys
 import numpy as np
 import torch
 from scipy.optimize import curve_fit
-from scipy.stats import norm as scipy_norm
 
 from .. import runtime
 from ..image import as_image
@@ -26,8 +25,19 @@ def median_absolute_deviation(data, axis=None):
     return np.median(np.abs(data - np.median(data, axis=axis)), axis=axis)
 
 
+_NORM_PDF_C = np.sqrt(2 * np.pi)
+
+
 def gaussian_curve(x, a, m, s):
-    return a * scipy_norm.pdf(x, loc=m, scale=s)
+    """a * scipy.stats.norm.pdf(x, loc=m, scale=s) (reference iar.py:55-56), evaluated with scipy's own operations in scipy's
+    order -- y = (x - m) / s, exp(-y^2 / 2) / sqrt(2 pi), / s, NaN for a scale that is not positive -- without the
+    rv_continuous argument machinery around them (32 us a call, a hundred calls per curve_fit, one curve_fit per atlas and
+    pass: 3 of the 3.7 ms of _q_metric).  Same bits: tests/test_iar.py holds the two equal."""
+    x = np.asarray(x, dtype=np.float64)
+    if not s > 0:
+        return np.full(x.shape, np.nan) * a
+    y = (x - m) / s
+    return a * (np.exp(-y ** 2 / 2.0) / _NORM_PDF_C / s)
 
 
 def distance_map(mask, signed=True, inside_positive=False):
@@ -140,9 +150,43 @@ def _outlier_limit(q_values, method, factor, min_best):
     sys.exit()
 
 
+def _support_roi(consensus, margin=2):
+    """(size, index) of the box around the consensus probability's support, `margin` voxels wider and clipped to the image.
+    Every atlas's label lies inside it (a voxel any atlas labels has a positive vote; the smoothing only widens the support),
+    and so does every later pass's consensus (removing atlases removes votes).  Fill-hole, largest component, the distance
+    map and the contour computed on this box equal the full-volume results at its voxels: everything outside it is
+    background connected to the image border, and a distance is a distance to the label's border voxels, all inside.
+    None: no support at all -- the caller works on the whole volume."""
+    ctx = runtime.context(consensus.device)
+    t = consensus.tensor if consensus.tensor.dtype == torch.float32 else consensus.tensor.float()
+    box = ctx.bounding_box(t.contiguous(), consensus.GetSize(), True)
+    if box[0] > box[1]:
+        return None
+    n = consensus.GetSize()
+    lo = [max(0, box[2 * k] - margin) for k in range(3)]
+    hi = [min(n[k] - 1, box[2 * k + 1] + margin) for k in range(3)]
+    return [hi[k] - lo[k] + 1 for k in range(3)], lo
+
+
+def _in_roi(image, roi):
+    from ..utils.crop import crop_to_roi
+
+    return as_image(image) if roi is None else crop_to_roi(as_image(image), roi[0], roi[1])
+
+
+def _test_distance_map(cache, atlas_id, label_image, roi=None):
+    """abs(SignedMaurerDistanceMap) of one atlas's propagated reference structure, flattened (projection.py:80-82 after
+    iar.py's process_probability_image(..., 0.1)), on the box `roi` (_support_roi).  The reference recomputes it in every
+    pass; it depends on the atlas alone -- only the consensus contour it is SAMPLED on changes between passes -- so it is
+    computed once per atlas and kept for the run (fp32, one box per atlas)."""
+    if atlas_id not in cache:
+        cache[atlas_id] = distance_map(process_probability_image(_in_roi(label_image, roi), 0.1), signed=False).tensor.flatten()
+    return cache[atlas_id]
+
+
 def run_iar(atlas_set, reference_structure, smooth_distance_maps=False, smooth_sigma=1, z_score_statistic="MAD",
             outlier_method="IQR", min_best_atlases=10, outlier_factor=1.5, iteration=0, single_step=False,
-            project_on_sphere=False, label="DIR"):
+            project_on_sphere=False, label="DIR", _distance_maps=None, _roi=False):
     """Perform iterative atlas removal on the atlas_set (reference iar.py:59-301): build the consensus contour,
     sample every atlas's distance to it, score each atlas by how non-Gaussian its robust z-scores are, drop the
     ones beyond the fence, repeat until nothing is dropped."""
@@ -152,13 +196,15 @@ def run_iar(atlas_set, reference_structure, smooth_distance_maps=False, smooth_s
     consensus = combine_labels(atlas_set, reference_structure, label=label)[reference_structure]
     # iar.py:104-112: fewer atlases -> thinner sampling (the "< 7" branch there is unreachable and stays so here)
     resample_factor = 5 if len(ids) < 12 else 1
-    reference_volume = process_probability_image(consensus, threshold=0.95)
+    # the structure occupies a small part of the volume (config 5's heart: 4.8 of 67 Mvoxel): everything below works on the box
+    # around the FIRST pass's consensus support, which holds every label and every later consensus (_support_roi)
+    roi = _support_roi(consensus) if _roi is False else _roi
+    reference_volume = process_probability_image(_in_roi(consensus, roi), threshold=0.95)
     # evaluate_distance_to_reference for every atlas (projection.py:67-92): the reference contour is the same for all of
     # them, so its voxel list is built once; the samples stay on the device for the leave-one-out statistics
     ref_index = torch.nonzero((label_contour(reference_volume).tensor == 1).flatten()).flatten()[::resample_factor]
-    samples = torch.stack([
-        distance_map(process_probability_image(atlas_set[i][label][reference_structure], 0.1), signed=False).tensor.flatten()[ref_index]
-        for i in ids])
+    cache = {} if _distance_maps is None else _distance_maps
+    samples = torch.stack([_test_distance_map(cache, i, atlas_set[i][label][reference_structure], roi)[ref_index] for i in ids])
 
     q_results = {}
     for k, atlas_id in enumerate(ids):
@@ -176,7 +222,7 @@ def run_iar(atlas_set, reference_structure, smooth_distance_maps=False, smooth_s
     return run_iar(atlas_set=survivors, reference_structure=reference_structure, smooth_distance_maps=smooth_distance_maps,
                    smooth_sigma=smooth_sigma, z_score_statistic=z_score_statistic, outlier_method=outlier_method,
                    min_best_atlases=min_best_atlases, outlier_factor=outlier_factor, iteration=iteration + 1,
-                   project_on_sphere=project_on_sphere, label=label)
+                   project_on_sphere=project_on_sphere, label=label, _distance_maps={i: cache[i] for i in keep}, _roi=roi)
 
 
 def run_iar_distributed(dd, atlas_set, my_ids, atlas_id_list, reference_structure, target, weights, smooth_distance_maps=False,
@@ -201,6 +247,8 @@ def run_iar_distributed(dd, atlas_set, my_ids, atlas_id_list, reference_structur
     kept = list(atlas_id_list)
     slots = (len(atlas_id_list) + dd.world - 1) // dd.world
     iteration = 0
+    cache = {}      # this rank's atlases' distance maps: computed once, sampled on every pass's consensus contour
+    roi = False     # the box around the first pass's consensus support (_support_roi): the same on every rank
     while True:
         mine = [i for i in my_ids if i in kept]
         buf = torch.zeros((2,) + tuple(target.shape), dtype=torch.float32, device=device)
@@ -211,14 +259,17 @@ def run_iar_distributed(dd, atlas_set, my_ids, atlas_id_list, reference_structur
         dd.all_reduce_sum(buf)
         consensus = finalize_probability(ctx, target, buf[0].contiguous(), buf[1].contiguous())
         resample_factor = 5 if len(kept) < 12 else 1
-        reference_volume = process_probability_image(consensus, threshold=0.95)
+        if roi is False:
+            roi = _support_roi(consensus)
+        reference_volume = process_probability_image(_in_roi(consensus, roi), threshold=0.95)
         ref_index = torch.nonzero((label_contour(reference_volume).tensor == 1).flatten()).flatten()[::resample_factor]
         n = int(ref_index.numel())
         local = torch.zeros((slots, n), dtype=torch.float32, device=device)
         for k, i in enumerate(my_ids):
             if i in kept:
-                local[k] = distance_map(process_probability_image(atlas_set[i][label][reference_structure], 0.1),
-                                        signed=False).tensor.flatten()[ref_index]
+                local[k] = _test_distance_map(cache, i, atlas_set[i][label][reference_structure], roi)[ref_index]
+            else:
+                cache.pop(i, None)
         gathered = dd.all_gather(local)
         rows = [gathered[idx % dd.world][idx // dd.world].to(device) for idx, aid in enumerate(atlas_id_list) if aid in kept]
         samples = torch.stack(rows)

@@ -71,3 +71,20 @@ def test_leave_one_out_z_scores_on_the_device_match_numpy(n_atlases, statistic):
             np.testing.assert_array_equal(got, want)
         else:
             np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-6)     # mean / std: different summation order
+
+
+def test_gaussian_curve_is_scipy_s_norm_pdf_bit_for_bit():
+    """label/iar.py::gaussian_curve restates a * scipy.stats.norm.pdf(x, loc=m, scale=s) (reference iar.py:55-56) without
+    rv_continuous's argument handling: the same floats, NaN for a non-positive scale, so curve_fit walks the same path."""
+    from scipy.stats import norm
+
+    from platipy_amd.label.iar import gaussian_curve
+
+    x = (np.linspace(-15, 15, 501)[1:] + np.linspace(-15, 15, 501)[:-1]) / 2.0
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        a, m, s = rng.uniform(0.1, 3.0), rng.normal(0, 2.0), rng.uniform(0.05, 6.0)
+        assert np.array_equal(gaussian_curve(x, a, m, s), a * norm.pdf(x, loc=m, scale=s))
+    for s in (0.0, -1.5):
+        got, want = gaussian_curve(x, 1.2, 0.3, s), 1.2 * norm.pdf(x, loc=0.3, scale=s)
+        assert np.isnan(got).all() and np.isnan(want).all()
