@@ -65,7 +65,7 @@ def classify(name, threads):
     return "o"
 
 
-NAMES = {"F": "demons finest level", "C": "demons coarse levels", "L": "linear metric", "R": "resample/compose/IIR", "G": "FIR blurs", "o": "other"}
+NAMES = {"F": "demons levels of >= 400 blocks", "C": "demons levels below that", "L": "linear metric", "R": "resample/compose/IIR", "G": "FIR blurs", "o": "other"}
 
 
 def analyse(d, title="kernel timeline of the atlas chains of one GPU (512x512x256, pipeline defaults)"):
@@ -130,9 +130,8 @@ def analyse(d, title="kernel timeline of the atlas chains of one GPU (512x512x25
             depth += dlt
             last = t
         vox = float(os.environ.get("TL_FINEST_VOXELS", 341 * 341 * 171))
-        print(f"\nFinest demons level: {n_launch} launches = {n_launch / 2:.0f} iterations of {vox / 1e6:.1f} Mvoxel; a finest-level kernel was "
-              f"running for {f_union:.1f} ms (two or more of them at once for {f_multi:.1f} ms): aggregate {n_launch / 2 * vox / f_union / 1e6:.1f} Gvoxel/s "
-              f"over that time.")
+        print(f"\nDemons levels of >= 400 blocks: {n_launch} launches; one of them was running for {f_union:.1f} ms (two or more at once for "
+              f"{f_multi:.1f} ms).")
     print(f"\nSum of kernel durations {tot:.1f} ms; device busy (>= 1 kernel running) {any_ms:.1f} ms of {span:.1f}; >= 2 kernels running {multi_ms:.1f} ms; idle {span - any_ms:.1f} ms.\n")
     binw = 5.0
     nb = int(span / binw) + 1
