@@ -287,7 +287,48 @@ def check_oracle_against_round4_vectors(R):
         g, fd = _gradient_wrt_sitk_parameters(r, R), R["linear_metric_masked_fd_gradient"]
         np.testing.assert_allclose(g, fd, rtol=ORACLE_TOL["fd_rel"], atol=ORACLE_TOL["fd_rel"] * np.abs(fd).max())
         checked.append("linear metric")
+    checked += _check_trajectories(R, None)
     return checked
+
+
+def _check_trajectories(R, pa):
+    """Round 6: SimpleITK's optimiser trajectories (tools/sitk_vectors.py::trajectories) against the oracle's registration
+    (pa None) or the product's linear_registration: per level the metric value of every iteration the reference reports, the
+    final parameters and where the corners land.  Oracle: values 1e-5 relative over the first level (separate fp64
+    implementations; a golden-section tie may move a later iteration), corners 0.02 mm.  Product: test_linear_oracle.py's bounds."""
+    from oracle import linear_oracle
+    from tools import sitk_vectors as sv
+
+    done = []
+    for method, optimiser in sv.TRAJECTORY_CASES:
+        key = f"linear_trajectory_{method}_{optimiser}"
+        if key + "_values" not in R.files:
+            continue
+        ref = R[key + "_values"]
+        kw = sv.TRAJECTORY_KW
+        if pa is None:
+            got = linear_oracle.registration(O.Vol(R["fixed"], SPACING, ORIGIN), O.Vol(R["moving"], SPACING, ORIGIN), method, optimiser,
+                                             kw["shrink_factors"], kw["smooth_sigmas"], kw["sampling_rate"], kw["number_of_iterations"])
+            levels = [lv["values"] for lv in got["levels"]]
+            A, off = got["matrix_offset"]
+            params, tol_first, tol_corner = got["parameters"], 1e-5, 0.02
+        else:
+            img = lambda a: pa.image_from_array(a, SPACING, ORIGIN)  # noqa: E731
+            _, tfm = pa.registration.linear_registration(img(R["fixed"]), img(R["moving"]), reg_method=method, optimiser=optimiser, **kw)
+            levels = [lv["values"] for lv in pa.registration.linear_registration.last_levels]
+            A, off = tfm.matrix_offset()
+            params, tol_first, tol_corner = np.asarray(tfm.transforms[1].GetParameters()), 2e-4, 0.05
+        for level in sorted({int(v) for v in ref[:, 0]}):
+            want = ref[ref[:, 0] == level][:, 2]
+            have = np.asarray(levels[level][:len(want)])
+            assert len(levels[level]) in (len(want), len(want) + 1), (key, level, len(levels[level]), len(want))
+            rel = np.abs(have - want[:len(have)]) / np.maximum(np.abs(want[:len(have)]), 1e-12)
+            assert rel[:5].max() <= (tol_first if level == 0 else 1e-2) and rel.max() <= 0.1, (key, level, rel)
+        corners = np.array([[ORIGIN[k] + (SHAPE[2 - k] - 1) * SPACING[k] * ((c >> k) & 1) for k in range(3)] for c in range(8)])
+        assert np.abs(corners @ np.asarray(A).T + off - R[key + "_corners"]).max() <= tol_corner, key
+        assert np.abs(np.asarray(params) - R[key + "_parameters"]).max() <= 1e-2 * max(1.0, np.abs(R[key + "_parameters"]).max()), key
+        done.append(key)
+    return done
 
 
 def check_product_kernels_against_round4_vectors(R, backend):
@@ -358,6 +399,7 @@ def check_product_api_against_round4_vectors(R, pa):
             got = corners @ A.T + off
             assert np.abs(got - R["linear_similarity_corners"]).max() <= PRODUCT_TOL["corner_mm"], kw
         checked.append("linear similarity registration")
+    checked += _check_trajectories(R, pa)
     return checked
 
 
@@ -415,7 +457,8 @@ def test_reference_vector_path_runs_end_to_end_with_the_double(double_vectors, b
     check_product_against_reference(double_vectors, backend)
     # round 4: every remaining SURVEY 8 row has its key; the double cannot run ITK's optimiser, which it says in meta_missing
     missing = [str(m) for m in double_vectors["meta_missing"]]
-    assert len(missing) == 1 and missing[0].startswith("linear similarity registration"), missing
+    assert len(missing) == 2 and missing[0].startswith("linear similarity registration") and missing[1].startswith(
+        "linear optimiser trajectories"), missing
     assert check_oracle_against_round4_vectors(double_vectors) == ["pyramid_level", "weight maps", "fusion chain", "ball morphology",
                                                                    "fill-hole / components", "linear metric"]
     assert check_product_kernels_against_round4_vectors(double_vectors, backend) == ["ball morphology", "linear metric"]
@@ -442,3 +485,30 @@ def test_emit_command_line_writes_a_file_the_tests_would_pick_up(tmp_path):
     R = np.load(dest)
     assert not is_reference(R) and {"execute_1it", "execute_halt_stats", "label_contour", "resample_nearest"} <= set(R.files)
     check_oracle_against_reference(R)
+
+
+def test_trajectory_checker_runs_on_vectors_of_the_right_shape(tmp_path, host_api):
+    """The round-6 trajectory check (_check_trajectories) has no SimpleITK file to run on yet: feed it a file of the emitted
+    SHAPE -- [level, iteration, value] rows, parameters, corners -- written from the oracle's own registration of the seeded pair
+    (NOT a reference: it only shows that the checker's indexing, level grouping and tolerances execute, for the oracle and for
+    the product), so that the day a real file arrives the check cannot fail on its own plumbing."""
+    from oracle import linear_oracle
+    from tools import sitk_vectors as sv
+
+    fixed, moving, _, _ = sv.inputs()
+    vectors = {"fixed": fixed, "moving": moving}
+    kw = sv.TRAJECTORY_KW
+    corners = np.array([[ORIGIN[k] + (SHAPE[2 - k] - 1) * SPACING[k] * ((c >> k) & 1) for k in range(3)] for c in range(8)])
+    for method, optimiser in sv.TRAJECTORY_CASES[:2]:
+        got = linear_oracle.registration(O.Vol(fixed, SPACING, ORIGIN), O.Vol(moving, SPACING, ORIGIN), method, optimiser, kw["shrink_factors"],
+                                         kw["smooth_sigmas"], kw["sampling_rate"], kw["number_of_iterations"])
+        key = f"linear_trajectory_{method}_{optimiser}"
+        vectors[key + "_values"] = np.array([[lv, it, v] for lv, rec in enumerate(got["levels"]) for it, v in enumerate(rec["values"])])
+        vectors[key + "_parameters"] = got["parameters"]
+        A, off = got["matrix_offset"]
+        vectors[key + "_corners"] = corners @ A.T + off
+    path = str(tmp_path / "shape_only.npz")
+    np.savez(path, **vectors)
+    R = np.load(path)
+    assert _check_trajectories(R, None) == [f"linear_trajectory_{m}_{o}" for m, o in sv.TRAJECTORY_CASES[:2]]
+    assert _check_trajectories(R, host_api) == [f"linear_trajectory_{m}_{o}" for m, o in sv.TRAJECTORY_CASES[:2]]

@@ -89,6 +89,13 @@ LINEAR_KW = dict(reg_method="similarity", metric="mean_squares", optimiser="grad
                  sampling_rate=1.0, number_of_iterations=20)
 
 
+# Round 6: optimiser TRAJECTORIES of sitk.ImageRegistrationMethod as the reference configures it (registration/linear.py:133-238),
+# per case: reg_method, optimiser; two levels without smoothing, REGULAR sampling at 0.5 with seed 42, 12 iterations a level.
+TRAJECTORY_KW = dict(metric="mean_squares", shrink_factors=[2, 1], smooth_sigmas=[0, 0], sampling_rate=0.5, number_of_iterations=12)
+TRAJECTORY_CASES = (("rigid", "gradient_descent_line_search"), ("affine", "gradient_descent_line_search"),
+                    ("similarity", "gradient_descent"))
+
+
 def cavity_mask(mask):
     """the seeded mask with a closed cavity inside it and a small satellite beside it (fill-hole / largest-component input)"""
     m = mask.copy()
@@ -224,8 +231,50 @@ def emit_round4(sitk, out, fixed, moving, field, mask):
         out["linear_similarity_corners"] = np.array([tfm.TransformPoint(c) for c in corners], dtype=np.float64)
         out["linear_similarity_metric"] = np.array(float(R.GetMetricValue()))
 
+    def trajectories():
+        # the same sitk calls with an iteration observer: the metric value ITK reports at every iteration (GetMetricValue() = the
+        # evaluation at the head of that iteration), the level each belongs to, the optimised transform's final parameters and
+        # where the composite sends the fixed image's corners -- what tests/test_linear_oracle.py compares product and oracle on
+        Ff, Mf = sitk.Cast(F, sitk.sitkFloat32), sitk.Cast(M, sitk.sitkFloat32)
+        corners = [[ORIGIN[k] + (SHAPE[2 - k] - 1) * SPACING[k] * ((c >> k) & 1) for k in range(3)] for c in range(8)]
+        for method, optimiser in TRAJECTORY_CASES:
+            init = sitk.CenteredTransformInitializer(Ff, Mf, sitk.Euler3DTransform(), False)
+            R = sitk.ImageRegistrationMethod()
+            R.SetShrinkFactorsPerLevel(TRAJECTORY_KW["shrink_factors"])
+            R.SetSmoothingSigmasPerLevel(TRAJECTORY_KW["smooth_sigmas"])
+            R.SmoothingSigmasAreSpecifiedInPhysicalUnitsOn()
+            R.SetMovingInitialTransform(init)
+            R.SetMetricAsMeanSquares()
+            R.SetInterpolator(sitk.sitkLinear)
+            R.SetMetricSamplingPercentage(TRAJECTORY_KW["sampling_rate"], seed=42)
+            R.SetMetricSamplingStrategy(sitk.ImageRegistrationMethod.REGULAR)
+            R.SetOptimizerScalesFromPhysicalShift()
+            R.SetInitialTransform({"rigid": sitk.VersorRigid3DTransform, "similarity": sitk.Similarity3DTransform,
+                                   "affine": lambda: sitk.AffineTransform(3)}[method]())
+            if optimiser == "gradient_descent_line_search":
+                R.SetOptimizerAsGradientDescentLineSearch(learningRate=1.0, numberOfIterations=TRAJECTORY_KW["number_of_iterations"])
+            else:
+                R.SetOptimizerAsGradientDescent(learningRate=1.0, numberOfIterations=TRAJECTORY_KW["number_of_iterations"])
+            seen = []      # (level, optimiser iteration, metric value); an iteration may fire its event more than once
+
+            def observe(R=R, seen=seen):
+                seen.append((R.GetCurrentLevel(), R.GetOptimizerIteration(), R.GetMetricValue()))
+
+            R.AddCommand(sitk.sitkIterationEvent, observe)
+            result = R.Execute(fixed=Ff, moving=Mf)
+            tfm = sitk.CompositeTransform([init, result])
+            key = f"linear_trajectory_{method}_{optimiser}"
+            first = {}
+            for level, it, value in seen:
+                first.setdefault((int(level), int(it)), float(value))
+            out[key + "_values"] = np.array([[lv, it, v] for (lv, it), v in sorted(first.items())], dtype=np.float64)
+            out[key + "_parameters"] = np.array(result.GetParameters(), dtype=np.float64)
+            out[key + "_corners"] = np.array([tfm.TransformPoint(c) for c in corners], dtype=np.float64)
+            out[key + "_stop"] = np.array(str(R.GetOptimizerStopConditionDescription()))
+
     for name, fn in (("pyramid_level", pyramid), ("weight maps", weights), ("fusion chain", fusion), ("ball morphology", morphology),
-                     ("fill-hole / components", components), ("linear metric", metric), ("linear similarity registration", similarity)):
+                     ("fill-hole / components", components), ("linear metric", metric), ("linear similarity registration", similarity),
+                     ("linear optimiser trajectories", trajectories)):
         group(name, fn)
     return missing
 
