@@ -263,3 +263,26 @@ def test_config5_thirty_two_atlases_four_streams_iterative_selection():
     assert set(wrong) <= set(removed_par) and len(removed_par) <= 12, removed_par
     assert np.array_equal(par["WHOLEHEART"].numpy(), seq["WHOLEHEART"].numpy())
     assert dice(par["WHOLEHEART"].numpy(), tmask) > 0.95
+
+
+def test_staggered_schedule_equals_lockstep(monkeypatch):
+    """projects.multiatlas.STAGGER / ENTRY_SLOTS (runtime.Turnstile: one chain at a time through its throughput-bound phase, an
+    event chain between the worker streams) only reorder device work: the fused masks and probabilities are those of the
+    lockstep run.  (Measured and left off by default: profiles/round6_streams_timeline.md.)"""
+    import platipy_amd as pa
+    from platipy_amd import runtime
+    from platipy_amd.projects import multiatlas
+
+    ids, atlases, target, tmask, _ = _atlases(pa, 6)
+    st = _atlas_settings(ids, ["WHOLEHEART", "SUBSTRUCTURE"])
+    monkeypatch.setattr(runtime, "HEAVY_VOXELS", 1 << 12)          # every level of these small grids counts as throughput-bound
+    out = {}
+    for name, stagger, slots in (("lockstep", False, 0), ("turnstile", True, 0), ("one at a time", True, 1)):
+        monkeypatch.setattr(multiatlas, "STAGGER", stagger)
+        monkeypatch.setattr(multiatlas, "ENTRY_SLOTS", slots)
+        out[name] = pa.projects.multiatlas.run_segmentation(target, st, atlases=atlases, streams_per_gpu=3)
+    for name in ("turnstile", "one at a time"):
+        for s in ("WHOLEHEART", "SUBSTRUCTURE"):
+            assert np.array_equal(out[name][0][s].numpy(), out["lockstep"][0][s].numpy()), (name, s)
+            np.testing.assert_allclose(out[name][1][s].numpy(), out["lockstep"][1][s].numpy(), rtol=0, atol=2e-6)
+    assert dice(out["lockstep"][0]["WHOLEHEART"].numpy(), tmask) > 0.95

@@ -173,3 +173,38 @@ def test_versor_update_is_a_composition_and_the_window_value_is_itk_s():
     assert _window_convergence(e[:9], 10) == float("inf")
     # the least-squares slope of the normalised line is (10 - 9) / 95 = 0.010526; the two-control-point approximation reads lower
     assert 0.5 * (1.0 / 95.0) < _window_convergence(e, 10) < 1.0 / 95.0
+
+
+@pytest.mark.parametrize("method,optimiser", [("rigid", "gradient_descent_line_search"), ("affine", "gradient_descent")])
+def test_native_optimiser_on_the_kernels_follows_the_itk_oracle(backend, monkeypatch, method, optimiser):
+    """The same comparison with NOTHING substituted, in the CPU suite too: pp_linear_optimize_f32 driving the metric KERNELS
+    (compiled for the CPU by tests/emu, or on the GPU) on a pair small enough for the emulator, against the fp64 oracle -- jitter,
+    filtered gradient image, versor composition and all.  (The `emu` runs of the tests above replace the metric kernels by the
+    oracle's index-space metric; this one does not.)"""
+    import torch
+
+    import platipy_amd as pa
+    from platipy_amd import runtime
+    from platipy_amd.registration import linear
+
+    if backend.name == "emu":
+        monkeypatch.setattr(runtime, "context", lambda device=None: backend.ctx)
+        monkeypatch.setattr(runtime, "default_device", lambda: torch.device("cpu"))
+    monkeypatch.setattr(linear, "NATIVE_OPTIMISER", True)
+    shape, spacing, origin = (16, 20, 24), (1.5, 1.5, 2.5), (-30.0, -20.0, 10.0)
+    fix, mov, _ = _rigid_pair(pa, shape, spacing, origin, angle=0.06, shift=(2.0, -1.5, 1.0))
+    kw = dict(shrink_factors=[2, 1], smooth_sigmas=[0, 0], sampling_rate=0.5, number_of_iterations=6)
+    _, tfm = pa.registration.linear_registration(pa.image_from_array(fix, spacing, origin), pa.image_from_array(mov, spacing, origin),
+                                                 reg_method=method, optimiser=optimiser, **kw)
+    got = [dict(lv) for lv in pa.registration.linear_registration.last_levels]
+    want = LO.registration(O.Vol(fix, spacing, origin), O.Vol(mov, spacing, origin), method, optimiser, kw["shrink_factors"], kw["smooth_sigmas"],
+                           kw["sampling_rate"], kw["number_of_iterations"])
+    for g, w in zip(got, want["levels"]):
+        assert g["iterations"] == len(w["values"])
+        np.testing.assert_allclose(g["values"], w["values"], rtol=2e-4 if optimiser == "gradient_descent" else 1e-2)
+    np.testing.assert_allclose(g["values"][:2], w["values"][:2], rtol=2e-4)
+    A, off = tfm.matrix_offset()
+    Aw, ow = want["matrix_offset"]
+    n = np.array(shape[::-1], dtype=np.float64) - 1
+    c = np.array([[i, j, k] for i in (0, n[0]) for j in (0, n[1]) for k in (0, n[2])]) * np.array(spacing) + np.array(origin)
+    assert np.sqrt((((c @ np.asarray(A).T + off) - (c @ Aw.T + ow)) ** 2).sum(1)).max() <= 0.05

@@ -47,6 +47,7 @@ for mod, name in ((deformable, "smooth_and_resample"), (deformable, "apply_trans
 orig_exec = deformable.HipDemonsFilter.Execute
 wrap(deformable.HipDemonsFilter, "Execute", "  demons level")
 wrap(linear, "_optimise_level_native", "  linear level")
+wrap(linear, "itk_moving_gradient", "  linear.itk_moving_gradient")
 torch.cuda.synchronize()
 log.clear()
 t0 = time.perf_counter()
