@@ -137,7 +137,7 @@ def synth_pair(ctx, shape, spacing, seed, device, warp_seed=None, label=None):
     return fixed.contiguous(), moving.contiguous(), geom
 
 
-def multi_atlas_leg(ctx, fixed, moving, spacing, rank, world, device, seed=1234):
+def multi_atlas_leg(ctx, fixed, moving, spacing, rank, world, device, seed=1234, linear_overrides=None):
     """Config 4 shape: one atlas per GPU, whole chain (quick crop registration, affine, demons, propagation of
     the CT and one structure, local weight map, fusion all-reduce, post-processing) with the reference pipeline's
     default settings (multiatlas/run.py:47-103) except that atlases are already in HBM.  Returns seconds."""
@@ -161,6 +161,7 @@ def multi_atlas_leg(ctx, fixed, moving, spacing, rank, world, device, seed=1234)
     st["atlas_settings"]["atlas_id_list"] = ids
     st["atlas_settings"]["atlas_structure_list"] = ["HEART"]
     st["label_fusion_settings"]["vote_type"] = "local"
+    st["linear_registration_settings"].update(linear_overrides or {})
     target = pa.Image(fixed, spacing)
     run_segmentation(target, st, atlases=atlases)            # warm-up: workspaces, RCCL communicator
     torch.cuda.synchronize()
@@ -177,7 +178,7 @@ def multi_atlas_leg(ctx, fixed, moving, spacing, rank, world, device, seed=1234)
     return dt, int(fused.sum()), dice
 
 
-def multi_atlas_streams_leg(ctx, shape, spacing, device, rank=0, world=1, per_gpu=4, streams=4, seed=1234):
+def multi_atlas_streams_leg(ctx, shape, spacing, device, rank=0, world=1, per_gpu=4, streams=4, seed=1234, linear_overrides=None):
     """Config 5's shape: `per_gpu` atlases on EVERY GPU (independent warps of one template, seeds 2000 + i), their
     chains overlapped on `streams` HIP streams (one worker thread + pp_ctx per stream), iterative atlas selection when
     there are enough atlases for it (>= 8), then fusion on the survivors.  Returns (seconds, Dice, atlases removed)."""
@@ -201,6 +202,7 @@ def multi_atlas_streams_leg(ctx, shape, spacing, device, rank=0, world=1, per_gp
     st["atlas_settings"]["atlas_id_list"] = ids
     st["atlas_settings"]["atlas_structure_list"] = ["HEART"]
     st["label_fusion_settings"]["vote_type"] = "local"
+    st["linear_registration_settings"].update(linear_overrides or {})
     if total >= 8:
         st["iar_settings"]["reference_structure"] = "HEART"
     target = pa.Image(target, spacing)
@@ -625,7 +627,12 @@ def main():
                                       "fusion_allreduce_ms": xms.get("fusion_allreduce", 0.0), "crop_allreduce_ms": xms.get("crop_allreduce", 0.0),
                                       "iar_exchange_ms": xms.get("iar_exchange", 0.0), "exchange_ms": xms,
                                       "settings": "multiatlas/run.py defaults (affine GD-line-search 16/8/4 x50; demons isotropic "
-                                                  "6/3/1.5 mm x150/125/100; local vote), atlases resident in HBM"}
+                                                  "6/3/1.5 mm x150/125/100; local vote), atlases resident in HBM; linear stage with "
+                                                  "ITK's sampling semantics (round 6's default: seeded jitter, filtered gradient image)"}
+                if world == 1:     # the same leg as rounds 1-5 timed it: samples on the lattice, the interpolant's gradient
+                    dt_l, _, dice_l = multi_atlas_leg(ctx, fixed, moving, spacing, rank, world, device, linear_overrides={"itk_sampling": False})
+                    out["multi_atlas"].update({"seconds_lattice_sampling": dt_l, "atlases_per_min_lattice_sampling": 60.0 / dt_l,
+                                               "dice_lattice_sampling": dice_l})
         except Exception as e:
             if rank == 0:
                 out["multi_atlas"] = f"failed: {e!r}"
@@ -642,6 +649,9 @@ def main():
                                               "iterative_atlas_removal": ("on, removed %s" % removed) if 4 * world >= 8 else "off (< 8 atlases)",
                                               "settings": "as multi_atlas; 4 independent atlas warps per GPU, chains overlapped on 4 HIP "
                                                           "streams (config 5's shape)"}
+                if world == 1:
+                    dt_l, _, _ = multi_atlas_streams_leg(ctx, (nz, ny, nx), spacing, device, rank, world, linear_overrides={"itk_sampling": False})
+                    out["multi_atlas_streams"].update({"seconds_lattice_sampling": dt_l, "atlases_per_min_lattice_sampling": 60.0 * 4 / dt_l})
         except Exception as e:
             if rank == 0:
                 out["multi_atlas_streams"] = f"failed: {e!r}"
