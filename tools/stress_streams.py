@@ -58,6 +58,7 @@ for name, env, eager, uncached, sync in settings:
     for k in ("PP_NO_FIXED_SAMPLES", "PP_METRIC_BLOCKS", "PP_FIR_MARCH_SP"):
         os.environ.pop(k, None)
     os.environ.update(env)
+    _lib.reload_switches()      # (the library reads its PP_* switches once)
     _D.HipDemonsFilter.Execute = eager_execute if eager else _execute
     _U._need_masks = _need.__wrapped__ if uncached else _need
     torch.cuda.synchronize()
