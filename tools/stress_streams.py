@@ -60,6 +60,9 @@ for name, env, eager, uncached, sync in settings:
     os.environ.update(env)
     _lib.reload_switches()      # (the library reads its PP_* switches once)
     _D.HipDemonsFilter.Execute = eager_execute if eager else _execute
+    if uncached and not hasattr(_need, "__wrapped__"):
+        print(f"{name}: skipped (registration/utils.py::_need_masks is no longer a cached wrapper)", flush=True)
+        continue
     _U._need_masks = _need.__wrapped__ if uncached else _need
     torch.cuda.synchronize()
     run_segmentation(tgt, st, atlases=atlases, streams_per_gpu=1)       # warm-up: caches, workspaces
