@@ -328,7 +328,8 @@ def _check_trajectories(R, pa):
             assert (rel[:5].max() <= tol_first if level == 0 else True) and rel.max() <= 0.1, (key, level, rel)
         corners = np.array([[ORIGIN[k] + (SHAPE[2 - k] - 1) * SPACING[k] * ((c >> k) & 1) for k in range(3)] for c in range(8)])
         assert np.abs(corners @ np.asarray(A).T + off - R[key + "_corners"]).max() <= tol_corner, key
-        assert np.abs(np.asarray(params) - R[key + "_parameters"]).max() <= 1e-2 * max(1.0, np.abs(R[key + "_parameters"]).max()), key
+        # (parameters: translations in mm to the corners' tolerance, matrix / versor entries to 1e-2)
+        assert np.abs(np.asarray(params) - R[key + "_parameters"]).max() <= max(tol_corner, 1e-2 * np.abs(R[key + "_parameters"]).max()), key
         done.append(key)
     return done
 
