@@ -384,9 +384,11 @@ def _shrunk_virtual_domain(size, spacing, origin, direction, factor):
 
 
 class _PhysicalMeanSquares:
-    """MeanSquaresImageToImageMetricv4 over one level's sample point set, in PHYSICAL space."""
+    """MeanSquaresImageToImageMetricv4 -- or, metric="correlation", CorrelationImageToImageMetricv4: value -(sum (f - fbar)(m - mbar))^2
+    / (sum (f - fbar)^2 sum (m - mbar)^2) over the valid samples -- over one level's sample point set, in PHYSICAL space."""
 
-    def __init__(self, fixed, moving, points, init_matrix, init_offset, gradient_image):
+    def __init__(self, fixed, moving, points, init_matrix, init_offset, gradient_image, metric="mean_squares"):
+        self.metric = metric
         self.f_arr, self.m_arr = np.asarray(fixed.arr, dtype=np.float32), np.asarray(moving.arr, dtype=np.float32)
         self.f_p2i, self.f_o = self._p2i(fixed), np.asarray(fixed.origin, dtype=np.float64)
         self.m_p2i, self.m_o = self._p2i(moving), np.asarray(moving.origin, dtype=np.float64)
@@ -409,12 +411,21 @@ class _PhysicalMeanSquares:
         ok, mval, g_idx = _sample(self.m_arr, cm)
         return ok & self.f_ok, mval, g_idx, cm
 
+    def _correlation(self, ok, mval):
+        f, m = self.fval[ok], mval[ok]
+        fc, mc = f - f.mean(), m - m.mean()
+        sff, smm, sfm = float((fc * fc).sum()), float((mc * mc).sum()), float((fc * mc).sum())
+        return fc, mc, sff, smm, sfm
+
     def value(self, tfm, p=None):
         self.evaluations += 1
         ok, mval, _, _ = self._moving(tfm, p)
         n = int(ok.sum())
         if n == 0:
             return np.inf
+        if self.metric == "correlation":
+            _, _, sff, smm, sfm = self._correlation(ok, mval)
+            return 0.0 if (sff <= 1e-300 or smm <= 1e-300) else -(sfm * sfm) / (sff * smm)
         d = np.where(ok, self.fval - mval, 0.0)
         return float((d * d).sum() / n)
 
@@ -432,6 +443,16 @@ class _PhysicalMeanSquares:
         d = np.where(ok, self.fval - mval, 0.0)
         J = np.einsum("rc,ncp->nrp", self.Ai, tfm.jacobian(self.points))    # composite: initial's position Jacobian x optimised's
         per_sample = np.einsum("nr,nrp->np", np.where(ok[:, None], g_phys, 0.0), J)
+        if self.metric == "correlation":
+            # d value / d p with m_s = m(T(x_s; p)):  d sfm = sum fc_s dm_s,  d smm = 2 sum mc_s dm_s  (the means' own derivatives
+            # cancel against sum fc = sum mc = 0);  ITK's sign: the optimiser ADDS the returned derivative, so it is minus the gradient
+            fc, mc, sff, smm, sfm = self._correlation(ok, mval)
+            if sff <= 1e-300 or smm <= 1e-300:
+                return 0.0, np.zeros(len(tfm.p))
+            dm = per_sample[ok]
+            dsfm, dsmm = (fc[:, None] * dm).sum(0), 2.0 * (mc[:, None] * dm).sum(0)
+            gradient = -(2.0 * sfm / (sff * smm) * dsfm - (sfm * sfm) / (sff * smm * smm) * dsmm)
+            return -(sfm * sfm) / (sff * smm), -gradient
         return float((d * d).sum() / n), (2.0 * d[:, None] * per_sample).sum(0) / n
 
 
@@ -495,7 +516,7 @@ def _golden_section_itk(value_at, a, b, c, state, metric_b=None, epsilon=0.01, m
 
 
 def registration(fixed, moving, reg_method="similarity", optimiser="gradient_descent", shrink_factors=(8, 2, 1), smooth_sigmas=(4, 2, 0),
-                 sampling_rate=0.25, number_of_iterations=50, seed=42, itk_sampling=True, return_best=False):
+                 sampling_rate=0.25, number_of_iterations=50, seed=42, itk_sampling=True, return_best=False, metric="mean_squares"):
     """fixed, moving: oracle.Vol (float32 [Z, Y, X] + geometry).  -> dict(parameters, levels=[dict(values, parameters per
     iteration, learning_rates, scales, stop)], init_matrix, init_offset, evaluations).  mean_squares only (the pipelines' metric).
     itk_sampling=False: samples on the lattice and the interpolant's gradient (the product's opt-out), for A/B tests."""
@@ -526,7 +547,7 @@ def registration(fixed, moving, reg_method="similarity", optimiser="gradient_des
         if generator is not None:       # SetMetricSamplePoints: each physical coordinate + N(0, 1) * spacing / 3, raster order
             points = points + generator.normal_variates(3 * len(points)).reshape(len(points), 3) * (vspacing / 3.0)[None, :]
         gimg = O.gradient_recursive_gaussian(m_l).astype(np.float64) if itk_sampling else None
-        metric = _PhysicalMeanSquares(f_l, m_l, points, Ai, oi, gimg)
+        level_metric = _PhysicalMeanSquares(f_l, m_l, points, Ai, oi, gimg, metric)
         corners = _corner_points(vsize, vspacing, vorigin, vdir)
         # ---- StartOptimization ----
         scales = _estimate_scales(tfm, corners, Ai)
@@ -535,7 +556,7 @@ def registration(fixed, moving, reg_method="similarity", optimiser="gradient_des
         energies, rec = [], {"values": [], "parameters": [], "learning_rates": [], "scales": scales.tolist(), "stop": "iterations"}
         learning_rate, best_value, best_p = 1.0, np.inf, tfm.p.copy()
         for it in range(number_of_iterations):
-            value, derivative = metric.value_and_derivative(tfm)
+            value, derivative = level_metric.value_and_derivative(tfm)
             if not np.isfinite(value):
                 if it == 0:
                     raise RuntimeError("no valid sample points")
@@ -556,16 +577,16 @@ def registration(fixed, moving, reg_method="similarity", optimiser="gradient_des
                 learning_rate = max_step / step_scale if step_scale > np.finfo(np.float64).eps else 1.0
             if optimiser == "gradient_descent_line_search":
                 def value_at(rate):
-                    return metric.value(tfm, tfm.updated(rate * gradient))
+                    return level_metric.value(tfm, tfm.updated(rate * gradient))
 
                 learning_rate = _golden_section_itk(value_at, 0.0 * learning_rate, learning_rate, 5.0 * learning_rate, {"iterations": 0})
             rec["learning_rates"].append(learning_rate)
             previous = tfm.p.copy()
             tfm.p = tfm.updated(learning_rate * gradient)                  # UpdateTransformParameters(m_Gradient)
-        if return_best and metric.value(tfm) > best_value:
+        if return_best and level_metric.value(tfm) > best_value:
             tfm.p = best_p
         rec["final"] = tfm.p.copy()
-        evaluations += metric.evaluations
+        evaluations += level_metric.evaluations
         levels.append(rec)
     return {"parameters": tfm.p.copy(), "levels": levels, "init_matrix": Ai, "init_offset": oi, "evaluations": evaluations,
             "matrix_offset": _total_matrix_offset(tfm, Ai, oi)}

@@ -276,6 +276,7 @@ def run_segmentation(img, settings=MUTLIATLAS_SETTINGS_DEFAULTS, atlases=None, s
     run_segmentation.last_fusion_payload_bytes = out["fusion_payload_bytes"]
     run_segmentation.last_exchange_ms = out["exchange_ms"]
     run_segmentation.last_world_size = out["world_size"]
+    run_segmentation.last_crop_box = out["crop_box"]        # (size, index), both (x, y, z): multiatlas/run.py:241-243
     if return_atlas_set:
         return out["results"], out["results_prob"], out["atlas_set"]
     return out["results"], out["results_prob"]
@@ -396,7 +397,9 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
         else:
             target_reg_image, atlas_reg_image = img_crop, cur["CT Image"]
         _, dir_tfm, _ = fast_symmetric_forces_demons_registration(target_reg_image, atlas_reg_image, **dir_set)
-        out = {"Transform": dir_tfm,
+        # ("Linear Transform": the stage-2 result, which the reference drops with its "RIR" entry at run.py:347 -- kept for
+        # diagnostics and tests/test_pipeline_oracle.py; no function of the path reads it)
+        out = {"Transform": dir_tfm, "Linear Transform": initial_tfm,
                "CT Image": apply_transform(cur["CT Image"], transform=dir_tfm, default_value=-1000, interpolator=sitkLinear)}
         for s in atlas_structure_list:
             if s in cur:
@@ -467,6 +470,7 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
     if root_only and dd.rank != 0:      # the sums live on rank 0: nothing to finalise here
         del buf
         return {"results": {}, "results_prob": {}, "atlas_set": atlas_set, "iar_removed": removed, "img_crop": img_crop,
+                "crop_box": (list(crop_box_size), list(crop_box_index)),
                 "fusion_payload_bytes": fusion_payload_bytes, "exchange_ms": dd.timings_ms(), "world_size": dd.world}
     combined_label_dict = {s: finalize_probability(ctx, img_crop, buf[0] if shared_wsum else buf[2 * k], buf[1 + k] if shared_wsum else buf[2 * k + 1])
                            for k, s in enumerate(atlas_structure_list)}
@@ -530,4 +534,5 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
     if as_cropped:
         results["CROP_IMAGE"] = img_crop
     return {"results": results, "results_prob": results_prob, "atlas_set": atlas_set, "iar_removed": removed, "img_crop": img_crop,
+            "crop_box": (list(crop_box_size), list(crop_box_index)),
             "fusion_payload_bytes": fusion_payload_bytes, "exchange_ms": dd.timings_ms(), "world_size": dd.world}

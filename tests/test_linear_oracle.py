@@ -35,7 +35,8 @@ def _compare(pa, fix, mov, method, optimiser, kw, label):
     _, tfm = pa.registration.linear_registration(fi, mi, reg_method=method, optimiser=optimiser, **kw)
     got_levels = [dict(l) for l in pa.registration.linear_registration.last_levels]
     want = LO.registration(O.Vol(fix, SPACING, ORIGIN), O.Vol(mov, SPACING, ORIGIN), method, optimiser, kw["shrink_factors"], kw["smooth_sigmas"],
-                           kw["sampling_rate"], kw["number_of_iterations"], seed=42, itk_sampling=kw.get("itk_sampling", True))
+                           kw["sampling_rate"], kw["number_of_iterations"], seed=42, itk_sampling=kw.get("itk_sampling", True),
+                           metric=kw.get("metric", "mean_squares"))
     stats = {"method": method, "optimiser": optimiser, "levels": []}
     assert len(got_levels) == len(want["levels"])
     for g, w in zip(got_levels, want["levels"]):
@@ -108,6 +109,20 @@ def test_linear_registration_pipeline_settings_follow_the_itk_oracle(host_api):
     _assert_same_trajectory(stats)
     kw = dict(shrink_factors=[4, 1], smooth_sigmas=[2, 0], sampling_rate=0.25, number_of_iterations=10)
     stats, _, _ = _compare(pa, fix, mov, "similarity", "gradient_descent_line_search", kw, "smoothed_similarity")
+    _assert_same_trajectory(stats, first5=5e-4)
+
+
+def test_correlation_metric_follows_the_itk_oracle(host_api):
+    """metric="correlation" (linear.py:142-143; CorrelationImageToImageMetricv4) through the same comparison, on a moving image
+    with another window / level (0.4 m + 250), which mean squares could not register."""
+    pa = host_api
+    fix, mov, _ = _rigid_pair(pa, SHAPE, SPACING, ORIGIN)
+    mov = (0.4 * mov + 250.0).astype(np.float32)
+    kw = dict(shrink_factors=[4, 2], smooth_sigmas=[0, 0], sampling_rate=0.5, number_of_iterations=12, metric="correlation",
+              default_value=float(mov.min()))
+    stats, _, _ = _compare(pa, fix, mov, "rigid", "gradient_descent_line_search", {k: v for k, v in kw.items()}, "rigid_correlation_line_search")
+    _assert_same_trajectory(stats, first5=5e-4)
+    stats, _, _ = _compare(pa, fix, mov, "similarity", "gradient_descent", dict(kw, number_of_iterations=8), "similarity_correlation_gd")
     _assert_same_trajectory(stats, first5=5e-4)
 
 
