@@ -126,3 +126,95 @@ def run_segmentation(img, settings, atlases):
         results[s] = paste(template_binary, O.process_probability_image(prob, thr), crop_box_index)
         results_prob[s] = paste(template_prob, prob, crop_box_index)
     return results, results_prob, record
+
+
+# =================================================================================================================================
+# platipy/imaging/projects/cardiac/run.py:507-1147 with a guide structure (the structure-guided path), restated the same way; vessel
+# splining, geometric valve / node definitions, iterative atlas removal and post-processing are left to their own tests (the caller's
+# settings switch them off, as the reference's own test does: platipy/imaging/tests/test_cardiac.py:174-196).
+
+
+def convert_mask_to_reg_structure(mask, expansion=2):
+    """registration/utils.py:302-344: ball dilation by int(expansion / spacing) voxels, inside distance map, zero outside, / max."""
+    grown = O.binary_dilate_ball(mask.like((mask.arr != 0).astype(np.uint8)), [int(expansion / s) for s in mask.spacing])
+    dm = O.maurer_distance_map(grown, signed=True, inside_positive=True).arr.astype(np.float64) * (grown.arr != 0)
+    return mask.like(dm / dm.max())
+
+
+def extend_mask(mask, extension_mm=10, interior_mm_shape=10):
+    """generation/mask.py:107-159, direction ("ax", "sup"): the superior end of the label is continued upwards by the union of its
+    last few slices."""
+    arr = (mask.arr != 0).astype(mask.arr.dtype)
+    occupied = np.nonzero(arr.any(axis=(1, 2)))[0]
+    top = int(occupied.max())
+    n_ext, n_est = int(extension_mm / mask.spacing[2]), int(interior_mm_shape / mask.spacing[2])
+    stop = min(arr.shape[0], top + 1 + n_ext)
+    for z in range(top + 1 - n_est, stop):
+        arr[z] = arr[top - n_est:top].max(axis=0)      # (re-read every pass, as the reference's loop does: later slices see earlier writes)
+    return mask.like(arr)
+
+
+def _mask_outside(vol, mask, outside):
+    """sitk.Mask(image, mask, outsideValue)"""
+    return vol.like(np.where(mask != 0, vol.arr, np.asarray(outside, dtype=vol.arr.dtype)))
+
+
+def run_cardiac_guided(img, guide_structure, settings, atlases):
+    a_set = settings["atlas_settings"]
+    atlas_id_list, atlas_structure_list = list(a_set["atlas_id_list"]), list(a_set["atlas_structure_list"])
+    name = a_set["guide_structure_name"]
+    ext = a_set["superior_extension"]
+    # step 1 (cardiac/run.py:603-616)
+    crop_box_size, crop_box_index = label_to_roi(guide_structure, expansion_mm=settings["auto_crop_target_image_settings"]["expansion_mm"])
+    img_crop = crop_to_roi(img, crop_box_size, crop_box_index)
+    guide = crop_to_roi(guide_structure, crop_box_size, crop_box_index)
+    target_reg_structure = convert_mask_to_reg_structure(guide, 2)
+    expanded_target = extend_mask(guide, ext, ext / 2)
+    lin_set = settings["linear_registration_settings"]
+    strip = ("ncores", "verbose")
+    sg_set = {k: v for k, v in settings["structure_guided_registration_settings"].items() if k not in strip}
+    dir_set = {k: v for k, v in settings["deformable_registration_settings"].items() if k not in strip}
+    atlas_set, record = {}, {"crop_box_size": crop_box_size, "crop_box_index": crop_box_index}
+    for atlas_id in atlas_id_list:
+        orig = atlases[atlas_id]
+        # step 2 (:668-745): the guide structures' registration images are registered, not the CTs
+        atlas_reg = convert_mask_to_reg_structure(orig[name], 2)
+        _, (A, off) = linear_registration(target_reg_structure, atlas_reg, **lin_set)
+        reg_mask = O.apply_transform(atlas_reg, img_crop, affine=(A, off), default_value=0, interpolator=LINEAR)
+        expanded = O.apply_transform(extend_mask(orig[name], ext, ext / 2), img_crop, affine=(A, off), default_value=0, interpolator=NEAREST)
+        cur = {"CT Image": O.apply_transform(orig["CT Image"], img_crop, affine=(A, off), default_value=-1000, interpolator=LINEAR)}
+        for s in atlas_structure_list:
+            cur[s] = O.apply_transform(orig[s], img_crop, affine=(A, off), default_value=0, interpolator=NEAREST)
+        # step 3a (:751-799): structure-guided demons on the registration images
+        _, sg, _ = O.fast_symmetric_forces_demons_registration(target_reg_structure, reg_mask, **sg_set)
+        nxt = {"CT Image": O.apply_transform(cur["CT Image"], field_vol=sg, default_value=-1000, interpolator=LINEAR)}
+        expanded = O.apply_transform(expanded, img_crop, field_vol=sg, default_value=0, interpolator=NEAREST)
+        for s in atlas_structure_list:
+            nxt[s] = O.apply_transform(cur[s], field_vol=sg, default_value=0, interpolator=NEAREST)
+        # step 3b (:818-870): both images masked to the union of the extended guide structures and to the ATLAS image's soft tissue
+        combined = np.maximum(expanded.arr, expanded_target.arr.astype(expanded.arr.dtype))
+        atlas_img = _mask_outside(nxt["CT Image"], combined, -1000)
+        atlas_img = _mask_outside(atlas_img, atlas_img.arr > -400, -1000)
+        target_img = _mask_outside(img_crop, combined, -1000)
+        target_img = _mask_outside(target_img, atlas_img.arr > -400, -1000)
+        _, dvf, _ = O.fast_symmetric_forces_demons_registration(target_img, atlas_img, **dir_set)
+        out = {"CT Image": O.apply_transform(nxt["CT Image"], field_vol=dvf, default_value=-1000, interpolator=LINEAR)}
+        for s in atlas_structure_list:
+            out[s] = O.apply_transform(nxt[s], field_vol=dvf, default_value=0, interpolator=NEAREST)
+        atlas_set[atlas_id] = {"DIR": out}
+    # step 5 (:910-922) and 6 (:928-1004)
+    fus = settings["label_fusion_settings"]
+    for atlas_id in atlas_id_list:
+        d = atlas_set[atlas_id]["DIR"]
+        d["Weight Map"] = O.compute_weight_map(img_crop, d["CT Image"], vote_type=fus["vote_type"], vote_params=fus["vote_params"])
+    combined_label_dict = O.combine_labels(atlas_set, atlas_structure_list)
+    results, results_prob = {}, {}
+    template_binary = img.like(np.zeros(img.arr.shape, dtype=np.uint8))
+    template_prob = img.like(np.zeros(img.arr.shape, dtype=np.float64))
+    for s in [k for k in fus["optimal_threshold"] if k in atlas_structure_list]:
+        prob = combined_label_dict[s]
+        results[s] = paste(template_binary, O.process_probability_image(prob, fus["optimal_threshold"][s]), crop_box_index)
+        results_prob[s] = paste(template_prob, prob, crop_box_index)
+        if not settings.get("return_atlas_guide_structure", False):
+            results[name] = paste(template_binary, guide, crop_box_index)
+    return results, results_prob, record

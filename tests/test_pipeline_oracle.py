@@ -109,3 +109,51 @@ def test_run_segmentation_against_the_oracle_s_whole_pipeline(host_api):
         assert v["dice_product_vs_template"] >= v["dice_oracle_vs_template"] - 0.01, (s, v)
     assert stats["structures"]["HEART"]["dice_product_vs_template"] > 0.9
     assert res["HEART"].GetSize() == tuple(SHAPE[::-1])
+
+
+def test_run_cardiac_segmentation_guided_against_the_oracle_s_whole_pipeline(host_api):
+    """The structure-guided cardiac pipeline (cardiac/run.py:507-1147 with a guide structure: crop from the structure,
+    registration images from the guide structures' distance maps, linear + structure-guided demons on them, images masked to
+    the extended structures, intensity demons, fusion) against oracle/pipeline_oracle.py::run_cardiac_guided, with the switches
+    the reference's own guided test sets (no vessels, no geometric definitions, no atlas removal, no post-processing)."""
+    from platipy_amd.projects.cardiac import CARDIAC_SETTINGS_DEFAULTS
+
+    pa = host_api
+    target, label, small, atl = _case()
+    ids = sorted(atl)
+    st = copy.deepcopy(CARDIAC_SETTINGS_DEFAULTS)
+    st["atlas_settings"].update({"atlas_id_list": ids, "atlas_structure_list": ["HEART", "NODE"], "guide_structure_name": "HEART",
+                                 "superior_extension": 10})
+    st["auto_crop_target_image_settings"]["expansion_mm"] = [8, 8, 10]
+    st["linear_registration_settings"].update({"reg_method": "similarity", "shrink_factors": [4, 2], "smooth_sigmas": [0, 0],
+                                               "number_of_iterations": 12})
+    st["structure_guided_registration_settings"].update({"resolution_staging": [8, 4, 2], "iteration_staging": [10, 10, 10]})
+    st["deformable_registration_settings"].update({"resolution_staging": [6, 3, 1.5], "iteration_staging": [15, 10, 10]})
+    st["iar_settings"]["reference_structure"] = None
+    st["label_fusion_settings"].update({"vote_type": "local", "optimal_threshold": {"HEART": 0.5, "NODE": 0.5}})
+    st["vessel_spline_settings"] = {"vessel_name_list": [], "vessel_radius_mm_dict": {}, "scan_direction_dict": {},
+                                    "stop_condition_type_dict": {}, "stop_condition_value_dict": {}}
+    st["postprocessing_settings"]["run_postprocessing"] = False
+    st["geometric_segmentation_settings"]["run_geometric_algorithms"] = False
+    p_atlases = {i: {"CT Image": pa.image_from_array(ct, SPACING, ORIGIN), "HEART": pa.image_from_array(lab, SPACING, ORIGIN),
+                     "NODE": pa.image_from_array(sub, SPACING, ORIGIN)} for i, (ct, lab, sub) in atl.items()}
+    o_atlases = {i: {"CT Image": O.Vol(ct, SPACING, ORIGIN), "HEART": O.Vol(lab, SPACING, ORIGIN), "NODE": O.Vol(sub, SPACING, ORIGIN)}
+                 for i, (ct, lab, sub) in atl.items()}
+    res, prob = pa.projects.cardiac.run_cardiac_segmentation(pa.image_from_array(target, SPACING, ORIGIN), pa.image_from_array(label, SPACING, ORIGIN),
+                                                            settings=st, atlases=p_atlases)
+    wres, wprob, rec = PO.run_cardiac_guided(O.Vol(target, SPACING, ORIGIN), O.Vol(label, SPACING, ORIGIN), st, o_atlases)
+    stats = {"crop_box_oracle": [rec["crop_box_size"], rec["crop_box_index"]], "structures": {}}
+    assert set(res) == set(wres) == {"HEART", "NODE"}
+    np.testing.assert_array_equal(res["HEART"].numpy(), label)          # the guide structure is handed back (cardiac/run.py:994-1004)
+    np.testing.assert_array_equal(wres["HEART"].arr, label)
+    got, want = res["NODE"].numpy(), wres["NODE"].arr
+    dp = np.abs(prob["NODE"].numpy().astype(np.float64) - wprob["NODE"].arr)
+    stats["structures"]["NODE"] = {"voxels_product": int(got.sum()), "voxels_oracle": int(want.sum()), "voxels_differing": int((got != want).sum()),
+                                   "dice_product_vs_oracle": float(dice(got, want)), "dice_product_vs_template": float(dice(got, small)),
+                                   "dice_oracle_vs_template": float(dice(want, small)), "prob_abs_diff_p99": float(np.quantile(dp, 0.99)),
+                                   "prob_abs_diff_max": float(dp.max())}
+    record_stats("pipeline_whole_run_cardiac_guided", stats)
+    print("guided cardiac pipeline, product vs oracle:", stats)
+    v = stats["structures"]["NODE"]
+    assert v["voxels_differing"] <= 0.02 * max(v["voxels_product"], v["voxels_oracle"]) + 2, v
+    assert v["prob_abs_diff_p99"] <= 0.05 and v["dice_product_vs_template"] >= v["dice_oracle_vs_template"] - 0.02 and v["dice_product_vs_template"] > 0.8, v
