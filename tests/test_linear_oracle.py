@@ -19,7 +19,7 @@ import pytest
 
 from oracle import linear_oracle as LO
 from oracle import oracle as O
-from tests.helpers import phantom, record_stats
+from tests.helpers import record_stats
 from tests.test_linear import _rigid_pair
 
 SHAPE, SPACING, ORIGIN = (24, 40, 48), (1.5, 1.5, 2.5), (-30.0, -20.0, 10.0)
