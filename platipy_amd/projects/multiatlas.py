@@ -398,7 +398,7 @@ def atlas_pipeline(img, settings, guide_structure=None, atlases=None, streams_pe
             target_reg_image, atlas_reg_image = img_crop, cur["CT Image"]
         _, dir_tfm, _ = fast_symmetric_forces_demons_registration(target_reg_image, atlas_reg_image, **dir_set)
         # ("Linear Transform": the stage-2 result, which the reference drops with its "RIR" entry at run.py:347 -- kept for
-        # diagnostics and tests/test_pipeline_oracle.py; no function of the path reads it)
+        # diagnostics and the whole-pipeline parity test; no function of the path reads it)
         out = {"Transform": dir_tfm, "Linear Transform": initial_tfm,
                "CT Image": apply_transform(cur["CT Image"], transform=dir_tfm, default_value=-1000, interpolator=sitkLinear)}
         for s in atlas_structure_list:
