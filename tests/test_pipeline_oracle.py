@@ -57,9 +57,9 @@ def _settings(ids):
     s["atlas_settings"]["atlas_structure_list"] = ["HEART", "NODE"]
     s["auto_crop_target_image_settings"]["expansion_mm"] = [1.5, 1.5, 3]       # one voxel: the box stays inside the image
     s["linear_registration_settings"].update({"reg_method": "similarity", "shrink_factors": [4, 2], "smooth_sigmas": [0, 0],
-                                              "number_of_iterations": 15})
+                                              "number_of_iterations": 10})
     s["deformable_registration_settings"].update({"isotropic_resample": True, "resolution_staging": [6, 3, 1.5],
-                                                  "iteration_staging": [20, 15, 10], "smoothing_sigmas": [0, 0, 0]})
+                                                  "iteration_staging": [12, 8, 6], "smoothing_sigmas": [0, 0, 0]})
     s["label_fusion_settings"]["vote_type"] = "local"
     return s
 
@@ -126,9 +126,9 @@ def test_run_cardiac_segmentation_guided_against_the_oracle_s_whole_pipeline(hos
                                  "superior_extension": 10})
     st["auto_crop_target_image_settings"]["expansion_mm"] = [8, 8, 10]
     st["linear_registration_settings"].update({"reg_method": "similarity", "shrink_factors": [4, 2], "smooth_sigmas": [0, 0],
-                                               "number_of_iterations": 12})
-    st["structure_guided_registration_settings"].update({"resolution_staging": [8, 4, 2], "iteration_staging": [10, 10, 10]})
-    st["deformable_registration_settings"].update({"resolution_staging": [6, 3, 1.5], "iteration_staging": [15, 10, 10]})
+                                               "number_of_iterations": 8})
+    st["structure_guided_registration_settings"].update({"resolution_staging": [8, 4, 2], "iteration_staging": [6, 6, 6]})
+    st["deformable_registration_settings"].update({"resolution_staging": [6, 3, 1.5], "iteration_staging": [8, 6, 6]})
     st["iar_settings"]["reference_structure"] = None
     st["label_fusion_settings"].update({"vote_type": "local", "optimal_threshold": {"HEART": 0.5, "NODE": 0.5}})
     st["vessel_spline_settings"] = {"vessel_name_list": [], "vessel_radius_mm_dict": {}, "scan_direction_dict": {},
