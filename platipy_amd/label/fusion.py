@@ -136,6 +136,33 @@ def process_probability_image(probability_image, threshold=0.5):
     ctx = runtime.context(probability_image.device)
     prob = _f32(probability_image)
     n = prob.numel()
+    if threshold > 0 and n >= CROP_MIN_VOXELS:
+        # A fused probability is zero outside the (smoothed) union of the atlas labels -- a few per cent of a 512 x 512 x 256
+        # volume -- and every voxel that can pass a POSITIVE threshold lies in the box around its support.  On that box (one
+        # voxel wider, so that its rim is background connected to the outside) the threshold, the fill-hole, the labelling and
+        # the largest component are those of the whole volume: everything outside is background reaching the image border.
+        from ..utils.crop import crop_to_roi
+
+        size = probability_image.GetSize()
+        box = ctx.bounding_box(prob, size, True)
+        if box[0] <= box[1]:
+            lo = [max(0, box[2 * k] - 1) for k in range(3)]
+            ext = [min(size[k] - 1, box[2 * k + 1] + 1) - lo[k] + 1 for k in range(3)]
+            if ext[0] * ext[1] * ext[2] <= n // 2:
+                inner = _process_probability_image(crop_to_roi(probability_image.like(prob), ext, lo), threshold)
+                out = torch.zeros(prob.shape, dtype=torch.uint8, device=prob.device)
+                out[lo[2]:lo[2] + ext[2], lo[1]:lo[1] + ext[1], lo[0]:lo[0] + ext[0]] = inner.tensor
+                return probability_image.like(out)
+    return _process_probability_image(probability_image.like(prob), threshold)
+
+
+CROP_MIN_VOXELS = 1 << 22
+
+
+def _process_probability_image(probability_image, threshold):
+    ctx = runtime.context(probability_image.device)
+    prob = _f32(probability_image)
+    n = prob.numel()
     _, hi = ctx.minmax(prob, n)
     binary = torch.empty(prob.shape, dtype=torch.uint8, device=prob.device)
     ctx.binary_threshold(prob, n, hi, threshold, binary)

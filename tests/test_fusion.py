@@ -145,3 +145,33 @@ def test_combine_labels_weights_float_and_wide_integer_labels_as_float32(host_ap
     aset = {f"{k}": {"DIR": {"Weight Map": pa.image_from_array(w[k], sp), "S": pa.image_from_array(wide[k], sp)}} for k in range(2)}
     got = pa.label.combine_labels(aset, "S", threshold=0.0, smooth_sigma=1e-3)["S"].numpy()
     assert got.max() == 1.0 and (got > 0).mean() > 0.5            # 256 did not wrap to 0
+
+
+@pytest.mark.gpu
+def test_process_probability_image_on_the_support_box_equals_the_whole_volume(monkeypatch):
+    """Round 6: on volumes of >= 4 Mvoxel process_probability_image works on the box around the probability's support (a fused
+    probability is zero outside the smoothed union of the atlas labels).  The result is that of the whole volume, bit for bit:
+    a blob with an internal hole, a second smaller component, one touching the volume's border."""
+    import torch
+
+    import platipy_amd as pa
+    from platipy_amd.label import fusion
+
+    n = 168
+    zz, yy, xx = np.meshgrid(*[np.arange(n, dtype=np.float32)] * 3, indexing="ij")
+    prob = np.zeros((n, n, n), np.float32)
+    r = np.sqrt((xx - 70) ** 2 + (yy - 80) ** 2 + (zz - 60) ** 2)
+    prob[r < 30] = 0.9
+    prob[r < 8] = 0.0                                      # a hole inside the blob
+    prob[(np.abs(xx - 120) < 6) & (np.abs(yy - 30) < 6) & (np.abs(zz - 100) < 6)] = 0.7      # a smaller component
+    prob[0:5, 100:110, 100:110] = 0.6                      # ... and one on the border
+    prob += np.where(prob > 0, 0.05 * np.sin(xx * 0.3), 0).astype(np.float32)
+    img = pa.image_from_array(prob, (1.0, 1.1, 1.2))
+    got = pa.label.process_probability_image(img, 0.5).numpy()
+    monkeypatch.setattr(fusion, "CROP_MIN_VOXELS", 1 << 62)
+    whole = pa.label.process_probability_image(img, 0.5).numpy()
+    want = O.process_probability_image(O.Vol(prob, (1.0, 1.1, 1.2)), 0.5).arr
+    assert got.sum() > 50000 and got[60, 80, 70] == 1            # the hole is filled, the largest component kept
+    np.testing.assert_array_equal(got, whole)
+    np.testing.assert_array_equal(got, want)
+    assert torch.cuda.is_available()
