@@ -127,23 +127,30 @@ for case in range(max(3, n_cases // 3)):
         mov = (mov + rng.normal(0, 5, size=shape)).astype(np.float32)
     tr, ptr = [], []
     _, w, _ = O.fast_symmetric_forces_demons_registration(O.Vol(fix, spacing, origin), O.Vol(mov, spacing, origin), trace=tr, **kw)
+    # the oracle's own conditioning: its response to the moving image one ulp up and one ulp down; the larger of the two per
+    # statistic (a maximum over one trial of a chaotic iteration is a noisy estimate: 0.1 ... 1.0 mm across this sweep's cases)
     pert = np.nextafter(mov.astype(np.float32), np.float32(np.inf))
     _, p, _ = O.fast_symmetric_forces_demons_registration(O.Vol(fix, spacing, origin), O.Vol(pert, spacing, origin), trace=ptr, **kw)
+    pert = np.nextafter(mov.astype(np.float32), np.float32(-np.inf))
+    _, p2, _ = O.fast_symmetric_forces_demons_registration(O.Vol(fix, spacing, origin), O.Vol(pert, spacing, origin), **kw)
     _, tfm, g = pa.registration.fast_symmetric_forces_demons_registration(pa.image_from_array(fix, spacing, origin),
                                                                           pa.image_from_array(mov, spacing, origin), **kw)
-    hip, own = err_stats(g.numpy(), w.arr), err_stats(p.arr, w.arr)
+    hip, own, own2 = err_stats(g.numpy(), w.arr), err_stats(p.arr, w.arr), err_stats(p2.arr, w.arr)
+    own = {k: max(own[k], own2[k]) for k in own}
     mask = ellipsoid(shape, [s / 2 for s in shape[::-1]], [0.25 * s for s in shape[::-1]]).cpu().numpy()
     mh = pa.registration.apply_transform(pa.image_from_array(mask, spacing, origin), transform=tfm, default_value=0,
                                          interpolator=pa.sitkNearestNeighbor).numpy()
     mo = O.apply_transform(O.Vol(mask, spacing, origin), field_vol=w, default_value=0, interpolator=O.INTERP_NEAREST).arr
     mp = O.apply_transform(O.Vol(mask, spacing, origin), field_vol=p, default_value=0, interpolator=O.INTERP_NEAREST).arr
-    ndiff, nown = int((mh != mo).sum()), int((mp != mo).sum())
+    mp2 = O.apply_transform(O.Vol(mask, spacing, origin), field_vol=p2, default_value=0, interpolator=O.INTERP_NEAREST).arr
+    ndiff, nown = int((mh != mo).sum()), max(int((mp != mo).sum()), int((mp2 != mo).sum()))
     ok = (hip["median"] <= max(5e-5, 4 * own["median"]) and hip["p99"] <= max(1e-3, 4 * own["p99"]) and hip["rms"] <= max(2e-3, 4 * own["rms"])
           and hip["inner_max"] <= max(2e-2, 4 * own["inner_max"]) and ndiff <= max(2e-4 * mask.sum(), 4 * nown, 2))
     bad += 0 if ok else 1
     print(f"case {case:2d} {'guided' if guided else 'ct    '} shape {shape} levels {[t['fixed'].arr.shape[::-1] for t in tr]} iterations "
           f"{[t['elapsed'] for t in tr]}: field median {hip['median']:.1e} (own {own['median']:.1e}) p99 {hip['p99']:.1e} ({own['p99']:.1e}) "
-          f"rms {hip['rms']:.1e} ({own['rms']:.1e}); whole-chain mask voxels differing {ndiff} (own {nown}) of {int(mask.sum())}"
+          f"rms {hip['rms']:.1e} ({own['rms']:.1e}) inner max {hip['inner_max']:.1e} ({own['inner_max']:.1e}); whole-chain mask voxels differing "
+          f"{ndiff} (own {nown}) of {int(mask.sum())}"
           f"{'' if ok else '  <-- OUT OF TOLERANCE'}")
 print("cases out of tolerance:", bad)
 sys.exit(1 if bad else 0)
