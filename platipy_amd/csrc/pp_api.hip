@@ -94,7 +94,7 @@ struct pp_switch_def {
 };
 constexpr pp_switch_def SWITCHES[] = {
     {"PP_CC_ROWS_BLOCK", false},  {"PP_COMPOSE_BLOCK", true},  {"PP_FIR_LEGACY", false},   {"PP_FIR_MARCH_SP", true},
-    {"PP_FUSED_GEN", true},       {"PP_FUSED_MASK", true},     {"PP_FUSED_MIX", true},     {"PP_FUSED_NT", true},
+    {"PP_FUSED_CUBE", true},      {"PP_FUSED_GEN", true},       {"PP_FUSED_MASK", true},     {"PP_FUSED_MIX", true},     {"PP_FUSED_NT", true},
     {"PP_FUSED_OPT", true},       {"PP_FUSED_PITCH", true},    {"PP_FUSED_SUM", true},     {"PP_FUSED_SYNC", true},
     {"PP_FUSED_TILE", true},      {"PP_FUSED_ZCHUNK", true},   {"PP_FUSED_ZCHUNK_A", true}, {"PP_FUSED_ZCHUNK_B", true},
     {"PP_GAUSS3", true},          {"PP_METRIC_BLOCKS", true},  {"PP_METRIC_GRAD_ONE_LAUNCH", true}, {"PP_METRIC_LANES", true},

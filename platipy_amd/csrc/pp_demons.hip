@@ -859,6 +859,7 @@ __global__ void __launch_bounds__(TILE_OUT / OPT, PP_B_WAVES) k_fused_add_smooth
 #define PP_RING_UNROLL_MAX_R 3
 #endif
 #include "pp_demons_fused2.h"
+#include "pp_demons_cube.h"
 
 // ---------------------------------------------------------------------------------------
 // host side
@@ -1124,6 +1125,36 @@ int launch_warp2(pp_ctx* ctx, int sh, bool sum, const float* D, const float* Us,
   return PP_OK;
 }
 
+// Generation 3 (pp_demons_cube.h): one block per 16 x 8 x 6 brick, plain 3-D grid (these levels live in the L2 / infinity cache).
+template <int R>
+int launch_cube_force(pp_ctx* ctx, const float* F, const float* Mw_in, const float* D, float* S, const cube_args& ca, const pp_esm_consts& K,
+                      double* partials, pp_dev_stats* st, const double* prev, int nprev, double max_rms) {
+  pp_prof_scope ps(ctx, "k_cube_force_smooth");
+  using G = cube_geom<R>;
+  const dim3 grid((unsigned)((ca.d.nx + G::TX - 1) / G::TX), (unsigned)((ca.d.ny + G::TY - 1) / G::TY), (unsigned)((ca.d.nz + G::TZ - 1) / G::TZ));
+  hipLaunchKernelGGL((k_cube_force_smooth<R>), grid, dim3(G::NTH), 0, ctx->stream, F, Mw_in, D, S, ca, K, partials, st, prev, nprev, max_rms);
+  return PP_OK;
+}
+template <int R>
+int launch_cube_warp(pp_ctx* ctx, const float* S, const float* M, float* Dn, float* Mw_out, const cube_args& ca, const pp_warp_scale& sc,
+                     const int* halt) {
+  pp_prof_scope ps(ctx, "k_cube_smooth_warp");
+  using G = cube_geom<R>;
+  const dim3 grid((unsigned)((ca.d.nx + G::TX - 1) / G::TX), (unsigned)((ca.d.ny + G::TY - 1) / G::TY), (unsigned)((ca.d.nz + G::TZ - 1) / G::TZ));
+  hipLaunchKernelGGL((k_cube_smooth_warp<R>), grid, dim3(G::NTH), 0, ctx->stream, S, M, Dn, Mw_out, ca, sc, halt);
+  return PP_OK;
+}
+// Up to this many bricks the launch is one block per CU or little more and lasts ~20 us per iteration (both kernels) against the
+// marching pair's 31 us floor; each further brick adds ~0.033 us (the halo's arithmetic: 3.1 x the update, 2.3 x the x pass), and
+// from ~420 bricks (250-600 k voxels) the two generations trade places by shape -- 87 x 80 x 57: 37 against 44 us, 96 x 96 x 48: 35
+// against 33 -- so the marching kernels keep everything beyond (profiles/round6_cube_levels.txt).  PP_FUSED_CUBE=1 / 0 forces /
+// forbids the bricks wherever they apply.
+constexpr size_t CUBE_MAX_BRICKS = 420;
+size_t cube_bricks(const pp_dims& d) {
+  using G = cube_geom<2>;   // (the brick shape is the same for every radius)
+  return (size_t)((d.nx + G::TX - 1) / G::TX) * ((d.ny + G::TY - 1) / G::TY) * ((d.nz + G::TZ - 1) / G::TZ);
+}
+
 // Mixed tile shapes (generation 2, SH == 2): 64 x 16 tiles wherever a whole 64-wide tile fits and ONE column of 32 x 32 tiles
 // over the rest, when that rest is at most 32 columns -- a 64-wide tile there would compute on >= 50 % overhang, and all
 // 32 x 32 tiles run a 15-20 % longer plane step.  Measured against the launcher's single shape (tools/r4/run24.sh, bit-identical
@@ -1372,6 +1403,19 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   }
   const int px = pitched ? (d.nx + 3) / 4 * 4 : d.nx;
   const size_t Np = (size_t)px * d.ny * d.nz;
+  // generation 3 for the latency-bound levels: the SUM pair's protocol, radii <= 2, dense rows
+  bool cube = gen_a == 2 && gen_b == 2 && sum_mode && !pitched && ra <= 2 && rb <= 2 && p->iterations > 0;
+  if (const char* e = pp_env("PP_FUSED_CUBE")) {
+    cube = cube && atoi(e) != 0;
+  } else {
+    // (a switch addressed to the marching kernels selects them: A/B runs and the tests of their variants keep their meaning)
+    for (const char* name : {"PP_FUSED_GEN", "PP_FUSED_TILE", "PP_FUSED_MASK", "PP_FUSED_MIX", "PP_FUSED_NT", "PP_FUSED_OPT", "PP_FUSED_PITCH",
+                             "PP_FUSED_SYNC", "PP_FUSED_ZCHUNK", "PP_FUSED_ZCHUNK_A", "PP_FUSED_ZCHUNK_B"})
+      if (pp_env(name)) cube = false;
+    cube = cube && cube_bricks(d) <= CUBE_MAX_BRICKS;
+  }
+  cube_args cu, cd;
+  cu.d = cd.d = d;
   // tile shape per kernel: 32 x 32 where the z-chunk model says the 64 x 16 launch wastes >= 10 % (512-thread layouts only)
   if (gen_a == 2) {
 #define PP_OCC_A20(RR) occ_force2<RR>(0)
@@ -1429,7 +1473,9 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   small_taps(td[0], rb, &fd.wx);
   small_taps(td[1], rb, &fd.wy);
   small_taps(td[2], rb, &fd.wz);
-  const size_t nblk = ((size_t)fu.gx * fu.gy + (size_t)fu.gx2 * fu.gy2) * fu.gz;
+  cu.wx = fu.wx; cu.wy = fu.wy; cu.wz = fu.wz;
+  cd.wx = fd.wx; cd.wy = fd.wy; cd.wz = fd.wz;
+  const size_t nblk = cube ? cube_bricks(d) : ((size_t)fu.gx * fu.gy + (size_t)fu.gx2 * fu.gy2) * fu.gz;
   constexpr size_t SYNC_WORDS = 8 * 64;   // per kernel: one word per resident block of each XCD (PP_SYNC_GROUP)
   const size_t need = (pitched ? 4 : 2) * pp_align_up(Np * 4, 256) + (pitched ? 3 : 2) * pp_align_up(3 * Np * 4, 256) +
                       2 * pp_align_up(3 * nblk * 8, 256) + 256 + pp_align_up(2 * SYNC_WORDS * sizeof(unsigned), 256);
@@ -1484,7 +1530,13 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     const float* Dcur = (it & 1) ? D2 : D1;
     float* Dnext = (it & 1) ? D1 : D2;
     // a failed first launch must not be masked by the second one's status
-    if (gen_a == 2) {
+    if (cube) {
+      double* const pcur = (it & 1) ? partials2 : partials;
+      const double* const pprev = (it & 1) ? partials : partials2;
+      const int np = it > 0 ? (int)nblk : 0;
+      rc = ra == 1 ? launch_cube_force<1>(ctx, fixed, mw_in, Dcur, Us, cu, K, pcur, dst, pprev, np, max_rms)
+                   : launch_cube_force<2>(ctx, fixed, mw_in, Dcur, Us, cu, K, pcur, dst, pprev, np, max_rms);
+    } else if (gen_a == 2) {
       double* const pcur = (it & 1) ? partials2 : partials;
       const double* const pprev = (it & 1) ? partials : partials2;
 #define PP_CALL_A2(RR) launch_force2<RR>(ctx, sh_a, sum_mode, fixed, mw_in, Dcur, Us, fu, K, pcur, dst, pprev, it > 0 ? (int)nblk : 0, max_rms)
@@ -1497,7 +1549,10 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     }
     PP_LAUNCH_CHECK(ctx, "k_fused_force_smooth");
     if (rc) return rc;
-    if (gen_b == 2) {
+    if (cube) {
+      rc = rb == 1 ? launch_cube_warp<1>(ctx, (const float*)Us, moving, Dnext, mw_out, cd, sc, halt)
+                   : launch_cube_warp<2>(ctx, (const float*)Us, moving, Dnext, mw_out, cd, sc, halt);
+    } else if (gen_b == 2) {
 #define PP_CALL_B2(RR) launch_warp2<RR>(ctx, sh_b, sum_mode, Dcur, (const float*)Us, moving, Dnext, mw_out, fd, sc, halt)
       rc = PP_BY_RADIUS_B2(rb, PP_CALL_B2);
 #undef PP_CALL_B2

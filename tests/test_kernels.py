@@ -532,6 +532,56 @@ def test_fused_demons_generations_agree(backend, grid, tile, monkeypatch):
     assert np.abs(out["2"][0]).max() > 0.1
 
 
+BRICKS = [GRIDS[1], ((9, 21, 67), (1.0, 1.1, 1.2), (0.0, 0.0, 0.0)), MIXED[0],   # (radii <= 2; odd rows: scalar stores)
+          ((20, 31, 38), (1.0, 1.2, 1.1), (5.0, 0.0, -3.0)),     # 4 x 4 x 3 bricks, every axis overhung
+          ((7, 8, 16), (1.1, 1.1, 1.1), (0.0, 0.0, 0.0)),        # one brick in x and y: every halo slot is a clamped one
+          ((5, 3, 4), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0))]         # smaller than the halo
+
+
+@pytest.mark.parametrize("grid", BRICKS)
+def test_fused_demons_bricks_equal_the_marching_kernels(backend, grid, monkeypatch):
+    """Round 6: the latency-bound pyramid levels run generation 3 (pp_demons_cube.h: a block owns a 16 x 8 x 6 brick with its
+    whole halo in LDS instead of marching a tile through z).  Same arithmetic voxel by voxel: the field -- and through the
+    following iterations the warped image, the sentinel voxels and the clamped halo -- equals generation 2's bit for bit,
+    with odd rows, overhung bricks and the RMS halt live; the statistics agree as sums grouped differently do."""
+    shape, spacing, origin = grid
+    fix = phantom(shape, seed=40)
+    dv = random_dvf(shape, spacing, seed=41, max_mm=2.5)
+    mov = O.warp_image(O.Vol(fix, spacing, origin), dv.astype(np.float64), edge_value=-1000.0).arr.astype(np.float32)
+    backend.ctx.profile_enable(True)
+    try:
+        rms4 = None
+        for iters, max_rms in ((3, 0.0), (4, 0.0), (12, None)):   # (the last leg halts early: a threshold just above iteration 4's RMS)
+            p = _demons_params(backend.ctx, iters, spacing, _lib.DEMONS_FUSED, max_rms=1.02 * rms4 if max_rms is None else max_rms)
+            out = {}
+            for cube in ("0", "1"):
+                monkeypatch.setenv("PP_FUSED_CUBE", cube)
+                backend.ctx.profile_read()
+                f = backend.empty((3,) + shape)
+                st = backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, f)
+                names = {k for k, v in backend.ctx.profile_read().items() if v[0] > 0}
+                assert ("k_cube_force_smooth" in names) == (cube == "1") and ("k_fused2_force_smooth" in names) == (cube == "0"), names
+                out[cube] = (backend.host(f).copy(), st.metric, st.rms_change, st.n_pixels, st.elapsed_iterations, st.halted)
+            np.testing.assert_array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32))
+            np.testing.assert_allclose(out["0"][1:3], out["1"][1:3], rtol=1e-6)
+            assert out["0"][3:] == out["1"][3:]
+            assert np.abs(out["1"][0]).max() > 0.05
+            if iters == 4:
+                rms4 = out["1"][2]
+            if iters == 12:
+                assert out["1"][5] == 1 and out["1"][4] < 12, out["1"][1:]
+    finally:
+        backend.ctx.profile_enable(False)
+    monkeypatch.delenv("PP_FUSED_CUBE")
+    f = backend.empty((3,) + shape)       # and the launcher picks the bricks by itself at these sizes
+    backend.ctx.profile_enable(True)
+    backend.ctx.demons_execute(backend.dev(fix), backend.dev(mov), geom_of(shape, spacing, origin), p, f)
+    names = {k for k, v in backend.ctx.profile_read().items() if v[0] > 0}
+    backend.ctx.profile_enable(False)
+    assert "k_cube_force_smooth" in names and "k_cube_smooth_warp" in names and "k_fused2_force_smooth" not in names, names
+    np.testing.assert_array_equal(backend.host(f).view(np.uint32), out["1"][0].view(np.uint32))
+
+
 def test_fused_demons_store_policy_does_not_change_the_field(backend, monkeypatch):
     """Generation 2 stores its outputs with a non-temporal hint on volumes far beyond the infinity cache (a template
     parameter chosen per launch); forcing either policy on a small grid gives the same bits, statistics included."""
