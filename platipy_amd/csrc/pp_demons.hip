@@ -1403,8 +1403,8 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
   }
   const int px = pitched ? (d.nx + 3) / 4 * 4 : d.nx;
   const size_t Np = (size_t)px * d.ny * d.nz;
-  // generation 3 for the latency-bound levels: the SUM pair's protocol, radii <= 2, dense rows
-  bool cube = gen_a == 2 && gen_b == 2 && sum_mode && !pitched && ra <= 2 && rb <= 2 && p->iterations > 0;
+  // generation 3 for the latency-bound levels: the SUM pair's protocol, radii <= 2 (update) / 3 (field), dense rows
+  bool cube = gen_a == 2 && gen_b == 2 && sum_mode && !pitched && ra <= 2 && rb <= 3 && p->iterations > 0;
   if (const char* e = pp_env("PP_FUSED_CUBE")) {
     cube = cube && atoi(e) != 0;
   } else {
@@ -1550,8 +1550,9 @@ int pp_demons_execute_f32(pp_ctx* ctx, const float* fixed, const float* moving, 
     PP_LAUNCH_CHECK(ctx, "k_fused_force_smooth");
     if (rc) return rc;
     if (cube) {
-      rc = rb == 1 ? launch_cube_warp<1>(ctx, (const float*)Us, moving, Dnext, mw_out, cd, sc, halt)
-                   : launch_cube_warp<2>(ctx, (const float*)Us, moving, Dnext, mw_out, cd, sc, halt);
+      rc = rb == 1   ? launch_cube_warp<1>(ctx, (const float*)Us, moving, Dnext, mw_out, cd, sc, halt)
+           : rb == 2 ? launch_cube_warp<2>(ctx, (const float*)Us, moving, Dnext, mw_out, cd, sc, halt)
+                     : launch_cube_warp<3>(ctx, (const float*)Us, moving, Dnext, mw_out, cd, sc, halt);
     } else if (gen_b == 2) {
 #define PP_CALL_B2(RR) launch_warp2<RR>(ctx, sh_b, sum_mode, Dcur, (const float*)Us, moving, Dnext, mw_out, fd, sc, halt)
       rc = PP_BY_RADIUS_B2(rb, PP_CALL_B2);

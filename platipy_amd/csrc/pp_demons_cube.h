@@ -12,8 +12,8 @@
 // halo slot holds its clamped neighbour's update: ZeroFluxNeumann on the smoothing input), each Gaussian pass a chain of fmaf
 // from 0 over taps -R .. +R, S = D + G_u * update, D' = G_d * S, the warp of kernel B -- fields bit-identical
 // (tests/test_kernels.py).  Same protocol as generation 2 in SUM mode: kernel A folds the previous launch's per-block sums and
-// evaluates FiniteDifferenceImageFilter::Halt() on device; kernel B reads the flag.  Radii <= 2 (sigma <= 1.55 voxels: the
-// pipelines' settings on grids of >= 0.97 mm).
+// evaluates FiniteDifferenceImageFilter::Halt() on device; kernel B reads the flag.  Radii <= 2 for the update (sigma_u = 1
+// voxel has 2) and <= 3 for the field (sigma_d <= 1.9 voxels: the pipelines' 1.5 mm on grids of >= 0.8 mm).
 
 template <int R>
 struct cube_geom {
@@ -34,7 +34,7 @@ struct cube_geom {
   static constexpr int SZ_Y = UZ * TY * TX;              // y pass output
   static constexpr int SZ_XY = (SZ_X + SZ_Y + 3) / 4 * 4;
   static constexpr int R1A = ((SZ_IMG > SZ_XY ? SZ_IMG : SZ_XY) + 3) / 4 * 4;   // kernel A: image bricks, then the passes
-  static_assert((R1A + SZ_U) * 4 <= 40960 && SZ_U * 4 >= 3 * (NTH / 64) * 8, "four blocks per CU; the fold's scratch");
+  static_assert(SZ_U * 4 >= 3 * (NTH / 64) * 8, "the fold's scratch");
 };
 
 struct cube_args {
@@ -115,6 +115,7 @@ __global__ void __launch_bounds__(cube_geom<R>::NTH) k_cube_force_smooth(const f
                                                                          int nprev, double max_rms) {
   using G = cube_geom<R>;
   constexpr int NTH = G::NTH;
+  static_assert((G::R1A + G::SZ_U) * 4 <= 40960, "four blocks per CU");
   __shared__ __attribute__((aligned(16))) float smem[G::R1A + G::SZ_U];
   float* const s_m = smem;
   float* const s_f = smem + G::NI;

@@ -608,8 +608,14 @@ class ItkRegularJitter:
 
 PACKED_GRADIENT_MIN_SAMPLES = 200_000
 
-_JITTER_CACHE = {}      # (device, seed, levels so far) -> device tensor; a handful of entries, oldest dropped first
-_JITTER_CACHE_MAX = 16
+# (device, seed, levels so far) -> device tensor.  Entries are NEVER evicted: a cached tensor is read by kernels on whatever
+# stream its caller runs on, while the allocator knows only the stream it was allocated on -- dropping one could hand its block
+# out again under another stream's kernel (the rule registration/utils.py::_need_masks follows since ADVICE round 3; until the
+# end of round 6 this cache dropped its oldest entry).  Past the bounds new levels are simply not cached; runtime.release_all()
+# empties the cache after a device synchronisation.
+_JITTER_CACHE = {}
+_JITTER_CACHE_MAX = 64
+_JITTER_CACHE_MAX_BYTES = 1 << 30
 _JITTER_LOCK = threading.Lock()
 
 
@@ -643,9 +649,9 @@ class _JitterSource:
         t = torch.from_numpy(self._gen.level(vsize, stride, vspacing, vdir)).to(self.device)
         self._drawn += 1
         with _JITTER_LOCK:
-            while len(_JITTER_CACHE) >= _JITTER_CACHE_MAX:
-                _JITTER_CACHE.pop(next(iter(_JITTER_CACHE)))
-            _JITTER_CACHE[key] = t
+            held = sum(v.numel() * v.element_size() for v in _JITTER_CACHE.values())
+            if len(_JITTER_CACHE) < _JITTER_CACHE_MAX and held + t.numel() * t.element_size() <= _JITTER_CACHE_MAX_BYTES:
+                return _JITTER_CACHE.setdefault(key, t)      # (the first thread's tensor serves everybody: one copy stays alive)
         return t
 
 

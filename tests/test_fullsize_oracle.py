@@ -283,13 +283,16 @@ def test_config5_eight_atlases_iterative_selection_256x256x128(ctx):
     wrong = ("002", "005")
     ids, atlases, target, label, st = _atlas_job(ctx, shape, 8, wrong=wrong)
     st["iar_settings"].update({"reference_structure": "HEART", "min_best_atlases": 4})
-    par, par_p, aset = run_segmentation(target, st, atlases=atlases, streams_per_gpu=4, return_atlas_set=True)
-    removed_par = list(run_segmentation.last_iar_removed)
-    seq, _ = run_segmentation(target, st, atlases=atlases, streams_per_gpu=1)
-    removed_seq = list(run_segmentation.last_iar_removed)
+    log = _ExecuteLog()
+    with log:
+        par, par_p, aset = run_segmentation(target, st, atlases=atlases, streams_per_gpu=4, return_atlas_set=True)
+        removed_par = list(run_segmentation.last_iar_removed)
+        log.next_run()
+        seq, _, aset_seq = run_segmentation(target, st, atlases=atlases, streams_per_gpu=1, return_atlas_set=True)
+        removed_seq = list(run_segmentation.last_iar_removed)
     assert sorted(removed_par) == sorted(removed_seq)
     assert set(wrong) <= set(removed_par) and len(removed_par) <= 4, removed_par
-    assert np.array_equal(par["HEART"].numpy(), seq["HEART"].numpy())
+    assert np.array_equal(par["HEART"].numpy(), seq["HEART"].numpy()), _first_deviation(aset, aset_seq) + log.report()
     # the oracle's Q metric of the first pass (iar.py:91-229) on the product's propagated labels, global-vote weights
     import platipy_amd as pa
 
@@ -313,6 +316,83 @@ def test_config5_eight_atlases_iterative_selection_256x256x128(ctx):
     assert stats["q_max_rel_diff"] <= 1e-3, stats
     assert set(sorted(q_o, key=q_o.get)[-2:]) == set(wrong)
     assert stats["dice_vs_template_label"] > 0.95, stats
+
+
+class _ExecuteLog:
+    """Diagnostics for a failing streams-equal-sequential assertion: every demons Execute of two runs -- level grid,
+    checksums of its inputs and of the field it returned -- so that the report names the levels whose INPUTS agree and
+    whose OUTPUT does not."""
+
+    def __init__(self):
+        import threading
+
+        self.rows, self.run, self.lock = [[], []], 0, threading.Lock()
+
+    def next_run(self):
+        self.run = 1
+
+    def __enter__(self):
+        from platipy_amd.registration import deformable
+
+        self._cls, self._orig = deformable.HipDemonsFilter, deformable.HipDemonsFilter.Execute
+        log = self
+
+        def execute(flt, f, m):
+            # (device-side checksums, read at report time: nothing here waits for the GPU, the schedule under test is unchanged)
+            key = (tuple(f.tensor.shape), f.tensor.double().sum(), m.tensor.double().sum())
+            out = log._orig(flt, f, m)
+            row = key + (out.tensor.double().abs().sum(),)
+            with log.lock:
+                log.rows[log.run].append(row)
+            return out
+
+        self._cls.Execute = execute
+        return self
+
+    def __exit__(self, *exc):
+        self._cls.Execute = self._orig
+
+    def report(self):
+        rows = [[(r[0], float(r[1]), float(r[2]), float(r[3])) for r in run] for run in self.rows]
+        a = {r[:3]: r[3] for r in rows[0]}
+        b = {r[:3]: r[3] for r in rows[1]}
+        lines = [f"level {k[0]} inputs {k[1]:.9g} / {k[2]:.9g}: |field| {a[k]:.12g} / {b[k]:.12g}" for k in a if k in b and a[k] != b[k]]
+        only = [f"{k[0]} inputs {k[1]:.9g} / {k[2]:.9g}" for k in a if k not in b]
+        return ("  ||  Execute calls with equal inputs and different outputs (run 1 / run 2): " + ("; ".join(lines) if lines else "none") +
+                "  ||  inputs seen in run 1 only: " + ("; ".join(only[:6]) if only else "none"))
+
+
+def _linear_parameters(t):
+    """The parameters of a (composite of) linear transform(s) as a flat tuple, or None for anything else."""
+    if t is None or hasattr(t, "field"):
+        return None
+    parts = getattr(t, "transforms", None)
+    if parts is not None:
+        flat = [_linear_parameters(p) for p in parts]
+        return None if any(f is None for f in flat) else tuple(v for f in flat for v in f)
+    return tuple(float(v) for v in t.GetParameters()) if hasattr(t, "GetParameters") else None
+
+
+def _first_deviation(a, b):
+    """Which propagated volumes of two atlas sets differ (stage / key / elements): names the stage a scheduling-dependent
+    result comes from."""
+    out = []
+    for cid in sorted(set(a) | set(b)):
+        for stage in ("RIR", "DIR"):
+            da, db = a.get(cid, {}).get(stage, {}), b.get(cid, {}).get(stage, {})
+            for key in sorted(set(da) | set(db)):
+                ta, tb = getattr(da.get(key), "tensor", None), getattr(db.get(key), "tensor", None)
+                if ta is None or tb is None:
+                    pa_, pb_ = _linear_parameters(da.get(key)), _linear_parameters(db.get(key))
+                    if pa_ is not None and pb_ is not None and pa_ != pb_:
+                        out.append(f"{cid}/{stage}/{key}: parameters differ by up to {max(abs(x - y) for x, y in zip(pa_, pb_)):.3g}")
+                    continue
+                if ta.shape != tb.shape:
+                    out.append(f"{cid}/{stage}/{key}: shapes {tuple(ta.shape)} / {tuple(tb.shape)}")
+                elif not torch.equal(ta, tb):
+                    d = (ta.float() - tb.float()).abs()
+                    out.append(f"{cid}/{stage}/{key}: {int((ta != tb).sum())} of {ta.numel()} differ, max {float(d.max()):.3g}")
+    return "atlas-set volumes that differ between the two runs: " + ("; ".join(out) if out else "none")
 
 
 def _crop_of(target, crop):

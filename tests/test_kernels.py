@@ -535,6 +535,7 @@ def test_fused_demons_generations_agree(backend, grid, tile, monkeypatch):
 BRICKS = [GRIDS[1], ((9, 21, 67), (1.0, 1.1, 1.2), (0.0, 0.0, 0.0)), MIXED[0],   # (radii <= 2; odd rows: scalar stores)
           ((20, 31, 38), (1.0, 1.2, 1.1), (5.0, 0.0, -3.0)),     # 4 x 4 x 3 bricks, every axis overhung
           ((7, 8, 16), (1.1, 1.1, 1.1), (0.0, 0.0, 0.0)),        # one brick in x and y: every halo slot is a clamped one
+          ((15, 19, 30), (0.85, 0.9, 2.0), (0.0, 0.0, 0.0)),     # sigma_d 1.76 / 1.67 / 0.75 voxels: field radius 3, 3, 1
           ((5, 3, 4), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0))]         # smaller than the halo
 
 
