@@ -734,3 +734,52 @@ def test_itk_gradient_image_kernels_match_the_oracle(backend):
     finally:
         ctx.set_moving_gradient(None)
     np.testing.assert_array_equal(np.array(ctx.meansq_affine(*args)), plain)
+
+
+def test_jitter_cache_never_drops_an_entry_and_serves_one_tensor_per_level():
+    """The per-level jitter tensors are shared by every registration (and worker thread) on the same grid.  A cached tensor is
+    read by kernels on its USER's stream while the allocator knows only the stream it was allocated on, so an entry is never
+    dropped while the process runs (round 6: an evicting cache let four streams' first chains deviate from the sequential run
+    on fresh boxes, profiles/round6_gpu_suite.txt): past the bounds new levels are simply not cached, threads that miss the same
+    key together all end up with the first one's tensor, and the variates stay ITK's whatever was served from the cache."""
+    import threading
+
+    import torch
+
+    from platipy_amd.registration import linear as L
+
+    L.release_cached_jitter()
+    dev = torch.device("cpu")
+    geoms = [((6 + k, 5, 4), 1, (2.0, 2.0, 3.0), np.eye(3)) for k in range(L._JITTER_CACHE_MAX + 5)]
+    try:
+        first = L._JitterSource(42, dev).level(*geoms[0])
+        for g in geoms[1:]:
+            L._JitterSource(42, dev).level(*g)
+        assert len(L._JITTER_CACHE) == L._JITTER_CACHE_MAX                      # full: the later geometries were not cached ...
+        assert L._JitterSource(42, dev).level(*geoms[0]) is first              # ... and the oldest entry is still the same tensor
+        late = L._JitterSource(42, dev).level(*geoms[-1])
+        assert late is not L._JitterSource(42, dev).level(*geoms[-1])          # uncached: private tensors, equal numbers
+        assert torch.equal(late, L._JitterSource(42, dev).level(*geoms[-1]))
+        # a second level after a cached first one consumes the first level's variates all the same
+        want = L.ItkRegularJitter(42)
+        want.level(*geoms[0])
+        second = ((5, 4, 3), 2, (4.0, 4.0, 6.0), np.eye(3))
+        src = L._JitterSource(42, dev)
+        assert src.level(*geoms[0]) is first
+        L.release_cached_jitter()
+        np.testing.assert_array_equal(src.level(*second).numpy(), want.level(*second))
+        # threads that miss one key together share one tensor afterwards
+        L.release_cached_jitter()
+        got, gate = [], threading.Barrier(4)
+
+        def worker():
+            s = L._JitterSource(7, dev)
+            gate.wait()
+            got.append(s.level(*geoms[3]))
+
+        threads = [threading.Thread(target=worker) for _ in range(4)]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        assert all(t is got[0] for t in got) and len(L._JITTER_CACHE) == 1
+    finally:
+        L.release_cached_jitter()
