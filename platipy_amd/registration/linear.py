@@ -558,11 +558,13 @@ def linear_registration(
     if not itk_sampling:
         params = _optimise_levels(ctx, None, **_level_args(locals()))
     else:
+        jitter_source = _JitterSource(sampling_seed, fixed_image.device)
         try:
-            params = _optimise_levels(ctx, _JitterSource(sampling_seed, fixed_image.device), **_level_args(locals()))
+            params = _optimise_levels(ctx, jitter_source, **_level_args(locals()))
         finally:
             ctx.set_sample_jitter(None)
             ctx.set_moving_gradient(None)
+            jitter_source.close()
     linear_registration.last_levels = record
 
     model.SetParameters(params)
@@ -608,13 +610,17 @@ class ItkRegularJitter:
 
 PACKED_GRADIENT_MIN_SAMPLES = 200_000
 
-# (device, seed, levels so far) -> device tensor.  Entries are NEVER evicted: a cached tensor is read by kernels on whatever
-# stream its caller runs on, while the allocator knows only the stream it was allocated on -- dropping one could hand its block
-# out again under another stream's kernel (the rule registration/utils.py::_need_masks follows since ADVICE round 3; until the
-# end of round 6 this cache dropped its oldest entry).  Past the bounds new levels are simply not cached; runtime.release_all()
-# empties the cache after a device synchronisation.
+# (device, seed, levels so far) -> device tensor.  Two rules, both learnt the hard way (profiles/round6_gpu_suite.txt: four atlas
+# chains started together deviated from the sequential run on 4 of 17 fresh boxes, and again on 1 of 7 with the cache off):
+#   * entries are NEVER evicted -- a cached tensor is read by kernels on whatever stream its caller runs on, while the allocator
+#     knows only the stream it was allocated on (the rule registration/utils.py::_need_masks follows since ADVICE round 3); past
+#     the bounds new levels are simply not cached, runtime.release_all() empties the cache after a device synchronisation;
+#   * a level is drawn and uploaded by ONE thread, under the lock: threads that miss the same key together wait for it instead
+#     of each uploading a private copy that is freed again when its level ends (the chains that deviated were exactly those
+#     running on such private copies; what goes wrong with them was not reconstructed).  A copy that cannot be cached (bounds
+#     reached) stays with its _JitterSource until close(), which waits for the stream before the allocator gets it back.
 _JITTER_CACHE = {}
-_JITTER_CACHE_MAX = 64
+_JITTER_CACHE_MAX = int(os.environ.get("PP_JITTER_CACHE_MAX", 64))      # (0: every registration draws and uploads its own levels)
 _JITTER_CACHE_MAX_BYTES = 1 << 30
 _JITTER_LOCK = threading.Lock()
 
@@ -631,16 +637,9 @@ class _JitterSource:
     atlas onto the same target grid with the same seed -- 1.5 M Mersenne-Twister draws per registration otherwise."""
 
     def __init__(self, seed, device):
-        self.seed, self.device, self.history, self._gen, self._drawn = int(seed), device, (), None, 0
+        self.seed, self.device, self.history, self._gen, self._drawn, self._private = int(seed), device, (), None, 0, []
 
-    def level(self, vsize, stride, vspacing, vdir):
-        here = (tuple(int(v) for v in vsize), int(stride), tuple(float(v) for v in vspacing), tuple(float(v) for v in np.ravel(vdir)))
-        self.history = self.history + (here,)
-        key = (str(self.device), self.seed, self.history)
-        with _JITTER_LOCK:
-            hit = _JITTER_CACHE.get(key)
-        if hit is not None:
-            return hit
+    def _draw(self, vsize, stride, vspacing, vdir):
         if self._gen is None:
             self._gen = ItkRegularJitter(self.seed)
         while self._drawn < len(self.history) - 1:      # levels served from the cache: their variates still have to be consumed
@@ -648,11 +647,33 @@ class _JitterSource:
             self._drawn += 1
         t = torch.from_numpy(self._gen.level(vsize, stride, vspacing, vdir)).to(self.device)
         self._drawn += 1
-        with _JITTER_LOCK:
-            held = sum(v.numel() * v.element_size() for v in _JITTER_CACHE.values())
-            if len(_JITTER_CACHE) < _JITTER_CACHE_MAX and held + t.numel() * t.element_size() <= _JITTER_CACHE_MAX_BYTES:
-                return _JITTER_CACHE.setdefault(key, t)      # (the first thread's tensor serves everybody: one copy stays alive)
         return t
+
+    def level(self, vsize, stride, vspacing, vdir):
+        here = (tuple(int(v) for v in vsize), int(stride), tuple(float(v) for v in vspacing), tuple(float(v) for v in np.ravel(vdir)))
+        self.history = self.history + (here,)
+        key = (str(self.device), self.seed, self.history)
+        with _JITTER_LOCK:
+            hit = _JITTER_CACHE.get(key)
+            if hit is not None:
+                return hit
+            nv = int(vsize[0]) * int(vsize[1]) * int(vsize[2])
+            nbytes = 12 * ((nv + int(stride) - 1) // int(stride))
+            held = sum(v.numel() * v.element_size() for v in _JITTER_CACHE.values())
+            if len(_JITTER_CACHE) < _JITTER_CACHE_MAX and held + nbytes <= _JITTER_CACHE_MAX_BYTES:
+                t = self._draw(vsize, stride, vspacing, vdir)       # (under the lock: the others wait for this upload, then hit)
+                _JITTER_CACHE[key] = t
+                return t
+        t = self._draw(vsize, stride, vspacing, vdir)
+        self._private.append(t)
+        return t
+
+    def close(self):
+        """End of the registration: uncached levels go back to the allocator only once the stream has finished with them."""
+        if self._private:
+            if torch.device(self.device).type == "cuda":
+                torch.cuda.current_stream(torch.device(self.device)).synchronize()
+            self._private.clear()
 
 
 def itk_moving_gradient(ctx, moving):
