@@ -645,7 +645,23 @@ class _JitterSource:
         while self._drawn < len(self.history) - 1:      # levels served from the cache: their variates still have to be consumed
             self._gen.level(*self.history[self._drawn][:3], np.asarray(self.history[self._drawn][3]).reshape(3, 3))
             self._drawn += 1
-        t = torch.from_numpy(self._gen.level(vsize, stride, vspacing, vdir)).to(self.device)
+        host = self._gen.level(vsize, stride, vspacing, vdir)
+        t = torch.from_numpy(host).to(self.device)
+        if t.is_cuda:
+            # The one array of this path that reaches the GPU through a host-to-device copy, and the one the unexplained
+            # deviation of concurrently uploaded copies points at (profiles/round6_gpu_suite.txt): hold the upload to the host
+            # array's sum -- one reduction per level and geometry -- and repeat it once, loudly, if it does not arrive whole.
+            want = float(host.sum(dtype=np.float64))
+            tol = 1e-9 * float(np.abs(host).sum(dtype=np.float64)) + 1e-12
+            if abs(float(t.sum(dtype=torch.float64)) - want) > tol:
+                import warnings
+
+                warnings.warn("platipy_amd: a sample-jitter upload did not arrive whole; uploading it again", RuntimeWarning)
+                t = torch.from_numpy(host).to(self.device)
+                if abs(float(t.sum(dtype=torch.float64)) - want) > tol:
+                    from .._lib import PlatipyAmdError
+
+                    raise PlatipyAmdError("the sample-jitter array could not be uploaded intact")
         self._drawn += 1
         return t
 
